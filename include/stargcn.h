@@ -1,0 +1,205 @@
+/*
+ * stargcn.h -- C ABI of libstargcn_hip.so: the MI355X (gfx950) replacement for the STAR-GCN
+ * multi-link graph-conv hot path.
+ *
+ * Boundary being replaced: the MXNet NNVM operators `_contrib_seg_*` registered in
+ * reference/seg_ops_cuda/mxnet_op/seg_op.cc:339-861 (FCompute signature seg_op.h:461-465; GPU attach
+ * seg_op.cu:1353-1390) and the `mxgraph._graph_sampler` CPython helpers
+ * (reference/GraphSampler/py_ext.cpp:612-627) that produce their integer inputs.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + int64 sizes, no framework types.  `_hip` functions take DEVICE pointers and
+ *     enqueue on `stream` (a hipStream_t, NULL = default stream) WITHOUT synchronising; `_cpu`
+ *     functions take HOST pointers and are host-side plan/graph helpers (no floating-point hot path
+ *     has a CPU implementation in this library: a missing GPU is an error, never a fallback).
+ *   - data is fp32, indices are int32 (reference seg_op.h:232-233, 410-413); element offsets are
+ *     64-bit internally (the reference is int32 and caps K*N*C < 2^31, seg_op.cu:825-831).
+ *   - `req` uses MXNet OpReqType values (reference seg_op.cc:188-196): 0 kNullOp = do nothing,
+ *     1 kWriteTo = overwrite dst, 3 kAddTo = accumulate into dst.
+ *   - return 0 on success or a negative SG_ERR_* code; sg_last_error() gives the thread-local message.
+ *     Nothing in this library calls exit() (the reference does: seg_op.cu:14-18).
+ *   - the caller owns every buffer; `workspace` may be NULL when sg_*_workspace_bytes() returns 0.
+ */
+#ifndef STARGCN_H_
+#define STARGCN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_REQ_NULL 0
+#define SG_REQ_WRITE 1
+#define SG_REQ_ADD 3
+
+#define SG_OK 0
+#define SG_ERR_INVALID (-1)   /* bad argument (shape / req / enum) */
+#define SG_ERR_UNSUPPORTED (-2) /* e.g. kAddTo on seg_pool / seg_softmax forward, as the reference */
+#define SG_ERR_ALLOC (-3)
+#define SG_ERR_VALUE (-4)     /* data-dependent failure (e.g. rating value matches no link) */
+#define SG_ERR_WORKSPACE (-5) /* workspace too small */
+#define SG_ERR_HIP (-6)       /* HIP runtime / launch error */
+
+#define SG_POOL_SUM 0
+#define SG_POOL_AVG 1
+#define SG_POOL_MAX 2
+
+#define SG_ACT_NONE 0
+#define SG_ACT_LEAKY 1 /* x>0 ? x : slope*x ; reference common.py:47 uses slope 0.1 */
+#define SG_ACT_RELU 2
+#define SG_ACT_SIGMOID 3
+#define SG_ACT_TANH 4
+
+const char* sg_last_error(void);
+int sg_version(void);
+/* number of visible HIP devices, or a negative SG_ERR_HIP */
+int sg_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (1) seg_weighted_pool forward  == reference `_contrib_seg_weighted_pool`
+ *     seg_op.cc:665-716, adapter seg_op.h:460-476, CPU kernel seg_op.cc:180-207, GPU seg_op.cu:682-722.
+ *       dst[b,i,:] (+)= sum_{j=indptr[i]}^{indptr[i+1]-1} weights[b,j] * data[b, indices[j], :]
+ *     data (batch,total_ind_num,feat_dim)  weights (batch,nnz)  indices (nnz)  indptr (seg_num+1)
+ *     dst (batch,seg_num,feat_dim).  Edges at positions >= indptr[seg_num] are ignored.
+ * ---------------------------------------------------------------------------------------------- */
+size_t sg_seg_weighted_pool_workspace_bytes(int64_t batch, int64_t seg_num, int64_t nnz, int64_t feat_dim);
+int sg_seg_weighted_pool_hip(float* dst, const float* data, const float* weights, const int32_t* indices,
+                             const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t total_ind_num,
+                             int64_t nnz, int64_t feat_dim, int req, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+/* Strided / grouped form of (1) used by the fused multi-link aggregator (batch = 1):
+ *   segment s writes   dst + (s / dst_group) * dst_ld + (s % dst_group) * feat_dim
+ *   index q reads      src + (q / src_group) * src_ld + (q % src_group) * feat_dim
+ * so R per-rating-level aggregates of one destination node land side by side in one row of a
+ * (N_dst, R*feat_dim [+pad]) matrix that feeds the MFMA contraction directly.  weights may be NULL
+ * (all ones = seg_pool 'sum').  `act`/`slope` (SG_ACT_*) fuse the aggregator activation
+ * (reference aggregators.py:160) into the row store: dst = act(sum (+ dst if req = add)).  */
+int sg_seg_gather_sum_hip(float* dst, int64_t dst_group, int64_t dst_ld, const float* src, int64_t src_group,
+                          int64_t src_ld, const float* weights, const int32_t* indices, const int32_t* indptr,
+                          int64_t seg_num, int64_t nnz, int64_t feat_dim, int req, int act, float slope,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (2) gradient of (1) w.r.t. data == reference `_contrib__backward_seg_take_k_corr_embed2(weights,
+ *     ograd, indices, indptr)` seg_op.cc:700-703,718-752; CPU kernel :209-240; GPU seg_op.cu:747-790,
+ *     882-926 (which radix-sorts the edges on EVERY call).
+ *       ddata[b, indices[j], :] (+)= weights[b,j] * ograd[b, seg(j), :]
+ *     Here the sort is hoisted into a reusable transposed plan (stable => same per-row summation
+ *     order as the reference): t_indptr (total_ind_num+1), t_pos (nnz_t: original edge position j,
+ *     increasing within a row), t_seg (nnz_t: segment of that edge).  Build it once with
+ *     sg_build_transpose_cpu (plan construction is host-side, as gen_plan is in the reference,
+ *     layers.py:260-337) and pass it on every call.
+ *     Padding edges (j >= indptr[seg_num]) are ignored (true gradient of (1)); the reference CPU path
+ *     charges them to segment 0 and its GPU path to the last non-empty segment.
+ * ---------------------------------------------------------------------------------------------- */
+size_t sg_seg_weighted_pool_bwd_data_workspace_bytes(int64_t batch, int64_t total_ind_num, int64_t nnz,
+                                                     int64_t feat_dim);
+int sg_seg_weighted_pool_bwd_data_hip(float* ddata, const float* weights, const float* ograd,
+                                      const int32_t* t_indptr, const int32_t* t_pos, const int32_t* t_seg,
+                                      int64_t batch, int64_t seg_num, int64_t total_ind_num, int64_t nnz,
+                                      int64_t feat_dim, int req, void* workspace, size_t workspace_bytes,
+                                      void* stream);
+/* host: stable counting sort of the covered edges by indices[j]; outputs sized total_ind_num+1 / nnz / nnz */
+int sg_build_transpose_cpu(int32_t* t_indptr, int32_t* t_pos, int32_t* t_seg, const int32_t* indices,
+                           const int32_t* indptr, int64_t seg_num, int64_t total_ind_num, int64_t nnz);
+
+/* ------------------------------------------------------------------------------------------------
+ * (3) seg_take_k_corr == reference `_contrib_seg_take_k_corr` seg_op.cc:602-663, CPU :150-178,
+ *     GPU seg_op.cu:573-664.  Also the gradient of (1) w.r.t. weights (seg_op.cc:703).
+ *       dst[k,j] (+)= sum_c embed1[k, seg(j), c] * embed2[k, neighbor_ids[j], c]
+ *     embed1 (K,node_num,C) embed2 (K,neighbor_node_num,C) -> dst (K,nnz); uncovered j get 0 on write.
+ * ---------------------------------------------------------------------------------------------- */
+int sg_seg_take_k_corr_hip(float* dst, const float* embed1, const float* embed2, const int32_t* neighbor_ids,
+                           const int32_t* neighbor_indptr, int64_t K, int64_t node_num,
+                           int64_t neighbor_node_num, int64_t nnz, int64_t feat_dim, int req, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (4) remaining segment-operator surface (reference seg_op.cc:339-600, 754-861)
+ * ---------------------------------------------------------------------------------------------- */
+/* seg_sum: data (B,nnz) -> dst (B,S)   [seg_op.cc:7-50] */
+int sg_seg_sum_hip(float* dst, const float* data, const int32_t* indptr, int64_t batch, int64_t seg_num,
+                   int64_t nnz, int req, void* stream);
+/* seg_broadcast_{add,mul,to}: op 0 add, 1 mul, 2 to (lhs ignored)  [seg_op.cc:52-78]
+ * dst[b,j] (+)= OP(lhs[b,j], rhs[b,seg(j)]) for covered j; on write, uncovered j get 0. */
+int sg_seg_broadcast_hip(float* dst, const float* lhs, const float* rhs, const int32_t* indptr, int64_t batch,
+                         int64_t seg_num, int64_t nnz, int op, int req, void* stream);
+/* seg_softmax forward / backward  [seg_op.cc:80-148]; forward rejects kAddTo like the reference */
+int sg_seg_softmax_hip(float* dst, const float* data, const int32_t* indptr, int64_t batch, int64_t seg_num,
+                       int64_t nnz, int req, void* stream);
+int sg_seg_softmax_bwd_hip(float* dst, const float* ograd, const float* val, const int32_t* indptr,
+                           int64_t batch, int64_t seg_num, int64_t nnz, int req, void* stream);
+/* seg_pool forward (sum/avg/max) [seg_op.cc:242-297]; pool_indices (B,S,C) int32 required for max:
+ * argmax is the EDGE POSITION j, first maximum wins, empty segment -> value 0 / index -1. */
+size_t sg_seg_pool_workspace_bytes(int64_t batch, int64_t seg_num, int64_t nnz, int64_t feat_dim);
+int sg_seg_pool_hip(float* dst, int32_t* pool_indices, const float* data, const int32_t* indices,
+                    const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t total_ind_num, int64_t nnz,
+                    int64_t feat_dim, int pool_type, int req, void* workspace, size_t workspace_bytes,
+                    void* stream);
+/* seg_pool backward [seg_op.cc:299-332], through the transposed plan of (2) */
+size_t sg_seg_pool_bwd_workspace_bytes(int64_t batch, int64_t total_ind_num, int64_t nnz, int64_t feat_dim);
+int sg_seg_pool_bwd_hip(float* ddata, const float* ograd, const int32_t* pool_indices, const int32_t* indptr,
+                        const int32_t* t_indptr, const int32_t* t_pos, const int32_t* t_seg, int64_t batch,
+                        int64_t seg_num, int64_t total_ind_num, int64_t nnz, int64_t feat_dim, int pool_type,
+                        int req, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (5) per-rating-level dense mix: fp32 MFMA GEMM with fused bias / activation epilogue.
+ *     Replaces MXNet FullyConnected/Dense at reference aggregators.py:141-145, layers.py:120,183,
+ *     STAR-GCN.py:241-245,257.  Row-major:
+ *       C[M,N] = act( opA(A)[M,K] * opB(B)[K,N] + bias[N] (+ C if accumulate) )
+ *     transA = 0: A is (M,K) with leading dim lda;  1: A is stored (K,M).
+ *     transB = 0: B is (K,N) with leading dim ldb;  1: B is stored (N,K)  (Linear weight layout).
+ *     v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (no TF32 on gfx950).
+ * ---------------------------------------------------------------------------------------------- */
+size_t sg_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K, int transA);
+int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, int transA, const float* B,
+                    int64_t ldb, int transB, int64_t M, int64_t N, int64_t K, const float* bias, int act,
+                    float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* dpre = dout * act'(.) evaluated from the activation OUTPUT `out` (all supported activations allow it) */
+int sg_act_bwd_hip(float* dpre, const float* dout, const float* out, int64_t n, int act, float slope,
+                   void* stream);
+/* dst[N] (+)= column sums of X (M,N) with leading dim ldx (bias gradient) */
+size_t sg_colsum_workspace_bytes(int64_t M, int64_t N);
+int sg_colsum_hip(float* dst, const float* X, int64_t ldx, int64_t M, int64_t N, int req, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (6) masked embedding gather (reference STAR-GCN.py:264-300 Net.get_embed) and row take / its grad
+ *       id' = noise ? noise[ids[i]] : ids[i];  out[i,:] = (id' == -1) ? 0 : table[id', :]
+ * ---------------------------------------------------------------------------------------------- */
+int sg_masked_embed_hip(float* out, const float* table, const int32_t* ids, const int32_t* noise,
+                        int64_t n_ids, int64_t n_rows, int64_t dim, void* stream);
+/* dtable[id', :] += dout[i,:] (atomic-free: through a transposed plan built on (ids -> id')) is done by
+ * calling sg_seg_gather_sum_hip on the plan; this helper resolves id' for plan building. */
+int sg_resolve_ids_hip(int32_t* resolved, const int32_t* ids, const int32_t* noise, int64_t n_ids,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (7) host graph helpers (reference GraphSampler/graph_sampler.cpp; `_cpu` = host pointers)
+ * ---------------------------------------------------------------------------------------------- */
+/* get_support  graph_sampler.cpp:393-420 */
+int sg_get_support_cpu(float* support, const int32_t* row_degrees, const int32_t* col_degrees,
+                       const int32_t* end_points, const int32_t* ind_ptr, int64_t row_num, int symm);
+/* multi_link_split_by_value  graph_sampler.cpp:277-376: out_pos (nnz) holds, level after level, the edge
+ * positions of each level in CSR order; out_indptr (num_links*(row_num+1)); level_off (num_links+1). */
+int sg_multi_link_split_cpu(int32_t* out_pos, int32_t* out_indptr, int64_t* level_off, const float* values,
+                            const int32_t* ind_ptr, const float* multi_link, int64_t row_num,
+                            int64_t num_links);
+/* Fuse R per-level CSRs (the end_points_l / indptr_l / support_l lists of reference
+ * aggregators.py:111-149) into ONE CSR over n_dst*R segments (segment i*R+r = level r of node i), and
+ * its transpose over n_src*R segments whose indices are destination NODES i.  Sizes:
+ * c_indptr n_dst*R+1, t_indptr n_src*R+1, c_idx/c_q/c_w/t_idx/t_q/t_w: sum_r indptr_l[r][n_dst].
+ * c_q = c_idx*R + r and t_q = t_idx*R + r (may be NULL) address the row of level r inside an R-expanded
+ * (N, R*width) matrix, so the same edge arrays also serve the un-split CSRs c_indptr[::R] / t_indptr[::R]. */
+int sg_multilink_fuse_cpu(int32_t* c_indptr, int32_t* c_idx, int32_t* c_q, float* c_w, int32_t* t_indptr,
+                          int32_t* t_idx, int32_t* t_q, float* t_w, const int32_t* const* end_points_l,
+                          const int32_t* const* indptr_l, const float* const* support_l, int64_t num_links,
+                          int64_t n_dst, int64_t n_src);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARGCN_H_ */

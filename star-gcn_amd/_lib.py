@@ -1,0 +1,142 @@
+"""ctypes binding of libstargcn_hip.so (C ABI: include/stargcn.h).
+
+There is deliberately NO fallback: if the shared library is missing, or a HIP device is not available when
+an operator is called, an exception is raised.  PyTorch is used only as plumbing (device memory, streams).
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # imported first so libamdhip64 (SONAME libamdhip64.so.7) is the one torch ships
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libstargcn_hip.so")
+
+REQ_NULL, REQ_WRITE, REQ_ADD = 0, 1, 3
+POOL = {"sum": 0, "avg": 1, "max": 2}
+ACT = {None: 0, "identity": 0, "none": 0, "leaky": 1, "relu": 2, "sigmoid": 3, "tanh": 4}
+
+
+class StarGCNError(RuntimeError):
+    """Raised when a libstargcn_hip entry point returns a negative status (message = sg_last_error())."""
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=None if verbose else subprocess.DEVNULL)
+    return SO_PATH
+
+
+_c = ctypes
+_P, _I64, _INT, _F32, _SZ = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes)   -- kept in the order of include/stargcn.h
+_SIGS = {
+    "sg_last_error": (_c.c_char_p, []),
+    "sg_version": (_INT, []),
+    "sg_device_count": (_INT, []),
+    "sg_seg_weighted_pool_workspace_bytes": (_SZ, [_I64] * 4),
+    "sg_seg_weighted_pool_hip": (_INT, [_P] * 5 + [_I64] * 5 + [_INT, _P, _SZ, _P]),
+    "sg_seg_gather_sum_hip": (_INT, [_P, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _F32,
+                                     _P, _SZ, _P]),
+    "sg_seg_weighted_pool_bwd_data_workspace_bytes": (_SZ, [_I64] * 4),
+    "sg_seg_weighted_pool_bwd_data_hip": (_INT, [_P] * 6 + [_I64] * 5 + [_INT, _P, _SZ, _P]),
+    "sg_build_transpose_cpu": (_INT, [_P] * 5 + [_I64] * 3),
+    "sg_seg_take_k_corr_hip": (_INT, [_P] * 5 + [_I64] * 5 + [_INT, _P]),
+    "sg_seg_sum_hip": (_INT, [_P] * 3 + [_I64] * 3 + [_INT, _P]),
+    "sg_seg_broadcast_hip": (_INT, [_P] * 4 + [_I64] * 3 + [_INT, _INT, _P]),
+    "sg_seg_softmax_hip": (_INT, [_P] * 3 + [_I64] * 3 + [_INT, _P]),
+    "sg_seg_softmax_bwd_hip": (_INT, [_P] * 4 + [_I64] * 3 + [_INT, _P]),
+    "sg_seg_pool_workspace_bytes": (_SZ, [_I64] * 4),
+    "sg_seg_pool_hip": (_INT, [_P] * 5 + [_I64] * 5 + [_INT, _INT, _P, _SZ, _P]),
+    "sg_seg_pool_bwd_workspace_bytes": (_SZ, [_I64] * 4),
+    "sg_seg_pool_bwd_hip": (_INT, [_P] * 7 + [_I64] * 5 + [_INT, _INT, _P, _SZ, _P]),
+    "sg_gemm_f32_workspace_bytes": (_SZ, [_I64, _I64, _I64, _INT]),
+    "sg_gemm_f32_hip": (_INT, [_P, _I64, _P, _I64, _INT, _P, _I64, _INT, _I64, _I64, _I64, _P, _INT, _F32, _INT,
+                               _P, _SZ, _P]),
+    "sg_act_bwd_hip": (_INT, [_P, _P, _P, _I64, _INT, _F32, _P]),
+    "sg_colsum_workspace_bytes": (_SZ, [_I64, _I64]),
+    "sg_colsum_hip": (_INT, [_P, _P, _I64, _I64, _I64, _INT, _P, _SZ, _P]),
+    "sg_masked_embed_hip": (_INT, [_P] * 4 + [_I64] * 3 + [_P]),
+    "sg_resolve_ids_hip": (_INT, [_P] * 3 + [_I64, _P]),
+    "sg_get_support_cpu": (_INT, [_P] * 5 + [_I64, _INT]),
+    "sg_multi_link_split_cpu": (_INT, [_P] * 6 + [_I64, _I64]),
+    "sg_multilink_fuse_cpu": (_INT, [_P] * 11 + [_I64] * 3),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises ImportError with the build hint if absent)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError("libstargcn_hip.so is missing (%s). Build it with `python -c 'import "
+                              "__graft_entry__ as g; g.build()'` or `make -C star-gcn_amd/csrc`. There is no "
+                              "CPU fallback." % SO_PATH)
+        handle = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGS)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().sg_last_error()
+        raise StarGCNError("%s failed (%d): %s" % (what or "libstargcn_hip", rc, msg.decode() if msg else "?"))
+
+
+def require_gpu(*tensors):
+    if not torch.cuda.is_available():
+        raise StarGCNError("no HIP device available: the STAR-GCN hot path only runs on the GPU (no CPU fallback)")
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise StarGCNError("expected a CUDA/HIP tensor, got a %s tensor" % t.device)
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Per-(device, stream) scratch buffer; kernels are stream-ordered so reuse across calls is safe."""
+    if nbytes <= 0:
+        return None, 0
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf, buf.numel()
+
+
+def f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def i32c(t):
+    if t.dtype != torch.int32:
+        t = t.to(torch.int32)
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,390 @@
+// gemm_f32.hip -- fp32 MFMA GEMM with fused bias / activation epilogue for gfx950.
+//
+// The per-rating-level dense mix of the multi-link graph conv (reference aggregators.py:141-145 runs R
+// separate MXNet FullyConnected calls BEFORE aggregation) is done here as ONE contraction AFTER aggregation:
+//   pre[N_dst, U] = Zext[N_dst, R*D + pad] * Wext[U, R*D + pad]^T
+// and the same kernel serves the output Dense (layers.py:183), the decoder embed_maps
+// (STAR-GCN.py:241-245) and the rating projections (:257), plus all their gradients (NN / TN forms).
+//
+//   C[M,N] = act( opA(A)[M,K] * opB(B)[K,N] + bias[N] (+ C) ),   row-major.
+//
+// CDNA4 mapping: v_mfma_f32_32x32x2_f32 (exact fp32 products and fp32 accumulation -- gfx950 has no
+// TF32/xf32 path, and the 1e-5 parity budget rules out bf16), 128x128x32 block tile, 256 threads = 4 waves
+// in a 2x2 arrangement, each wave a 64x64 sub-tile = 2x2 MFMA tiles (64 accumulator registers).  Both
+// operands are staged in LDS K-MAJOR ([k][m] / [k][n]) so that an MFMA operand read is 32 consecutive
+// floats per half-wave (bank-conflict free) whatever the global layout; K-contiguous global operands are
+// transposed on the way in (LDS leading dim 129 makes those b32 stores conflict-free), M/N-contiguous ones
+// are copied with b128 stores (leading dim 132).  Global loads of tile t+1 are issued before the MFMAs of
+// tile t and written to the other LDS buffer afterwards: one barrier per K tile.  Workgroups are remapped so
+// that the tiles sharing an A row-panel run on the same XCD (private 4 MiB L2 each).  Small-tile-count /
+// large-K problems (weight gradients: K = #nodes) use deterministic split-K through a workspace.
+#include "common.hpp"
+
+namespace sg {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int kThreads = 256;
+constexpr int LD_T = BM + 1;  // leading dim when the operand is transposed on the way into LDS
+constexpr int LD_D = BM + 4;  // leading dim for direct (b128) stores
+constexpr int LD_MAX = LD_D;
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct GemmArgs {
+  float* C;
+  const float* A;
+  const float* B;
+  const float* bias;
+  float* ws;  // split-K partials [splits][M][N]
+  long long lda, ldb, ldc;
+  int M, N, K;
+  int act;
+  float slope;
+  int accumulate;
+  int splits, tiles_per_split;
+  int tiles_m, tiles_n;
+  int vecA, vecB;  // 16-byte vector loads allowed
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case SG_ACT_LEAKY: return v > 0.f ? v : slope * v;
+    case SG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case SG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case SG_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// Loads the (rows x BK) slab of a K-CONTIGUOUS operand (element (r,k) at p[r*ld + k]) for this thread:
+// 4 float4 = rows (t/8 + 32*i), k = 4*(t%8)..+3.
+__device__ __forceinline__ void gload_kcontig(float (&r)[4][4], const float* __restrict__ p, long long ld, int row0,
+                                              int k0, int R, int K, int vec, int t) {
+  const int kc = (t & 7) * 4;
+  const int rr = t >> 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = row0 + rr + 32 * i;
+    const int k = k0 + kc;
+    if (row < R && vec && k + 3 < K) {
+      const float4 v = *reinterpret_cast<const float4*>(p + static_cast<long long>(row) * ld + k);
+      r[i][0] = v.x; r[i][1] = v.y; r[i][2] = v.z; r[i][3] = v.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        r[i][j] = (row < R && k + j < K) ? p[static_cast<long long>(row) * ld + k + j] : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void sstore_kcontig(float* __restrict__ s, const float (&r)[4][4], int t) {
+  const int kc = (t & 7) * 4;
+  const int rr = t >> 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[(kc + j) * LD_T + rr + 32 * i] = r[i][j];
+}
+
+// Loads the (BK x cols) slab of an M/N-CONTIGUOUS operand (element (k,c) at p[k*ld + c]):
+// 4 float4 = k rows (t/32 + 8*i), c = 4*(t%32)..+3.
+__device__ __forceinline__ void gload_mcontig(float (&r)[4][4], const float* __restrict__ p, long long ld, int col0,
+                                              int k0, int Ccols, int K, int vec, int t) {
+  const int cc = (t & 31) * 4;
+  const int kr = t >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + kr + 8 * i;
+    const int c = col0 + cc;
+    if (k < K && vec && c + 3 < Ccols) {
+      const float4 v = *reinterpret_cast<const float4*>(p + static_cast<long long>(k) * ld + c);
+      r[i][0] = v.x; r[i][1] = v.y; r[i][2] = v.z; r[i][3] = v.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        r[i][j] = (k < K && c + j < Ccols) ? p[static_cast<long long>(k) * ld + c + j] : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void sstore_mcontig(float* __restrict__ s, const float (&r)[4][4], int t) {
+  const int cc = (t & 31) * 4;
+  const int kr = t >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 v = make_float4(r[i][0], r[i][1], r[i][2], r[i][3]);
+    *reinterpret_cast<float4*>(s + (kr + 8 * i) * LD_D + cc) = v;
+  }
+}
+
+// TA: A is stored (K,M) (M-contiguous).  TB: B is stored (N,K) (K-contiguous, Linear weight layout).
+template <bool TA, bool TB>
+__global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float sA[2][BK * LD_MAX];
+  __shared__ __attribute__((aligned(16))) float sB[2][BK * LD_MAX];
+  constexpr int LDA_S = TA ? LD_D : LD_T;   // A K-contiguous (TA = false) -> transposing store
+  constexpr int LDB_S = TB ? LD_T : LD_D;   // B K-contiguous (TB = true)  -> transposing store
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware bijective remap: hardware places block b on XCD b % 8; give each XCD a contiguous run of
+  // logical tiles (n fastest) so tiles sharing an A row-panel hit the same L2.
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = wg / g.tiles_n, tn = wg - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int z = blockIdx.y;
+  const int ktiles = (g.K + BK - 1) / BK;
+  const int kt_begin = z * g.tiles_per_split;
+  const int kt_end = min(ktiles, kt_begin + g.tiles_per_split);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float ra[4][4], rb[4][4];
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK;
+    if (TA) gload_mcontig(ra, g.A, g.lda, m0, k0, g.M, g.K, g.vecA, t);
+    else gload_kcontig(ra, g.A, g.lda, m0, k0, g.M, g.K, g.vecA, t);
+    if (TB) gload_kcontig(rb, g.B, g.ldb, n0, k0, g.N, g.K, g.vecB, t);
+    else gload_mcontig(rb, g.B, g.ldb, n0, k0, g.N, g.K, g.vecB, t);
+  };
+  auto sstore = [&](int buf) {
+    if (TA) sstore_mcontig(sA[buf], ra, t); else sstore_kcontig(sA[buf], ra, t);
+    if (TB) sstore_kcontig(sB[buf], rb, t); else sstore_mcontig(sB[buf], rb, t);
+  };
+
+  if (kt_begin < kt_end) {
+    gload(kt_begin);
+    sstore(0);
+  }
+  __syncthreads();
+  const int kh = lane >> 5;   // which k of the pair this lane supplies
+  const int l31 = lane & 31;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = (kt + 1 < kt_end);
+    if (more) gload(kt + 1);
+    const float* pa = sA[buf] + wm * 64 + l31;
+    const float* pb = sB[buf] + wn * 64 + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = pa[(kk + kh) * LDA_S];
+      const float a1 = pa[(kk + kh) * LDA_S + 32];
+      const float b0 = pb[(kk + kh) * LDB_S];
+      const float b1 = pb[(kk + kh) * LDB_S + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) -------
+  const bool partial = (g.splits > 1);
+  float* out = partial ? g.ws + static_cast<long long>(z) * g.M * g.N : g.C;
+  const long long ldo = partial ? g.N : g.ldc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        if (row >= g.M) continue;
+        float v = acc[i][j][e];
+        float* o = out + static_cast<long long>(row) * ldo + col;
+        if (!partial) {
+          v += bv;
+          if (g.accumulate) v += *o;
+          v = apply_act(v, g.act, g.slope);
+        }
+        *o = v;
+      }
+    }
+  }
+}
+
+// out = act( sum_z ws[z] + bias (+ C) )
+__global__ void splitk_reduce_kernel(const GemmArgs g) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long total = static_cast<long long>(g.M) * g.N;
+  if (i >= total) return;
+  const int row = static_cast<int>(i / g.N), col = static_cast<int>(i - static_cast<long long>(row) * g.N);
+  float v = 0.f;
+  for (int z = 0; z < g.splits; ++z) v += g.ws[static_cast<long long>(z) * total + i];
+  if (g.bias) v += g.bias[col];
+  float* o = g.C + static_cast<long long>(row) * g.ldc + col;
+  if (g.accumulate) v += *o;
+  *o = apply_act(v, g.act, g.slope);
+}
+
+static void plan_split(int64_t M, int64_t N, int64_t K, int* splits, int* tiles_per_split) {
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int64_t ktiles = (K + BK - 1) / BK;
+  int64_t s = 1;
+  if (tiles < 192 && ktiles >= 16) {
+    s = (768 + tiles - 1) / tiles;            // aim for ~3 workgroups per CU
+    const int64_t max_s = ktiles / 8;          // keep >= 8 K tiles (256 k) per split
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+  }
+  int64_t per = (ktiles + s - 1) / s;
+  if (per < 1) per = 1;
+  s = (ktiles + per - 1) / per;
+  if (s < 1) s = 1;
+  *splits = static_cast<int>(s);
+  *tiles_per_split = static_cast<int>(per);
+}
+
+// ---- elementwise helpers used by the dense backward -------------------------------------------------
+__global__ void act_bwd_kernel(float* __restrict__ dpre, const float* __restrict__ dout, const float* __restrict__ out,
+                               long long n, int act, float slope) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long p = i; p < n; p += stride) {
+    const float y = out[p];
+    float d;
+    switch (act) {
+      case SG_ACT_LEAKY: d = y > 0.f ? 1.f : slope; break;   // leaky preserves sign for slope > 0
+      case SG_ACT_RELU: d = y > 0.f ? 1.f : 0.f; break;
+      case SG_ACT_SIGMOID: d = y * (1.f - y); break;
+      case SG_ACT_TANH: d = 1.f - y * y; break;
+      default: d = 1.f; break;
+    }
+    dpre[p] = dout[p] * d;
+  }
+}
+
+constexpr int kColRows = 512;  // rows per workgroup in pass 1 of colsum
+// pass 1: partial[chunk][col] = sum over the chunk's rows; 256 threads = 64 columns x 4 row lanes
+__global__ __launch_bounds__(256) void colsum_partial_kernel(float* __restrict__ partial, const float* __restrict__ X,
+                                                             long long ldx, long long M, int N) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const long long r0 = static_cast<long long>(blockIdx.y) * kColRows;
+  const long long r1 = min(M, r0 + kColRows);
+  float acc = 0.f;
+  if (col < N)
+    for (long long r = r0 + rl; r < r1; r += 4) acc += X[r * ldx + col];
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && col < N) partial[static_cast<long long>(blockIdx.y) * N + col] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+__global__ void colsum_final_kernel(float* __restrict__ dst, const float* __restrict__ partial, int chunks, int N,
+                                    int add) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  float acc = 0.f;
+  for (int c = 0; c < chunks; ++c) acc += partial[static_cast<long long>(c) * N + col];
+  dst[col] = add ? dst[col] + acc : acc;
+}
+
+}  // namespace sg
+
+using namespace sg;
+
+SG_API size_t sg_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K, int transA) {
+  (void)transA;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int s, per;
+  plan_split(M, N, K, &s, &per);
+  return s > 1 ? static_cast<size_t>(s) * M * N * sizeof(float) : 0;
+}
+
+SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, int transA, const float* B, int64_t ldb,
+                           int transB, int64_t M, int64_t N, int64_t K, const float* bias, int act, float slope,
+                           int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  if (M < 0 || N < 0 || K < 0) return fail(SG_ERR_INVALID, "negative GEMM dimension");
+  if (M == 0 || N == 0) return SG_OK;
+  if (M >= (1ll << 31) || N >= (1ll << 31) || K >= (1ll << 31)) return fail(SG_ERR_INVALID, "GEMM dimension overflow");
+  if (act < SG_ACT_NONE || act > SG_ACT_TANH) return fail(SG_ERR_INVALID, "bad activation %d", act);
+  if (!C || (K > 0 && (!A || !B))) return fail(SG_ERR_INVALID, "null pointer argument");
+  if (ldc < N || lda < (transA ? M : K) || ldb < (transB ? K : N)) return fail(SG_ERR_INVALID, "leading dimension too small");
+  GemmArgs g{};
+  g.C = C; g.A = A; g.B = B; g.bias = bias;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.M = static_cast<int>(M); g.N = static_cast<int>(N); g.K = static_cast<int>(K);
+  g.act = act; g.slope = slope; g.accumulate = accumulate ? 1 : 0;
+  g.tiles_m = static_cast<int>((M + BM - 1) / BM);
+  g.tiles_n = static_cast<int>((N + BN - 1) / BN);
+  if (static_cast<int64_t>(g.tiles_m) * g.tiles_n >= (1ll << 31)) return fail(SG_ERR_INVALID, "too many tiles");
+  plan_split(M, N, K, &g.splits, &g.tiles_per_split);
+  if (K == 0) { g.splits = 1; g.tiles_per_split = 1; }
+  if (g.splits > 1) {
+    const size_t need = static_cast<size_t>(g.splits) * M * N * sizeof(float);
+    if (!workspace || workspace_bytes < need)
+      return fail(SG_ERR_WORKSPACE, "split-K workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    g.ws = static_cast<float*>(workspace);
+  }
+  g.vecA = (lda % 4 == 0) && aligned(A, 16);
+  g.vecB = (ldb % 4 == 0) && aligned(B, 16);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 grid(static_cast<unsigned>(g.tiles_m * g.tiles_n), static_cast<unsigned>(g.splits));
+  if (transA) {
+    if (transB) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(kThreads), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(kThreads), 0, st, g);
+  } else {
+    if (transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(kThreads), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(kThreads), 0, st, g);
+  }
+  if (g.splits > 1) {
+    const long long total = static_cast<long long>(M) * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, g);
+  }
+  return check_launch("gemm_f32");
+}
+
+SG_API int sg_act_bwd_hip(float* dpre, const float* dout, const float* out, int64_t n, int act, float slope,
+                          void* stream) {
+  if (n < 0) return fail(SG_ERR_INVALID, "negative size");
+  if (act < SG_ACT_NONE || act > SG_ACT_TANH) return fail(SG_ERR_INVALID, "bad activation %d", act);
+  if (n == 0) return SG_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dpre, dout, out, static_cast<long long>(n), act, slope);
+  return check_launch("act_bwd");
+}
+
+SG_API size_t sg_colsum_workspace_bytes(int64_t M, int64_t N) {
+  if (M <= 0 || N <= 0) return 0;
+  return static_cast<size_t>((M + kColRows - 1) / kColRows) * N * sizeof(float);
+}
+
+SG_API int sg_colsum_hip(float* dst, const float* X, int64_t ldx, int64_t M, int64_t N, int req, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (!valid_req(req)) return fail(SG_ERR_INVALID, "bad req %d", req);
+  if (req == SG_REQ_NULL || N <= 0) return SG_OK;
+  if (M < 0 || ldx < N || N >= (1ll << 31)) return fail(SG_ERR_INVALID, "bad colsum shape");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t chunks = (M + kColRows - 1) / kColRows;
+  if (chunks > 65535) return fail(SG_ERR_INVALID, "colsum: too many rows");
+  if (chunks > 0) {
+    if (!workspace || workspace_bytes < sg_colsum_workspace_bytes(M, N))
+      return fail(SG_ERR_WORKSPACE, "colsum workspace too small");
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(static_cast<unsigned>((N + 63) / 64), static_cast<unsigned>(chunks)),
+                       dim3(256), 0, st, static_cast<float*>(workspace), X, static_cast<long long>(ldx),
+                       static_cast<long long>(M), static_cast<int>(N));
+  }
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, st, dst,
+                     static_cast<const float*>(workspace), static_cast<int>(chunks), static_cast<int>(N),
+                     req == SG_REQ_ADD);
+  return check_launch("colsum");
+}

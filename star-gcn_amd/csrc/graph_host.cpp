@@ -1,0 +1,160 @@
+// graph_host.cpp -- host-side plan / graph helpers of libstargcn_hip.so (C++17, no GPU work).
+//
+// Counterparts of the reference's native `mxgraph._graph_sampler` helpers (reference
+// GraphSampler/graph_sampler.cpp, exposed by py_ext.cpp:612-627) that produce the integer inputs of the hot
+// path, plus the plan builders the reference does not have (it re-sorts edges on every backward call,
+// seg_op.cu:906-925, and rebuilds/uploads every index array on every iteration, layers.py:366-377).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace sg {
+static thread_local std::string g_last_error;
+void set_error(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+}  // namespace sg
+
+using namespace sg;
+
+SG_API const char* sg_last_error(void) { return g_last_error.c_str(); }
+SG_API int sg_version(void) { return 100; }  // 0.1.0
+
+SG_API int sg_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(SG_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+// Stable counting sort of the covered edges by destination index (reference semantics: stable radix sort
+// of (indices, iota), seg_op.cu:906-912) -> transposed CSR.  t_pos[p] = original edge position (increasing
+// inside a row), t_seg[p] = segment that edge belongs to.
+SG_API int sg_build_transpose_cpu(int32_t* t_indptr, int32_t* t_pos, int32_t* t_seg, const int32_t* indices,
+                                  const int32_t* indptr, int64_t seg_num, int64_t total_ind_num, int64_t nnz) {
+  if (seg_num < 0 || total_ind_num < 0 || nnz < 0) return fail(SG_ERR_INVALID, "negative dimension");
+  if (!t_indptr || !indptr) return fail(SG_ERR_INVALID, "null pointer argument");
+  const int64_t E = seg_num > 0 ? indptr[seg_num] : 0;
+  if (E < 0 || E > nnz) return fail(SG_ERR_INVALID, "indptr[-1]=%lld exceeds nnz=%lld", (long long)E, (long long)nnz);
+  std::vector<int64_t> cnt(static_cast<size_t>(total_ind_num) + 1, 0);
+  for (int64_t j = 0; j < E; ++j) {
+    const int32_t n = indices[j];
+    if (n < 0 || n >= total_ind_num) return fail(SG_ERR_VALUE, "indices[%lld]=%d out of range [0,%lld)", (long long)j, n, (long long)total_ind_num);
+    cnt[static_cast<size_t>(n) + 1]++;
+  }
+  for (int64_t n = 0; n < total_ind_num; ++n) cnt[n + 1] += cnt[n];
+  for (int64_t n = 0; n <= total_ind_num; ++n) t_indptr[n] = static_cast<int32_t>(cnt[n]);
+  for (int64_t i = 0; i < seg_num; ++i) {
+    if (indptr[i + 1] < indptr[i]) return fail(SG_ERR_VALUE, "indptr is not non-decreasing at %lld", (long long)i);
+    for (int64_t j = indptr[i]; j < indptr[i + 1]; ++j) {
+      const int64_t p = cnt[indices[j]]++;
+      t_pos[p] = static_cast<int32_t>(j);
+      t_seg[p] = static_cast<int32_t>(i);
+    }
+  }
+  return SG_OK;
+}
+
+// reference graph_sampler.cpp:393-420
+SG_API int sg_get_support_cpu(float* support, const int32_t* row_degrees, const int32_t* col_degrees,
+                              const int32_t* end_points, const int32_t* ind_ptr, int64_t row_num, int symm) {
+  if (row_num < 0) return fail(SG_ERR_INVALID, "negative row_num");
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < row_num; ++i) {
+    const int32_t dr = row_degrees[i];
+    for (int64_t j = ind_ptr[i]; j < ind_ptr[i + 1]; ++j) {
+      if (symm) {
+        const int32_t dc = col_degrees[end_points[j]];
+        support[j] = (dr == 0 || dc == 0) ? 0.0f : std::sqrt(1.0f / static_cast<float>(dr) / static_cast<float>(dc));
+      } else {
+        support[j] = (dr == 0) ? 0.0f : 1.0f / static_cast<float>(dr);
+      }
+    }
+  }
+  return SG_OK;
+}
+
+// reference graph_sampler.cpp:277-376 (levels matched by exact float equality, edges kept in CSR order,
+// a full-length indptr per level).
+SG_API int sg_multi_link_split_cpu(int32_t* out_pos, int32_t* out_indptr, int64_t* level_off, const float* values,
+                                   const int32_t* ind_ptr, const float* multi_link, int64_t row_num,
+                                   int64_t num_links) {
+  if (row_num < 0 || num_links <= 0) return fail(SG_ERR_INVALID, "bad row_num/num_links");
+  const int64_t nnz = ind_ptr[row_num];
+  std::vector<int32_t> level(static_cast<size_t>(nnz));
+  std::vector<int64_t> cnt(static_cast<size_t>(num_links) + 1, 0);
+  for (int64_t j = 0; j < nnz; ++j) {
+    int64_t l = 0;
+    while (l < num_links && values[j] != multi_link[l]) ++l;
+    if (l == num_links) return fail(SG_ERR_VALUE, "edge value %g at position %lld matches no link level", (double)values[j], (long long)j);
+    level[j] = static_cast<int32_t>(l);
+    cnt[l + 1]++;
+  }
+  level_off[0] = 0;
+  for (int64_t l = 0; l < num_links; ++l) level_off[l + 1] = level_off[l] + cnt[l + 1];
+  std::vector<int64_t> w(level_off, level_off + num_links);
+  for (int64_t l = 0; l < num_links; ++l) out_indptr[l * (row_num + 1)] = 0;
+  for (int64_t i = 0; i < row_num; ++i) {
+    for (int64_t j = ind_ptr[i]; j < ind_ptr[i + 1]; ++j) out_pos[w[level[j]]++] = static_cast<int32_t>(j);
+    for (int64_t l = 0; l < num_links; ++l) out_indptr[l * (row_num + 1) + i + 1] = static_cast<int32_t>(w[l] - level_off[l]);
+  }
+  return SG_OK;
+}
+
+// Fuses the R per-level CSRs into one CSR over n_dst*R segments and builds its transpose over n_src*R
+// segments (edges of a transposed segment in increasing destination order == original CSR order).
+SG_API int sg_multilink_fuse_cpu(int32_t* c_indptr, int32_t* c_idx, int32_t* c_q, float* c_w, int32_t* t_indptr,
+                                 int32_t* t_idx, int32_t* t_q, float* t_w, const int32_t* const* end_points_l,
+                                 const int32_t* const* indptr_l, const float* const* support_l, int64_t num_links,
+                                 int64_t n_dst, int64_t n_src) {
+  if (num_links <= 0 || n_dst < 0 || n_src < 0) return fail(SG_ERR_INVALID, "bad multilink dimensions");
+  const int64_t R = num_links;
+  if (n_dst * R >= (1ll << 31) - 1 || n_src * R >= (1ll << 31) - 1) return fail(SG_ERR_INVALID, "n*R overflows int32");
+  int64_t total = 0;
+  for (int64_t r = 0; r < R; ++r) {
+    if (indptr_l[r][0] != 0) return fail(SG_ERR_VALUE, "indptr_l[%lld][0] != 0", (long long)r);
+    total += indptr_l[r][n_dst];
+  }
+  if (total >= (1ll << 31) - 1) return fail(SG_ERR_INVALID, "edge count overflows int32");
+  std::vector<int64_t> tcnt(static_cast<size_t>(n_src * R) + 1, 0);
+  int64_t w = 0;
+  c_indptr[0] = 0;
+  for (int64_t i = 0; i < n_dst; ++i) {
+    for (int64_t r = 0; r < R; ++r) {
+      const int32_t* ep = end_points_l[r];
+      const float* sp = support_l[r];
+      for (int64_t j = indptr_l[r][i]; j < indptr_l[r][i + 1]; ++j) {
+        const int32_t n = ep[j];
+        if (n < 0 || n >= n_src) return fail(SG_ERR_VALUE, "end point %d out of range [0,%lld)", n, (long long)n_src);
+        c_idx[w] = n;
+        if (c_q) c_q[w] = static_cast<int32_t>(static_cast<int64_t>(n) * R + r);
+        c_w[w] = sp[j];
+        ++w;
+        tcnt[static_cast<size_t>(n) * R + r + 1]++;
+      }
+      c_indptr[i * R + r + 1] = static_cast<int32_t>(w);
+    }
+  }
+  for (int64_t s = 0; s < n_src * R; ++s) tcnt[s + 1] += tcnt[s];
+  for (int64_t s = 0; s <= n_src * R; ++s) t_indptr[s] = static_cast<int32_t>(tcnt[s]);
+  for (int64_t i = 0; i < n_dst; ++i) {
+    for (int64_t r = 0; r < R; ++r) {
+      for (int64_t j = c_indptr[i * R + r]; j < c_indptr[i * R + r + 1]; ++j) {
+        const int64_t p = tcnt[static_cast<size_t>(c_idx[j]) * R + r]++;
+        t_idx[p] = static_cast<int32_t>(i);
+        if (t_q) t_q[p] = static_cast<int32_t>(i * R + r);
+        t_w[p] = c_w[j];
+      }
+    }
+  }
+  return SG_OK;
+}

@@ -1,0 +1,446 @@
+// seg_gather.hip -- the HBM-bound hot kernel of the STAR-GCN multi-link graph convolution on gfx950.
+//
+//   dst[row(s), :] (+)= sum_{j = indptr[s]}^{indptr[s+1]-1}  w[j] * src[row(idx[j]), :]
+//
+// This one kernel serves (a) `seg_weighted_pool` forward (reference seg_op.cc:180-207, seg_op.cu:682-722),
+// (b) its gradient w.r.t. data through a cached transposed plan (reference seg_op.cc:209-240,
+// seg_op.cu:747-790/882-926 re-sorts on every call), (c) `seg_pool` sum/avg, and (d) the fused multi-link
+// aggregation where the R per-rating-level aggregates of a node are written side by side into one row of
+// the matrix that feeds the MFMA contraction (reference aggregators.py:133-159 does R separate op calls).
+//
+// CDNA4 mapping (not the reference's 32-thread-block-per-(row,128 channels) design):
+//   * work unit = a CHUNK of 256 consecutive edges handled by ONE 64-lane wavefront (one wave per
+//     workgroup, so the only synchronisation is wave-local).  Edge-balanced: a 35k-edge hub row is split
+//     over ~140 waves, a run of 14-edge rows shares one wave.  No atomics, deterministic.
+//   * the chunk's (index, weight) pairs are loaded once, coalesced, into LDS; the CSR row-pointer tile of
+//     the segments that start in the chunk is staged in LDS 64 pointers at a time.
+//   * each gathered neighbour row is read as ONE coalesced burst: lanes hold VEC consecutive floats
+//     (float4 -> 1 KiB per wave instruction at C = 256).  For narrow rows (C*4 < 1 KiB) the wave splits
+//     into 64/LPR edge groups that gather different edges concurrently and combine with __shfl_xor.
+//   * segments that straddle a chunk boundary write fp32 partial rows to a workspace; a tiny second
+//     kernel adds the partials of each such segment in chunk order.
+#include "common.hpp"
+
+namespace sg {
+
+constexpr int kChunk = 256;  // edges per wavefront
+constexpr int kPtrTile = 64; // CSR row pointers staged in LDS per refill
+
+struct GatherArgs {
+  float* dst;
+  const float* src;
+  const float* w;        // may be null (all ones)
+  const int32_t* wpos;   // may be null; else weight of edge j is w[wpos[j]]
+  const int32_t* idx;
+  const int32_t* indptr; // seg_num + 1
+  float* ws_head;        // [batch][n_chunks][C] partial of the segment that started in an earlier chunk
+  float* ws_tail;        // [batch][n_chunks][C] partial of the segment that continues into the next chunk
+  int32_t* ws_tailseg;   // [batch][n_chunks]    that segment's id, or -1
+  long long dst_ld, src_ld, dst_bs, src_bs, w_bs;
+  int32_t dst_group, src_group;
+  uint32_t src_magic;    // q / src_group == (uint64(q) * src_magic) >> (31 + src_shift)   for q < 2^31
+  int32_t src_shift;
+  int32_t seg_num, C, n_chunks, lpr;
+  int32_t req, mean;
+  int32_t act;
+  float slope;
+};
+
+__device__ __forceinline__ float gather_act(float v, int act, float slope) {
+  switch (act) {
+    case SG_ACT_LEAKY: return v > 0.f ? v : slope * v;
+    case SG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case SG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case SG_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+template <int V> struct VecT;
+template <> struct VecT<1> { using T = float; };
+template <> struct VecT<2> { using T = float2; };
+template <> struct VecT<4> { using T = float4; };
+
+template <int V> __device__ __forceinline__ void ld_vec(float (&r)[V], const float* p) {
+  typename VecT<V>::T t = *reinterpret_cast<const typename VecT<V>::T*>(p);
+  const float* f = reinterpret_cast<const float*>(&t);
+#pragma unroll
+  for (int v = 0; v < V; ++v) r[v] = f[v];
+}
+template <int V> __device__ __forceinline__ void st_vec(float* p, const float (&r)[V]) {
+  typename VecT<V>::T t;
+  float* f = reinterpret_cast<float*>(&t);
+#pragma unroll
+  for (int v = 0; v < V; ++v) f[v] = r[v];
+  *reinterpret_cast<typename VecT<V>::T*>(p) = t;
+}
+
+// first s in [0, n] with a[s] >= t (a is non-decreasing, n+1 entries, a[n] >= t guaranteed by callers).
+// 64-ary search: every step all lanes probe, __ballot narrows the range 64x (wave-uniform result).
+__device__ __forceinline__ int wave_lower_bound(const int32_t* __restrict__ a, int n, int t, int lane) {
+  int lo = 0, hi = n + 1;
+  while (lo < hi) {
+    const int len = hi - lo;
+    const int step = (len + 63) >> 6;
+    const int p = lo + lane * step;
+    const bool pred = (p < hi) && (a[p] >= t);
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) {
+      const int nprobe = (len + step - 1) / step;
+      lo = lo + (nprobe - 1) * step + 1;
+    } else {
+      const int f = __ffsll(static_cast<long long>(m)) - 1;
+      const int nhi = lo + f * step;
+      lo = (f == 0) ? nhi : (lo + (f - 1) * step + 1);
+      hi = nhi;
+    }
+  }
+  return lo;
+}
+
+template <bool GROUPED>
+__device__ __forceinline__ long long src_row_off(const GatherArgs& a, int q) {
+  if (!GROUPED) return static_cast<long long>(q) * a.src_ld;
+  const unsigned hi = static_cast<unsigned>((static_cast<unsigned long long>(static_cast<unsigned>(q)) * a.src_magic) >>
+                                            (31 + a.src_shift));
+  const unsigned lo = static_cast<unsigned>(q) - hi * static_cast<unsigned>(a.src_group);
+  return static_cast<long long>(hi) * a.src_ld + static_cast<long long>(lo) * a.C;
+}
+
+// Accumulate edges [ea, eb) (chunk-relative LDS positions) for the channel tile starting at ct; the
+// result (summed over edge groups) is returned in acc on every lane.
+template <int VEC, bool GROUPED, bool UNI>
+__device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const float* __restrict__ src, const int32_t* s_idx,
+                                                 const float* s_w, int ea, int eb, int c, bool chan_ok, int grp,
+                                                 int epg, float (&acc)[VEC]) {
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  int e = ea + grp;
+  constexpr int U = 4;
+  for (; e + (U - 1) * epg < eb; e += U * epg) {
+    float x[U][VEC];
+    float wv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int q = s_idx[e + u * epg];
+      wv[u] = s_w[e + u * epg];
+      if (UNI) {
+        q = __builtin_amdgcn_readfirstlane(q);
+        wv[u] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wv[u])));
+      }
+      if (chan_ok) ld_vec<VEC>(x[u], src + src_row_off<GROUPED>(a, q) + c);
+    }
+    if (chan_ok) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = fmaf(wv[u], x[u][v], acc[v]);
+    }
+  }
+  for (; e < eb; e += epg) {
+    int q = s_idx[e];
+    float wv = s_w[e];
+    if (UNI) {
+      q = __builtin_amdgcn_readfirstlane(q);
+      wv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wv)));
+    }
+    if (chan_ok) {
+      float x[VEC];
+      ld_vec<VEC>(x, src + src_row_off<GROUPED>(a, q) + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = fmaf(wv, x[v], acc[v]);
+    }
+  }
+  if (!UNI) {
+    for (int off = a.lpr; off < kWave; off <<= 1) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], off);
+    }
+  }
+}
+
+template <int VEC, bool GROUPED, bool UNI>
+__global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
+  __shared__ int32_t s_idx[kChunk];
+  __shared__ float s_w[kChunk];
+  __shared__ int32_t s_ptr[kPtrTile + 1];
+
+  const int lane = threadIdx.x;
+  const int k = blockIdx.x;
+  const int b = blockIdx.y;
+  const int32_t* __restrict__ indptr = a.indptr;
+  const int E = indptr[a.seg_num];  // covered edges; positions >= E are padding
+  const long long cb64 = static_cast<long long>(k) * kChunk;
+  int32_t* tailseg = a.ws_tailseg + static_cast<long long>(b) * a.n_chunks + k;
+  if (cb64 >= E && !(E == 0 && k == 0)) {
+    if (lane == 0) *tailseg = -1;
+    return;
+  }
+  const int cb = static_cast<int>(cb64);
+  const int ce = min(cb + kChunk, E);
+  const bool is_last = (ce == E);
+  const float* __restrict__ src = a.src + static_cast<long long>(b) * a.src_bs;
+  float* __restrict__ dst = a.dst + static_cast<long long>(b) * a.dst_bs;
+
+  // ---- stage this chunk's edges in LDS (coalesced) -------------------------------------------------
+  for (int q = lane; q < ce - cb; q += kWave) {
+    const int j = cb + q;
+    s_idx[q] = a.idx[j];
+    float wv = 1.f;
+    if (a.w) wv = a.w[static_cast<long long>(b) * a.w_bs + (a.wpos ? a.wpos[j] : j)];
+    s_w[q] = wv;
+  }
+  const int s_lo = wave_lower_bound(indptr, a.seg_num, cb, lane);
+  __syncthreads();  // single-wave workgroup: only orders the LDS writes above before the reads below
+
+  const int lpr = a.lpr;
+  const int epg = kWave / lpr;
+  const int grp = UNI ? 0 : lane / lpr;
+  const int slot = UNI ? lane : lane % lpr;
+  const int ctile = lpr * VEC;
+  const long long wsrow = (static_cast<long long>(b) * a.n_chunks + k) * a.C;
+  const bool add = (a.req == SG_REQ_ADD);
+
+  // ---- head piece: the segment that started before this chunk --------------------------------------
+  const int p_lo = indptr[s_lo];  // s_lo <= seg_num
+  if (cb < ce && p_lo > cb) {
+    const int hb = min(ce, p_lo);
+    for (int ct = 0; ct < a.C; ct += ctile) {
+      const int c = ct + slot * VEC;
+      const bool chan_ok = c < a.C;
+      float acc[VEC];
+      accumulate_piece<VEC, GROUPED, UNI>(a, src, s_idx, s_w, 0, hb - cb, c, chan_ok, grp, epg, acc);
+      if (grp == 0 && chan_ok) st_vec<VEC>(a.ws_head + wsrow + c, acc);
+    }
+  }
+
+  // ---- segments that start in this chunk ------------------------------------------------------------
+  int s = s_lo;
+  int tail_s = -1;
+  bool done = false;
+  while (!done && s < a.seg_num) {
+    const int cnt = min(kPtrTile, a.seg_num - s);
+    __syncthreads();
+    if (lane <= cnt) s_ptr[lane] = indptr[s + lane];
+    if (lane == 0 && cnt == kPtrTile) s_ptr[kPtrTile] = indptr[s + kPtrTile];
+    __syncthreads();
+    for (int t = 0; t < cnt; ++t, ++s) {
+      const int pb = __builtin_amdgcn_readfirstlane(s_ptr[t]);
+      const int pe = __builtin_amdgcn_readfirstlane(s_ptr[t + 1]);
+      if (!is_last && pb >= ce) { done = true; break; }
+      const bool whole = (pe <= ce);
+      const int eb = whole ? pe : ce;
+      float* out;
+      if (whole) {
+        const int dg = s / a.dst_group;
+        out = dst + static_cast<long long>(dg) * a.dst_ld + static_cast<long long>(s - dg * a.dst_group) * a.C;
+      } else {
+        out = a.ws_tail + wsrow;
+      }
+      const float scale = (a.mean && pe > pb) ? 1.f / static_cast<float>(pe - pb) : 1.f;
+      for (int ct = 0; ct < a.C; ct += ctile) {
+        const int c = ct + slot * VEC;
+        const bool chan_ok = c < a.C;
+        float acc[VEC];
+        accumulate_piece<VEC, GROUPED, UNI>(a, src, s_idx, s_w, pb - cb, eb - cb, c, chan_ok, grp, epg, acc);
+        if (grp == 0 && chan_ok) {
+          if (whole) {
+            if (a.mean) {
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) acc[v] *= scale;
+            }
+            if (add) {
+              float old[VEC];
+              ld_vec<VEC>(old, out + c);
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) acc[v] += old[v];
+            }
+            if (a.act) {
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) acc[v] = gather_act(acc[v], a.act, a.slope);
+            }
+          }
+          st_vec<VEC>(out + c, acc);
+        }
+      }
+      if (!whole) { tail_s = s; done = true; break; }
+    }
+  }
+  if (lane == 0) *tailseg = tail_s;
+}
+
+// Adds, in chunk order, the partial rows of every segment that straddles chunk boundaries.
+template <int VEC>
+__global__ __launch_bounds__(kWave) void seg_gather_fixup_kernel(const GatherArgs a) {
+  const int k = blockIdx.x;
+  const int b = blockIdx.y;
+  const int s = a.ws_tailseg[static_cast<long long>(b) * a.n_chunks + k];
+  if (s < 0) return;
+  const int lane = threadIdx.x;
+  const int pb = a.indptr[s];
+  const int pe = a.indptr[s + 1];
+  const long long base = static_cast<long long>(b) * a.n_chunks;
+  const int dg = s / a.dst_group;
+  float* out = a.dst + static_cast<long long>(b) * a.dst_bs + static_cast<long long>(dg) * a.dst_ld +
+               static_cast<long long>(s - dg * a.dst_group) * a.C;
+  const float scale = (a.mean && pe > pb) ? 1.f / static_cast<float>(pe - pb) : 1.f;
+  for (int c = lane * VEC; c < a.C; c += kWave * VEC) {
+    float acc[VEC];
+    ld_vec<VEC>(acc, a.ws_tail + (base + k) * a.C + c);
+    for (int kk = k + 1; kk < a.n_chunks && static_cast<long long>(kk) * kChunk < pe; ++kk) {
+      float h[VEC];
+      ld_vec<VEC>(h, a.ws_head + (base + kk) * a.C + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += h[v];
+    }
+    if (a.mean) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] *= scale;
+    }
+    if (a.req == SG_REQ_ADD) {
+      float old[VEC];
+      ld_vec<VEC>(old, out + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += old[v];
+    }
+    if (a.act) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = gather_act(acc[v], a.act, a.slope);
+    }
+    st_vec<VEC>(out + c, acc);
+  }
+}
+
+static inline int64_t n_chunks_for(int64_t nnz) { return nnz <= 0 ? 1 : (nnz + kChunk - 1) / kChunk; }
+
+size_t gather_workspace_bytes(int64_t batch, int64_t nnz, int64_t C) {
+  const int64_t nc = n_chunks_for(nnz);
+  // head + tail partial rows, then the tail-segment ids (kept 16-byte aligned)
+  size_t rows = static_cast<size_t>(batch) * nc * C * sizeof(float);
+  rows = (rows + 15) & ~static_cast<size_t>(15);
+  return 2 * rows + static_cast<size_t>(batch) * nc * sizeof(int32_t) + 16;
+}
+
+template <int VEC>
+static void launch_variants(const GatherArgs& a, dim3 grid, hipStream_t st, bool grouped, bool uni) {
+  if (grouped) {
+    if (uni) hipLaunchKernelGGL((seg_gather_kernel<VEC, true, true>), grid, dim3(kWave), 0, st, a);
+    else hipLaunchKernelGGL((seg_gather_kernel<VEC, true, false>), grid, dim3(kWave), 0, st, a);
+  } else {
+    if (uni) hipLaunchKernelGGL((seg_gather_kernel<VEC, false, true>), grid, dim3(kWave), 0, st, a);
+    else hipLaunchKernelGGL((seg_gather_kernel<VEC, false, false>), grid, dim3(kWave), 0, st, a);
+  }
+  hipLaunchKernelGGL((seg_gather_fixup_kernel<VEC>), grid, dim3(kWave), 0, st, a);
+}
+
+// Generic launcher shared by every public entry point built on the gather kernel.
+int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs, const float* src, int64_t src_group,
+                  int64_t src_ld, int64_t src_bs, const float* w, int64_t w_bs, const int32_t* wpos,
+                  const int32_t* idx, const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t nnz, int64_t C,
+                  int req, int mean, int act, float slope, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (!valid_req(req)) return fail(SG_ERR_INVALID, "req must be 0 (null), 1 (write) or 3 (add), got %d", req);
+  if (req == SG_REQ_NULL) return SG_OK;
+  if (batch < 0 || seg_num < 0 || nnz < 0 || C < 0) return fail(SG_ERR_INVALID, "negative dimension");
+  if (batch == 0 || seg_num == 0 || C == 0) return SG_OK;
+  if (seg_num >= (1ll << 31) - 1 || nnz >= (1ll << 31) - kChunk || C >= (1 << 24))
+    return fail(SG_ERR_INVALID, "seg_num/nnz must fit int32 indices (seg_num=%lld nnz=%lld C=%lld)",
+                (long long)seg_num, (long long)nnz, (long long)C);
+  if (dst_group < 1 || src_group < 1 || src_group >= (1 << 30)) return fail(SG_ERR_INVALID, "bad group size");
+  if (act < SG_ACT_NONE || act > SG_ACT_TANH) return fail(SG_ERR_INVALID, "bad activation %d", act);
+  if (!dst || !src || !indptr || (nnz > 0 && !idx)) return fail(SG_ERR_INVALID, "null pointer argument");
+  const size_t need = gather_workspace_bytes(batch, nnz, C);
+  if (workspace_bytes < need || !workspace)
+    return fail(SG_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+
+  GatherArgs a{};
+  a.dst = dst; a.src = src; a.w = w; a.wpos = wpos; a.idx = idx; a.indptr = indptr;
+  a.n_chunks = static_cast<int32_t>(n_chunks_for(nnz));
+  char* wsp = static_cast<char*>(workspace);
+  wsp = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(wsp) + 15) & ~static_cast<uintptr_t>(15));
+  size_t rows = static_cast<size_t>(batch) * a.n_chunks * C * sizeof(float);
+  rows = (rows + 15) & ~static_cast<size_t>(15);
+  a.ws_head = reinterpret_cast<float*>(wsp);
+  a.ws_tail = reinterpret_cast<float*>(wsp + rows);
+  a.ws_tailseg = reinterpret_cast<int32_t*>(wsp + 2 * rows);
+  a.dst_ld = dst_ld; a.src_ld = src_ld; a.dst_bs = dst_bs; a.src_bs = src_bs; a.w_bs = w_bs;
+  a.dst_group = static_cast<int32_t>(dst_group);
+  a.src_group = static_cast<int32_t>(src_group);
+  a.seg_num = static_cast<int32_t>(seg_num);
+  a.C = static_cast<int32_t>(C);
+  a.req = req; a.mean = mean; a.act = act; a.slope = slope;
+  if (src_group > 1) {
+    int l = 0;
+    while ((1ll << l) < src_group) ++l;  // ceil(log2 d), >= 1
+    const unsigned long long num = 1ull << (31 + l);
+    a.src_magic = static_cast<uint32_t>((num + static_cast<unsigned long long>(src_group) - 1) /
+                                        static_cast<unsigned long long>(src_group));
+    a.src_shift = l;
+  }
+  // vector width by alignment of every row start
+  int vec = 1;
+  auto ok = [&](int v) {
+    return C % v == 0 && dst_ld % v == 0 && src_ld % v == 0 && dst_bs % v == 0 && src_bs % v == 0 &&
+           aligned(dst, 4 * v) && aligned(src, 4 * v);
+  };
+  if (ok(4)) vec = 4; else if (ok(2)) vec = 2;
+  int lpr = 1;
+  while (lpr < kWave && static_cast<int64_t>(lpr) * vec < C) lpr <<= 1;
+  a.lpr = lpr;
+  const bool uni = (lpr == kWave);
+  const bool grouped = (src_group > 1);
+  dim3 grid(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch));
+  if (batch > 65535) return fail(SG_ERR_INVALID, "batch > 65535 not supported");
+  if (vec == 4) launch_variants<4>(a, grid, st, grouped, uni);
+  else if (vec == 2) launch_variants<2>(a, grid, st, grouped, uni);
+  else launch_variants<1>(a, grid, st, grouped, uni);
+  return check_launch("seg_gather");
+}
+
+}  // namespace sg
+
+// ------------------------------------------------------------------------------------------------------
+// C ABI (see include/stargcn.h for the reference citations of every entry point)
+// ------------------------------------------------------------------------------------------------------
+SG_API size_t sg_seg_weighted_pool_workspace_bytes(int64_t batch, int64_t seg_num, int64_t nnz, int64_t feat_dim) {
+  (void)seg_num;
+  return sg::gather_workspace_bytes(batch, nnz, feat_dim);
+}
+
+SG_API int sg_seg_weighted_pool_hip(float* dst, const float* data, const float* weights, const int32_t* indices,
+                                    const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t total_ind_num,
+                                    int64_t nnz, int64_t feat_dim, int req, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  if (weights == nullptr && nnz > 0 && req != SG_REQ_NULL) return sg::fail(SG_ERR_INVALID, "weights is null");
+  return sg::launch_gather(dst, 1, feat_dim, seg_num * feat_dim, data, 1, feat_dim, total_ind_num * feat_dim, weights,
+                           nnz, nullptr, indices, indptr, batch, seg_num, nnz, feat_dim, req, 0, SG_ACT_NONE, 0.f,
+                           workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+SG_API int sg_seg_gather_sum_hip(float* dst, int64_t dst_group, int64_t dst_ld, const float* src, int64_t src_group,
+                                 int64_t src_ld, const float* weights, const int32_t* indices, const int32_t* indptr,
+                                 int64_t seg_num, int64_t nnz, int64_t feat_dim, int req, int act, float slope,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  return sg::launch_gather(dst, dst_group, dst_ld, 0, src, src_group, src_ld, 0, weights, 0, nullptr, indices, indptr,
+                           1, seg_num, nnz, feat_dim, req, 0, act, slope, workspace, workspace_bytes,
+                           static_cast<hipStream_t>(stream));
+}
+
+SG_API size_t sg_seg_weighted_pool_bwd_data_workspace_bytes(int64_t batch, int64_t total_ind_num, int64_t nnz,
+                                                            int64_t feat_dim) {
+  (void)total_ind_num;
+  return sg::gather_workspace_bytes(batch, nnz, feat_dim);
+}
+
+SG_API int sg_seg_weighted_pool_bwd_data_hip(float* ddata, const float* weights, const float* ograd,
+                                             const int32_t* t_indptr, const int32_t* t_pos, const int32_t* t_seg,
+                                             int64_t batch, int64_t seg_num, int64_t total_ind_num, int64_t nnz,
+                                             int64_t feat_dim, int req, void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+  if (req != SG_REQ_NULL && (!t_indptr || (nnz > 0 && (!t_pos || !t_seg || !weights))))
+    return sg::fail(SG_ERR_INVALID, "transposed plan (t_indptr, t_pos, t_seg) and weights are required; build the "
+                                    "plan once with sg_build_transpose_cpu");
+  // gather over the transposed plan: segment n collects ograd rows t_seg[p] with weight weights[t_pos[p]]
+  return sg::launch_gather(ddata, 1, feat_dim, total_ind_num * feat_dim, ograd, 1, feat_dim, seg_num * feat_dim,
+                           weights, nnz, t_pos, t_seg, t_indptr, batch, total_ind_num, nnz, feat_dim, req, 0, SG_ACT_NONE,
+                           0.f, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}

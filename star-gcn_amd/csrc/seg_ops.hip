@@ -1,0 +1,374 @@
+// seg_ops.hip -- the rest of the reference's segment-operator surface on gfx950 (wave64):
+//   seg_take_k_corr (reference seg_op.cc:150-178, seg_op.cu:573-664), seg_sum (:7-50), seg_broadcast_*
+//   (:52-78), seg_softmax fwd/bwd (:80-148), seg_pool fwd/bwd (:242-332).
+// None of these is executed by STAR-GCN training except through the gather kernel (seg_gather.hip);
+// they exist for operator-API parity (reference test_seg_ops.py).  Simple wave-per-segment mappings with
+// __shfl_xor reductions -- no 32-lane warp idioms (the reference's SumSharedMem, seg_op.cu:30-60, is
+// warp-synchronous over 32 lanes and invalid on a 64-lane wavefront).
+#include "common.hpp"
+
+namespace sg {
+
+int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs, const float* src, int64_t src_group,
+                  int64_t src_ld, int64_t src_bs, const float* w, int64_t w_bs, const int32_t* wpos,
+                  const int32_t* idx, const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t nnz, int64_t C,
+                  int req, int mean, int act, float slope, void* workspace, size_t workspace_bytes, hipStream_t st);
+size_t gather_workspace_bytes(int64_t batch, int64_t nnz, int64_t C);
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+constexpr int kBlock = 256;             // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+// ---------------------------------------------------------------------------------------------------
+// seg_take_k_corr: one wave per segment; 64/LPR edge groups; per edge an LPR-lane dot product.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void take_k_corr_kernel(float* __restrict__ dst, const float* __restrict__ e1,
+                                                             const float* __restrict__ e2,
+                                                             const int32_t* __restrict__ ids,
+                                                             const int32_t* __restrict__ indptr, int node_num,
+                                                             long long nbr_num, long long nnz, int C, int lpr, int add) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long seg = static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (seg >= node_num) return;
+  const int k = blockIdx.y;
+  const int epg = kWave / lpr;
+  const int grp = lane / lpr, slot = lane % lpr;
+  const float* row1 = e1 + (static_cast<long long>(k) * node_num + seg) * C;
+  const int pb = indptr[seg], pe = indptr[seg + 1];
+  for (int j0 = pb; j0 < pe; j0 += epg) {
+    const int j = j0 + grp;
+    float acc = 0.f;
+    if (j < pe) {
+      const float* row2 = e2 + (static_cast<long long>(k) * nbr_num + ids[j]) * C;
+      for (int c = slot; c < C; c += lpr) acc = fmaf(row1[c], row2[c], acc);
+    }
+    for (int off = 1; off < lpr; off <<= 1) acc += __shfl_xor(acc, off);
+    if (j < pe && slot == 0) {
+      float* o = dst + static_cast<long long>(k) * nnz + j;
+      *o = add ? (*o + acc) : acc;
+    }
+  }
+}
+
+// zero dst[k, j] for j in [E, nnz) (uncovered positions) -- E read on device
+__global__ void zero_uncovered_kernel(float* __restrict__ dst, const int32_t* __restrict__ indptr, int seg_num,
+                                      long long nnz) {
+  const long long E = indptr[seg_num];
+  const long long j = E + static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j < nnz) dst[static_cast<long long>(blockIdx.y) * nnz + j] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// seg_sum: one wave per (segment, batch)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void seg_sum_kernel(float* __restrict__ dst, const float* __restrict__ data,
+                                                         const int32_t* __restrict__ indptr, int seg_num, long long nnz,
+                                                         int add) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long seg = static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (seg >= seg_num) return;
+  const int k = blockIdx.y;
+  const float* d = data + static_cast<long long>(k) * nnz;
+  float acc = 0.f;
+  for (int j = indptr[seg] + lane; j < indptr[seg + 1]; j += kWave) acc += d[j];
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float* o = dst + static_cast<long long>(k) * seg_num + seg;
+    *o = add ? (*o + acc) : acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// seg_broadcast_{add,mul,to}: one thread per (edge position, batch); segment by binary search
+// ---------------------------------------------------------------------------------------------------
+__global__ void seg_broadcast_kernel(float* __restrict__ dst, const float* __restrict__ lhs,
+                                     const float* __restrict__ rhs, const int32_t* __restrict__ indptr, int seg_num,
+                                     long long nnz, int op, int add) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= nnz) return;
+  const int k = blockIdx.y;
+  float* o = dst + static_cast<long long>(k) * nnz + j;
+  if (j >= indptr[seg_num]) {
+    if (!add) *o = 0.f;
+    return;
+  }
+  int lo = 0, hi = seg_num;  // largest s with indptr[s] <= j  (then indptr[s+1] > j after skipping empties)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (indptr[mid] <= j) lo = mid; else hi = mid;
+  }
+  const float r = rhs[static_cast<long long>(k) * seg_num + lo];
+  float v;
+  if (op == 0) v = lhs[static_cast<long long>(k) * nnz + j] + r;
+  else if (op == 1) v = lhs[static_cast<long long>(k) * nnz + j] * r;
+  else v = r;
+  *o = add ? (*o + v) : v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// seg_softmax forward / backward: one wave per (segment, batch)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void seg_softmax_kernel(float* __restrict__ dst, const float* __restrict__ data,
+                                                             const int32_t* __restrict__ indptr, int seg_num,
+                                                             long long nnz) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long seg = static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (seg >= seg_num) return;
+  const int k = blockIdx.y;
+  const float* d = data + static_cast<long long>(k) * nnz;
+  float* o = dst + static_cast<long long>(k) * nnz;
+  const int pb = indptr[seg], pe = indptr[seg + 1];
+  float m = -3.402823466e+38f;
+  for (int j = pb + lane; j < pe; j += kWave) m = fmaxf(m, d[j]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int j = pb + lane; j < pe; j += kWave) {
+    const float e = expf(d[j] - m);
+    o[j] = e;
+    s += e;
+  }
+  s = wave_sum(s);
+  for (int j = pb + lane; j < pe; j += kWave) o[j] = o[j] / s;
+}
+
+__global__ __launch_bounds__(kBlock) void seg_softmax_bwd_kernel(float* __restrict__ dst,
+                                                                 const float* __restrict__ ograd,
+                                                                 const float* __restrict__ val,
+                                                                 const int32_t* __restrict__ indptr, int seg_num,
+                                                                 long long nnz, int add) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long seg = static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (seg >= seg_num) return;
+  const long long off = static_cast<long long>(blockIdx.y) * nnz;
+  const int pb = indptr[seg], pe = indptr[seg + 1];
+  float s = 0.f;
+  for (int j = pb + lane; j < pe; j += kWave) s = fmaf(ograd[off + j], val[off + j], s);
+  s = wave_sum(s);
+  for (int j = pb + lane; j < pe; j += kWave) {
+    const float g = val[off + j] * (ograd[off + j] - s);
+    dst[off + j] = add ? (dst[off + j] + g) : g;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// seg_pool max forward: one wave per (segment, batch); lanes over channels; edges in CSR order with a
+// strict '>' so the first maximum wins; empty segment -> 0 / -1 (reference seg_op.cc:264-283).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void seg_pool_max_kernel(float* __restrict__ dst, int32_t* __restrict__ arg,
+                                                              const float* __restrict__ data,
+                                                              const int32_t* __restrict__ indices,
+                                                              const int32_t* __restrict__ indptr, int seg_num,
+                                                              long long total, int C) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long seg = static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (seg >= seg_num) return;
+  const int k = blockIdx.y;
+  const int pb = indptr[seg], pe = indptr[seg + 1];
+  const float* base = data + static_cast<long long>(k) * total * C;
+  const long long orow = (static_cast<long long>(k) * seg_num + seg) * C;
+  for (int c = lane; c < C; c += kWave) {
+    float best = (pe == pb) ? 0.f : -3.402823466e+38f;
+    int bi = -1;
+    for (int j = pb; j < pe; ++j) {
+      const float v = base[static_cast<long long>(indices[j]) * C + c];
+      if (v > best) { best = v; bi = j; }
+    }
+    dst[orow + c] = best;
+    arg[orow + c] = bi;
+  }
+}
+
+// seg_pool max backward over the transposed plan: ddata[n,c] (+)= sum_p ograd[t_seg[p],c] * (arg[t_seg[p],c]==t_pos[p])
+__global__ __launch_bounds__(kBlock) void seg_pool_max_bwd_kernel(float* __restrict__ ddata,
+                                                                  const float* __restrict__ ograd,
+                                                                  const int32_t* __restrict__ arg,
+                                                                  const int32_t* __restrict__ t_indptr,
+                                                                  const int32_t* __restrict__ t_pos,
+                                                                  const int32_t* __restrict__ t_seg, int seg_num,
+                                                                  long long total, int C, int add) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const long long n = static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+  if (n >= total) return;
+  const int k = blockIdx.y;
+  const int pb = t_indptr[n], pe = t_indptr[n + 1];
+  const long long gbase = static_cast<long long>(k) * seg_num * C;
+  float* o = ddata + (static_cast<long long>(k) * total + n) * C;
+  for (int c = lane; c < C; c += kWave) {
+    float acc = 0.f;
+    for (int p = pb; p < pe; ++p) {
+      const long long r = gbase + static_cast<long long>(t_seg[p]) * C + c;
+      acc += (arg[r] == t_pos[p]) ? ograd[r] : 0.f;
+    }
+    o[c] = add ? (o[c] + acc) : acc;
+  }
+}
+
+// w_e[p] = 1 / len(segment of transposed edge p)   (avg-pool backward weights)
+__global__ void inv_len_kernel(float* __restrict__ w, const int32_t* __restrict__ t_seg,
+                               const int32_t* __restrict__ indptr, const int32_t* __restrict__ t_indptr,
+                               long long total) {
+  const long long p = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= t_indptr[total]) return;
+  const int s = t_seg[p];
+  w[p] = 1.f / static_cast<float>(indptr[s + 1] - indptr[s]);
+}
+
+static inline dim3 seg_grid(int64_t segs, int64_t batch) {
+  return dim3(static_cast<unsigned>((segs + kWavesPerBlock - 1) / kWavesPerBlock), static_cast<unsigned>(batch));
+}
+
+static int common_checks(int req, int64_t batch, int64_t seg_num, int64_t nnz) {
+  if (!valid_req(req)) return fail(SG_ERR_INVALID, "req must be 0, 1 or 3, got %d", req);
+  if (batch < 0 || seg_num < 0 || nnz < 0) return fail(SG_ERR_INVALID, "negative dimension");
+  if (batch > 65535) return fail(SG_ERR_INVALID, "batch > 65535 not supported");
+  if (seg_num >= (1ll << 31) - 1 || nnz >= (1ll << 31) - 1) return fail(SG_ERR_INVALID, "int32 index overflow");
+  return SG_OK;
+}
+
+}  // namespace sg
+
+using namespace sg;
+
+SG_API int sg_seg_take_k_corr_hip(float* dst, const float* embed1, const float* embed2, const int32_t* neighbor_ids,
+                                  const int32_t* neighbor_indptr, int64_t K, int64_t node_num,
+                                  int64_t neighbor_node_num, int64_t nnz, int64_t feat_dim, int req, void* stream) {
+  if (int rc = common_checks(req, K, node_num, nnz)) return rc;
+  if (req == SG_REQ_NULL || K == 0 || nnz == 0) return SG_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (req == SG_REQ_WRITE)
+    hipLaunchKernelGGL(zero_uncovered_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256), static_cast<unsigned>(K)),
+                       dim3(256), 0, st, dst, neighbor_indptr, static_cast<int>(node_num), static_cast<long long>(nnz));
+  if (node_num > 0) {
+    int lpr = 1;
+    while (lpr < kWave && lpr < feat_dim) lpr <<= 1;
+    hipLaunchKernelGGL(take_k_corr_kernel, seg_grid(node_num, K), dim3(kBlock), 0, st, dst, embed1, embed2,
+                       neighbor_ids, neighbor_indptr, static_cast<int>(node_num),
+                       static_cast<long long>(neighbor_node_num), static_cast<long long>(nnz),
+                       static_cast<int>(feat_dim), lpr, req == SG_REQ_ADD);
+  }
+  return check_launch("seg_take_k_corr");
+}
+
+SG_API int sg_seg_sum_hip(float* dst, const float* data, const int32_t* indptr, int64_t batch, int64_t seg_num,
+                          int64_t nnz, int req, void* stream) {
+  if (int rc = common_checks(req, batch, seg_num, nnz)) return rc;
+  if (req == SG_REQ_NULL || batch == 0 || seg_num == 0) return SG_OK;
+  hipLaunchKernelGGL(seg_sum_kernel, seg_grid(seg_num, batch), dim3(kBlock), 0, static_cast<hipStream_t>(stream), dst,
+                     data, indptr, static_cast<int>(seg_num), static_cast<long long>(nnz), req == SG_REQ_ADD);
+  return check_launch("seg_sum");
+}
+
+SG_API int sg_seg_broadcast_hip(float* dst, const float* lhs, const float* rhs, const int32_t* indptr, int64_t batch,
+                                int64_t seg_num, int64_t nnz, int op, int req, void* stream) {
+  if (int rc = common_checks(req, batch, seg_num, nnz)) return rc;
+  if (op < 0 || op > 2) return fail(SG_ERR_INVALID, "op must be 0 (add), 1 (mul) or 2 (to)");
+  if (op != 2 && lhs == nullptr && nnz > 0) return fail(SG_ERR_INVALID, "lhs is null");
+  if (req == SG_REQ_NULL || batch == 0 || nnz == 0) return SG_OK;
+  hipLaunchKernelGGL(seg_broadcast_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256), static_cast<unsigned>(batch)),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), dst, lhs, rhs, indptr, static_cast<int>(seg_num),
+                     static_cast<long long>(nnz), op, req == SG_REQ_ADD);
+  return check_launch("seg_broadcast");
+}
+
+SG_API int sg_seg_softmax_hip(float* dst, const float* data, const int32_t* indptr, int64_t batch, int64_t seg_num,
+                              int64_t nnz, int req, void* stream) {
+  if (int rc = common_checks(req, batch, seg_num, nnz)) return rc;
+  if (req == SG_REQ_ADD) return fail(SG_ERR_UNSUPPORTED, "AddTo for seg_softmax is not supported (as the reference)");
+  if (req == SG_REQ_NULL || batch == 0 || nnz == 0) return SG_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(zero_uncovered_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256), static_cast<unsigned>(batch)),
+                     dim3(256), 0, st, dst, indptr, static_cast<int>(seg_num), static_cast<long long>(nnz));
+  if (seg_num > 0)
+    hipLaunchKernelGGL(seg_softmax_kernel, seg_grid(seg_num, batch), dim3(kBlock), 0, st, dst, data, indptr,
+                       static_cast<int>(seg_num), static_cast<long long>(nnz));
+  return check_launch("seg_softmax");
+}
+
+SG_API int sg_seg_softmax_bwd_hip(float* dst, const float* ograd, const float* val, const int32_t* indptr,
+                                  int64_t batch, int64_t seg_num, int64_t nnz, int req, void* stream) {
+  if (int rc = common_checks(req, batch, seg_num, nnz)) return rc;
+  if (req == SG_REQ_NULL || batch == 0 || nnz == 0) return SG_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (req == SG_REQ_WRITE)
+    hipLaunchKernelGGL(zero_uncovered_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256), static_cast<unsigned>(batch)),
+                       dim3(256), 0, st, dst, indptr, static_cast<int>(seg_num), static_cast<long long>(nnz));
+  if (seg_num > 0)
+    hipLaunchKernelGGL(seg_softmax_bwd_kernel, seg_grid(seg_num, batch), dim3(kBlock), 0, st, dst, ograd, val, indptr,
+                       static_cast<int>(seg_num), static_cast<long long>(nnz), req == SG_REQ_ADD);
+  return check_launch("seg_softmax_bwd");
+}
+
+SG_API size_t sg_seg_pool_workspace_bytes(int64_t batch, int64_t seg_num, int64_t nnz, int64_t feat_dim) {
+  (void)seg_num;
+  return gather_workspace_bytes(batch, nnz, feat_dim);
+}
+
+SG_API int sg_seg_pool_hip(float* dst, int32_t* pool_indices, const float* data, const int32_t* indices,
+                           const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t total_ind_num, int64_t nnz,
+                           int64_t feat_dim, int pool_type, int req, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  if (int rc = common_checks(req, batch, seg_num, nnz)) return rc;
+  if (req == SG_REQ_ADD) return fail(SG_ERR_UNSUPPORTED, "AddTo for seg_pool forward is not supported (as the reference)");
+  if (pool_type < SG_POOL_SUM || pool_type > SG_POOL_MAX) return fail(SG_ERR_INVALID, "bad pool_type %d", pool_type);
+  if (req == SG_REQ_NULL || batch == 0 || seg_num == 0 || feat_dim == 0) return SG_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (pool_type == SG_POOL_MAX) {
+    if (!pool_indices) return fail(SG_ERR_INVALID, "pool_indices is required for max pooling");
+    hipLaunchKernelGGL(seg_pool_max_kernel, seg_grid(seg_num, batch), dim3(kBlock), 0, st, dst, pool_indices, data,
+                       indices, indptr, static_cast<int>(seg_num), static_cast<long long>(total_ind_num),
+                       static_cast<int>(feat_dim));
+    return check_launch("seg_pool_max");
+  }
+  return launch_gather(dst, 1, feat_dim, seg_num * feat_dim, data, 1, feat_dim, total_ind_num * feat_dim, nullptr, 0,
+                       nullptr, indices, indptr, batch, seg_num, nnz, feat_dim, req, pool_type == SG_POOL_AVG, SG_ACT_NONE, 0.f,
+                       workspace, workspace_bytes, st);
+}
+
+SG_API size_t sg_seg_pool_bwd_workspace_bytes(int64_t batch, int64_t total_ind_num, int64_t nnz, int64_t feat_dim) {
+  (void)total_ind_num;
+  return gather_workspace_bytes(batch, nnz, feat_dim) + static_cast<size_t>(nnz) * sizeof(float) + 16;
+}
+
+SG_API int sg_seg_pool_bwd_hip(float* ddata, const float* ograd, const int32_t* pool_indices, const int32_t* indptr,
+                               const int32_t* t_indptr, const int32_t* t_pos, const int32_t* t_seg, int64_t batch,
+                               int64_t seg_num, int64_t total_ind_num, int64_t nnz, int64_t feat_dim, int pool_type,
+                               int req, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = common_checks(req, batch, seg_num, nnz)) return rc;
+  if (pool_type < SG_POOL_SUM || pool_type > SG_POOL_MAX) return fail(SG_ERR_INVALID, "bad pool_type %d", pool_type);
+  if (req == SG_REQ_NULL || batch == 0 || total_ind_num == 0 || feat_dim == 0) return SG_OK;
+  if (!t_indptr || (nnz > 0 && (!t_pos || !t_seg))) return fail(SG_ERR_INVALID, "transposed plan is required");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (pool_type == SG_POOL_MAX) {
+    if (!pool_indices) return fail(SG_ERR_INVALID, "pool_indices is required for max pooling");
+    hipLaunchKernelGGL(seg_pool_max_bwd_kernel, seg_grid(total_ind_num, batch), dim3(kBlock), 0, st, ddata, ograd,
+                       pool_indices, t_indptr, t_pos, t_seg, static_cast<int>(seg_num),
+                       static_cast<long long>(total_ind_num), static_cast<int>(feat_dim), req == SG_REQ_ADD);
+    return check_launch("seg_pool_max_bwd");
+  }
+  const size_t gbytes = gather_workspace_bytes(batch, nnz, feat_dim);
+  if (!workspace || workspace_bytes < gbytes + static_cast<size_t>(nnz) * sizeof(float) + 16)
+    return fail(SG_ERR_WORKSPACE, "workspace too small for seg_pool backward");
+  const float* w = nullptr;
+  if (pool_type == SG_POOL_AVG && nnz > 0) {
+    char* p = static_cast<char*>(workspace) + gbytes;
+    p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 15) & ~static_cast<uintptr_t>(15));
+    float* wl = reinterpret_cast<float*>(p);
+    hipLaunchKernelGGL(inv_len_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256)), dim3(256), 0, st, wl, t_seg,
+                       indptr, t_indptr, static_cast<long long>(total_ind_num));
+    w = wl;
+  }
+  // same weights for every batch element (w_bs = 0)
+  return launch_gather(ddata, 1, feat_dim, total_ind_num * feat_dim, ograd, 1, feat_dim, seg_num * feat_dim, w, 0,
+                       nullptr, t_seg, t_indptr, batch, total_ind_num, nnz, feat_dim, req, 0, SG_ACT_NONE, 0.f, workspace, gbytes,
+                       st);
+}

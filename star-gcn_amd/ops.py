@@ -1,0 +1,204 @@
+"""Thin, autograd-free wrappers over the C ABI (include/stargcn.h) on torch CUDA tensors.
+
+Every function enqueues on the current torch stream and never synchronises.  Arguments are validated by
+the native side; errors surface as `StarGCNError` carrying `sg_last_error()`.
+"""
+import torch
+
+from . import _lib as L
+from ._lib import ACT, REQ_ADD, REQ_NULL, REQ_WRITE  # noqa: F401  (re-exported)
+
+
+def _act_id(act):
+    if isinstance(act, int):
+        return act
+    if act not in ACT:
+        raise L.StarGCNError("unsupported activation %r for the fused path" % (act,))
+    return ACT[act]
+
+
+def gather_sum(dst, src, indices, indptr, weights, seg_num, feat_dim, dst_group=1, dst_ld=None, src_group=1,
+               src_ld=None, req=REQ_WRITE, act=None, slope=0.1):
+    """dst[row(s)] (+)= act( sum_j w[j] * src[row(idx[j])] )  -- sg_seg_gather_sum_hip (strided/grouped rows)."""
+    L.require_gpu(dst, src, indices, indptr, weights)
+    nnz = indices.numel()
+    dst_ld = feat_dim * dst_group if dst_ld is None else dst_ld
+    src_ld = feat_dim * src_group if src_ld is None else src_ld
+    lib = L.lib()
+    wsb = lib.sg_seg_weighted_pool_workspace_bytes(1, seg_num, nnz, feat_dim)
+    ws, wsn = L.workspace(wsb, dst.device)
+    L.check(lib.sg_seg_gather_sum_hip(L.ptr(dst), dst_group, dst_ld, L.ptr(src), src_group, src_ld, L.ptr(weights),
+                                      L.ptr(indices), L.ptr(indptr), seg_num, nnz, feat_dim, req, _act_id(act),
+                                      float(slope), L.ptr(ws), wsn, L.stream_ptr()), "sg_seg_gather_sum_hip")
+    return dst
+
+
+def seg_weighted_pool(data, weights, indices, indptr, out=None, req=REQ_WRITE):
+    """reference `_contrib_seg_weighted_pool` forward (seg_op.cc:665-716)."""
+    L.require_gpu(data, weights, indices, indptr)
+    B, T, C = data.shape
+    nnz = indices.numel()
+    S = indptr.numel() - 1
+    if out is None:
+        out = torch.empty((B, S, C), dtype=torch.float32, device=data.device)
+    lib = L.lib()
+    ws, wsn = L.workspace(lib.sg_seg_weighted_pool_workspace_bytes(B, S, nnz, C), data.device)
+    L.check(lib.sg_seg_weighted_pool_hip(L.ptr(out), L.ptr(data), L.ptr(weights), L.ptr(indices), L.ptr(indptr), B, S,
+                                         T, nnz, C, req, L.ptr(ws), wsn, L.stream_ptr()), "sg_seg_weighted_pool_hip")
+    return out
+
+
+def seg_weighted_pool_bwd_data(weights, ograd, tplan, total_ind_num, out=None, req=REQ_WRITE):
+    """gradient of seg_weighted_pool w.r.t. data through a cached TransposePlan (reference seg_op.cc:700-703)."""
+    L.require_gpu(weights, ograd)
+    B, S, C = ograd.shape
+    nnz = weights.shape[1]
+    T = int(total_ind_num)
+    if out is None:
+        out = torch.empty((B, T, C), dtype=torch.float32, device=ograd.device)
+    lib = L.lib()
+    ws, wsn = L.workspace(lib.sg_seg_weighted_pool_bwd_data_workspace_bytes(B, T, nnz, C), ograd.device)
+    L.check(lib.sg_seg_weighted_pool_bwd_data_hip(L.ptr(out), L.ptr(weights), L.ptr(ograd), L.ptr(tplan.t_indptr),
+                                                  L.ptr(tplan.t_pos), L.ptr(tplan.t_seg), B, S, T, nnz, C, req,
+                                                  L.ptr(ws), wsn, L.stream_ptr()), "sg_seg_weighted_pool_bwd_data_hip")
+    return out
+
+
+def seg_take_k_corr(embed1, embed2, neighbor_ids, neighbor_indptr, out=None, req=REQ_WRITE):
+    L.require_gpu(embed1, embed2, neighbor_ids, neighbor_indptr)
+    K, N, C = embed1.shape
+    M = embed2.shape[1]
+    nnz = neighbor_ids.numel()
+    if out is None:
+        out = torch.empty((K, nnz), dtype=torch.float32, device=embed1.device)
+    L.check(L.lib().sg_seg_take_k_corr_hip(L.ptr(out), L.ptr(embed1), L.ptr(embed2), L.ptr(neighbor_ids),
+                                           L.ptr(neighbor_indptr), K, N, M, nnz, C, req, L.stream_ptr()),
+            "sg_seg_take_k_corr_hip")
+    return out
+
+
+def seg_sum(data, indptr, out=None, req=REQ_WRITE):
+    L.require_gpu(data, indptr)
+    B, nnz = data.shape
+    S = indptr.numel() - 1
+    if out is None:
+        out = torch.empty((B, S), dtype=torch.float32, device=data.device)
+    L.check(L.lib().sg_seg_sum_hip(L.ptr(out), L.ptr(data), L.ptr(indptr), B, S, nnz, req, L.stream_ptr()),
+            "sg_seg_sum_hip")
+    return out
+
+
+def seg_broadcast(lhs, rhs, indptr, op, nnz=None, out=None, req=REQ_WRITE):
+    L.require_gpu(rhs, indptr, lhs)
+    B, S = rhs.shape
+    nnz = lhs.shape[1] if lhs is not None else int(nnz)
+    if out is None:
+        out = torch.empty((B, nnz), dtype=torch.float32, device=rhs.device)
+    L.check(L.lib().sg_seg_broadcast_hip(L.ptr(out), L.ptr(lhs), L.ptr(rhs), L.ptr(indptr), B, S, nnz, op, req,
+                                         L.stream_ptr()), "sg_seg_broadcast_hip")
+    return out
+
+
+def seg_softmax(data, indptr):
+    L.require_gpu(data, indptr)
+    B, nnz = data.shape
+    out = torch.empty_like(data)
+    L.check(L.lib().sg_seg_softmax_hip(L.ptr(out), L.ptr(data), L.ptr(indptr), B, indptr.numel() - 1, nnz, REQ_WRITE,
+                                       L.stream_ptr()), "sg_seg_softmax_hip")
+    return out
+
+
+def seg_softmax_bwd(ograd, val, indptr, out=None, req=REQ_WRITE):
+    L.require_gpu(ograd, val, indptr)
+    B, nnz = ograd.shape
+    if out is None:
+        out = torch.empty_like(ograd)
+    L.check(L.lib().sg_seg_softmax_bwd_hip(L.ptr(out), L.ptr(ograd), L.ptr(val), L.ptr(indptr), B, indptr.numel() - 1,
+                                           nnz, req, L.stream_ptr()), "sg_seg_softmax_bwd_hip")
+    return out
+
+
+def seg_pool(data, indices, indptr, pool_type):
+    L.require_gpu(data, indices, indptr)
+    B, T, C = data.shape
+    nnz = indices.numel()
+    S = indptr.numel() - 1
+    out = torch.empty((B, S, C), dtype=torch.float32, device=data.device)
+    arg = torch.empty((B, S, C), dtype=torch.int32, device=data.device) if pool_type == "max" else None
+    lib = L.lib()
+    ws, wsn = L.workspace(lib.sg_seg_pool_workspace_bytes(B, S, nnz, C), data.device)
+    L.check(lib.sg_seg_pool_hip(L.ptr(out), L.ptr(arg), L.ptr(data), L.ptr(indices), L.ptr(indptr), B, S, T, nnz, C,
+                                L.POOL[pool_type], REQ_WRITE, L.ptr(ws), wsn, L.stream_ptr()), "sg_seg_pool_hip")
+    return out, arg
+
+
+def seg_pool_bwd(ograd, pool_indices, indptr, tplan, total_ind_num, pool_type, out=None, req=REQ_WRITE):
+    L.require_gpu(ograd, indptr)
+    B, S, C = ograd.shape
+    T = int(total_ind_num)
+    nnz = tplan.nnz
+    if out is None:
+        out = torch.empty((B, T, C), dtype=torch.float32, device=ograd.device)
+    lib = L.lib()
+    ws, wsn = L.workspace(lib.sg_seg_pool_bwd_workspace_bytes(B, T, nnz, C), ograd.device)
+    L.check(lib.sg_seg_pool_bwd_hip(L.ptr(out), L.ptr(ograd), L.ptr(pool_indices), L.ptr(indptr), L.ptr(tplan.t_indptr),
+                                    L.ptr(tplan.t_pos), L.ptr(tplan.t_seg), B, S, T, nnz, C, L.POOL[pool_type], req,
+                                    L.ptr(ws), wsn, L.stream_ptr()), "sg_seg_pool_bwd_hip")
+    return out
+
+
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=None, slope=0.1, out=None, accumulate=False):
+    """out[M,N] = act(op(a) @ op(b) + bias (+ out)) on the fp32 MFMA kernel.  2-D tensors whose last stride is 1
+    (row strides = leading dims are honoured, so column slices of a wider matrix work)."""
+    L.require_gpu(a, b, bias, out)
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    Kb, N = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if K != Kb:
+        raise L.StarGCNError("gemm: inner dimensions differ (%d vs %d)" % (K, Kb))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    assert out.stride(1) == 1 or N == 1
+    lda = a.stride(0) if a.shape[0] > 1 else max(a.shape[1], 1)
+    ldb = b.stride(0) if b.shape[0] > 1 else max(b.shape[1], 1)
+    ldc = out.stride(0) if out.shape[0] > 1 else max(N, 1)
+    lib = L.lib()
+    ws, wsn = L.workspace(lib.sg_gemm_f32_workspace_bytes(M, N, K, int(trans_a)), a.device)
+    L.check(lib.sg_gemm_f32_hip(L.ptr(out), ldc, L.ptr(a), lda, int(trans_a), L.ptr(b), ldb, int(trans_b), M, N, K,
+                                L.ptr(bias), _act_id(act), float(slope), int(accumulate), L.ptr(ws), wsn,
+                                L.stream_ptr()), "sg_gemm_f32_hip")
+    return out
+
+
+def act_bwd(dout, out_act, act, slope=0.1):
+    """dpre = dout * act'(.) computed from the activation output."""
+    if _act_id(act) == 0:
+        return dout
+    L.require_gpu(dout, out_act)
+    dout = L.f32c(dout)
+    dpre = torch.empty_like(dout)
+    L.check(L.lib().sg_act_bwd_hip(L.ptr(dpre), L.ptr(dout), L.ptr(out_act), dout.numel(), _act_id(act), float(slope),
+                                   L.stream_ptr()), "sg_act_bwd_hip")
+    return dpre
+
+
+def colsum(x):
+    L.require_gpu(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, N = x.shape
+    out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    lib = L.lib()
+    ws, wsn = L.workspace(lib.sg_colsum_workspace_bytes(M, N), x.device)
+    L.check(lib.sg_colsum_hip(L.ptr(out), L.ptr(x), x.stride(0) if M > 1 else N, M, N, REQ_WRITE, L.ptr(ws), wsn,
+                              L.stream_ptr()), "sg_colsum_hip")
+    return out
+
+
+def masked_embed(table, ids, noise=None):
+    """reference Net.get_embed (STAR-GCN.py:290-299): rows of `table` at noise[ids] (or ids), zero where -1."""
+    L.require_gpu(table, ids, noise)
+    n = ids.numel()
+    out = torch.empty((n, table.shape[1]), dtype=torch.float32, device=table.device)
+    L.check(L.lib().sg_masked_embed_hip(L.ptr(out), L.ptr(table), L.ptr(ids), L.ptr(noise), n, table.shape[0],
+                                        table.shape[1], L.stream_ptr()), "sg_masked_embed_hip")
+    return out

@@ -1,0 +1,146 @@
+"""Aggregation plans: integer structure that is built ONCE per graph by native host code and kept resident in
+HBM, instead of being re-sorted on every backward call (reference seg_op.cu:906-925) and re-uploaded on every
+forward call (reference layers.py:366-377).
+"""
+import collections
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _np_i32(a):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _np_f32(a):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class TransposePlan(object):
+    """Stable transpose of a CSR (indices, indptr): for every source row n the edges j with indices[j] == n in
+    increasing j (t_pos) and the segment each belongs to (t_seg).  Same summation order as the reference's
+    stable radix sort + run scan (seg_op.cu:906-925)."""
+
+    def __init__(self, indices, indptr, total_ind_num, device):
+        idx, ip = _np_i32(indices), _np_i32(indptr)
+        S, nnz, T = ip.shape[0] - 1, idx.shape[0], int(total_ind_num)
+        t_indptr = np.empty(T + 1, np.int32)
+        t_pos = np.empty(max(nnz, 1), np.int32)
+        t_seg = np.empty(max(nnz, 1), np.int32)
+        L.check(L.lib().sg_build_transpose_cpu(_vp(t_indptr), _vp(t_pos), _vp(t_seg), _vp(idx), _vp(ip), S, T, nnz),
+                "sg_build_transpose_cpu")
+        self.seg_num, self.nnz, self.total_ind_num = S, nnz, T
+        self.covered = int(t_indptr[-1])
+        self.t_indptr = torch.from_numpy(t_indptr).to(device)
+        self.t_pos = torch.from_numpy(t_pos).to(device)
+        self.t_seg = torch.from_numpy(t_seg).to(device)
+
+
+_tplan_cache = collections.OrderedDict()
+_TPLAN_CACHE_MAX = 64
+
+
+def transpose_plan_for(indices, indptr, total_ind_num):
+    """Cached TransposePlan for device index tensors (first use copies them to the host once).  The cache holds
+    references to the key tensors so their storage cannot be recycled under a stale entry."""
+    key = (indices.data_ptr(), indptr.data_ptr(), indices._version, indptr._version, indices.numel(),
+           indptr.numel(), int(total_ind_num), str(indices.device))
+    hit = _tplan_cache.get(key)
+    if hit is not None:
+        _tplan_cache.move_to_end(key)
+        return hit[0]
+    plan = TransposePlan(indices, indptr, total_ind_num, indices.device)
+    _tplan_cache[key] = (plan, indices, indptr)
+    while len(_tplan_cache) > _TPLAN_CACHE_MAX:
+        _tplan_cache.popitem(last=False)
+    return plan
+
+
+class MultiLinkPlan(object):
+    """The R per-rating-level CSRs of one (destination type, source type) aggregation (the `end_points_l`,
+    `indptr_l`, `support_l` lists of reference aggregators.py:111-149) fused into ONE CSR over n_dst*R segments
+    plus its transpose over n_src*R segments, resident on the device.
+
+    c_*: segment i*R+r lists the level-r neighbours of destination i   (c_idx = source node, c_q = node*R+r)
+    t_*: segment n*R+r lists the destinations reached from source n    (t_idx = dest node,   t_q = node*R+r)
+    d_indptr / s_indptr: the same edge arrays viewed as un-split CSRs over n_dst / n_src rows.
+    """
+
+    def __init__(self, end_points_l, indptr_l, support_l, n_src, device):
+        R = len(end_points_l)
+        if R == 0 or len(indptr_l) != R or len(support_l) != R:
+            raise L.StarGCNError("MultiLinkPlan needs equally long, non-empty per-level lists")
+        ips = [_np_i32(a) for a in indptr_l]
+        n_dst = ips[0].shape[0] - 1
+        for a in ips:
+            if a.shape[0] != n_dst + 1:
+                raise L.StarGCNError("every level must carry a full-length indptr (n_dst+1)")
+        eps = [_np_i32(a) for a in end_points_l]
+        sps = [_np_f32(a) for a in support_l]
+        nnz = int(sum(int(a[-1]) for a in ips))
+        for r in range(R):  # padding (empty_as_zero, reference graph.py:221-222) may make arrays longer, never shorter
+            if eps[r].shape[0] < ips[r][-1] or sps[r].shape[0] < ips[r][-1]:
+                raise L.StarGCNError("level %d: end_points/support shorter than indptr[-1]" % r)
+        n_src = int(n_src)
+        m = max(nnz, 1)
+        c_indptr = np.empty(n_dst * R + 1, np.int32)
+        t_indptr = np.empty(n_src * R + 1, np.int32)
+        c_idx, c_q, t_idx, t_q = (np.zeros(m, np.int32) for _ in range(4))
+        c_w, t_w = np.zeros(m, np.float32), np.zeros(m, np.float32)
+        arr = ctypes.c_void_p * R
+        L.check(L.lib().sg_multilink_fuse_cpu(
+            _vp(c_indptr), _vp(c_idx), _vp(c_q), _vp(c_w), _vp(t_indptr), _vp(t_idx), _vp(t_q), _vp(t_w),
+            ctypes.cast(arr(*[a.ctypes.data for a in eps]), ctypes.c_void_p),
+            ctypes.cast(arr(*[a.ctypes.data for a in ips]), ctypes.c_void_p),
+            ctypes.cast(arr(*[a.ctypes.data for a in sps]), ctypes.c_void_p), R, n_dst, n_src),
+            "sg_multilink_fuse_cpu")
+        self.R, self.n_dst, self.n_src, self.nnz, self.device = R, n_dst, n_src, nnz, torch.device(device)
+        up = lambda a: torch.from_numpy(a).to(device)
+        self.c_indptr, self.c_idx, self.c_q, self.c_w = up(c_indptr), up(c_idx), up(c_q), up(c_w)
+        self.t_indptr, self.t_idx, self.t_q, self.t_w = up(t_indptr), up(t_idx), up(t_q), up(t_w)
+        self.d_indptr = up(np.ascontiguousarray(c_indptr[::R]))
+        self.s_indptr = up(np.ascontiguousarray(t_indptr[::R]))
+        self._rowsum = None
+
+    @property
+    def rowsum(self):
+        """(n_dst, R): sum of the support over each (node, level) segment -- the factor that scales the level bias
+        when the contraction is applied after aggregation (A_r (X W^T + 1 b^T) = (A_r X) W^T + (A_r 1) b^T)."""
+        if self._rowsum is None:
+            from . import ops
+            if self.nnz == 0:
+                self._rowsum = torch.zeros((self.n_dst, self.R), dtype=torch.float32, device=self.device)
+            else:
+                self._rowsum = ops.seg_sum(self.c_w.view(1, -1), self.c_indptr).view(self.n_dst, self.R)
+        return self._rowsum
+
+
+class TakePlan(object):
+    """Row gather `out[i] = table[ids[i]]` (ids == -1 -> zero row) with an atomic-free gradient: the transposed
+    plan groups the positions i by id, so d table[n] = sum of dout rows in segment n (gather kernel again)."""
+
+    def __init__(self, ids, n_rows, device):
+        ids = _np_i32(ids)
+        n = ids.shape[0]
+        self.n, self.n_rows = n, int(n_rows)
+        valid = ids >= 0
+        order = np.nonzero(valid)[0].astype(np.int32)
+        order = order[np.argsort(ids[order], kind="stable")]
+        counts = np.bincount(ids[valid], minlength=self.n_rows).astype(np.int64)
+        indptr = np.zeros(self.n_rows + 1, np.int32)
+        np.cumsum(counts, out=indptr[1:])
+        self.ids = torch.from_numpy(ids).to(device)
+        self.t_indptr = torch.from_numpy(indptr).to(device)
+        self.t_pos = torch.from_numpy(np.ascontiguousarray(order if order.size else np.zeros(1, np.int32))).to(device)
+        self.covered = int(order.size)

@@ -1,0 +1,148 @@
+"""CPU-runnable checks: the C-ABI library loads and exports every symbol include/stargcn.h declares, and the
+host-side (`_cpu`) plan/graph helpers match the oracle.  No compute kernels are called (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import star_gcn_amd._lib as L
+from oracle import seg as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "stargcn.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sg_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_symbols()
+    assert len(names) >= 25
+    handle = ctypes.CDLL(L.SO_PATH)
+    for n in names:
+        assert hasattr(handle, n), "libstargcn_hip.so does not export %s" % n
+    assert sorted(L.exported_symbols()) == names, "ctypes table and header disagree"
+    assert L.lib().sg_version() >= 100
+
+
+def test_errors_are_codes_not_exit():
+    lib = L.lib()
+    rc = lib.sg_build_transpose_cpu(None, None, None, None, None, -1, 0, 0)
+    assert rc < 0 and b"negative" in lib.sg_last_error()
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def test_build_transpose_matches_stable_sort():
+    rng = np.random.default_rng(3)
+    S, T, nnz = 50, 37, 700
+    cuts = np.sort(rng.integers(0, nnz - 20, S - 1))
+    indptr = np.concatenate([[0], cuts, [nnz - 20]]).astype(np.int32)  # 20 padding edges past indptr[-1]
+    indices = rng.integers(0, T, nnz).astype(np.int32)
+    t_indptr, t_pos, t_seg = np.empty(T + 1, np.int32), np.empty(nnz, np.int32), np.empty(nnz, np.int32)
+    L.check(L.lib().sg_build_transpose_cpu(_vp(t_indptr), _vp(t_pos), _vp(t_seg), _vp(indices), _vp(indptr), S, T, nnz))
+    E = int(indptr[-1])
+    order = np.argsort(indices[:E], kind="stable")
+    assert t_indptr[-1] == E
+    assert np.array_equal(t_pos[:E], order.astype(np.int32))
+    seg_of = np.repeat(np.arange(S), np.diff(indptr)).astype(np.int32)
+    assert np.array_equal(t_seg[:E], seg_of[order])
+    assert np.array_equal(np.diff(t_indptr), np.bincount(indices[:E], minlength=T))
+
+
+def test_get_support_and_multi_link_split_match_oracle():
+    rng = np.random.default_rng(4)
+    N, M, nnz = 40, 30, 500
+    cuts = np.sort(rng.integers(0, nnz + 1, N - 1))
+    ip = np.concatenate([[0], cuts, [nnz]]).astype(np.int32)
+    ep = rng.integers(0, M, nnz).astype(np.int32)
+    rd = np.diff(ip).astype(np.int32)
+    cd = np.bincount(ep, minlength=M).astype(np.int32)
+    cd[3] = 0  # force a zero-degree column: support must be 0 there
+    for symm in (1, 0):
+        got = np.empty(nnz, np.float32)
+        L.check(L.lib().sg_get_support_cpu(_vp(got), _vp(rd), _vp(cd), _vp(ep), _vp(ip), N, symm))
+        np.testing.assert_array_equal(got, O.get_support(rd, cd, ep, ip, symm=bool(symm)))
+    levels = np.array([0.5, 1.0, 2.5, 4.0], np.float32)
+    vals = levels[rng.integers(0, 4, nnz)]
+    pos = np.empty(nnz, np.int32)
+    ips = np.empty((4, N + 1), np.int32)
+    off = np.empty(5, np.int64)
+    L.check(L.lib().sg_multi_link_split_cpu(_vp(pos), _vp(ips), _vp(off), _vp(vals), _vp(ip), _vp(levels), N, 4))
+    opos, oips = O.multi_link_split(vals, ip, levels)
+    for l in range(4):
+        assert np.array_equal(pos[off[l]:off[l + 1]], opos[l])
+        assert np.array_equal(ips[l], oips[l])
+    vals[7] = 3.0  # matches no level -> error code, not exit()
+    assert L.lib().sg_multi_link_split_cpu(_vp(pos), _vp(ips), _vp(off), _vp(vals), _vp(ip), _vp(levels), N, 4) == -4
+
+
+def make_multilink(rng, n_dst, n_src, nnz, R, pad_empty=True):
+    """Random per-level CSR lists the way reference gen_plan/heter_sage hands them to the aggregator."""
+    cuts = np.sort(rng.integers(0, nnz + 1, n_dst - 1))
+    ip = np.concatenate([[0], cuts, [nnz]]).astype(np.int32)
+    ep = rng.integers(0, n_src, nnz).astype(np.int32)
+    sup = rng.uniform(0.05, 1.0, nnz).astype(np.float32)
+    lev = rng.integers(0, R, nnz)
+    if R > 2:
+        lev[lev == R - 1] = 0  # make the last level empty (exercises empty_as_zero padding)
+    eps, ips, sps = [], [], []
+    for r in range(R):
+        sel = lev == r
+        cs = np.concatenate([[0], np.cumsum(sel.astype(np.int64))])
+        cnt = cs[ip[1:]] - cs[ip[:-1]]
+        ips.append(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32))
+        e, s = ep[sel], sup[sel]
+        if e.size == 0 and pad_empty:  # reference graph.py:221-222 empty_as_zero
+            e, s = np.zeros(1, np.int32), np.zeros(1, np.float32)
+        eps.append(e)
+        sps.append(s)
+    return eps, ips, sps
+
+
+def test_multilink_fuse_structure():
+    from star_gcn_amd.plan import MultiLinkPlan
+    rng = np.random.default_rng(5)
+    n_dst, n_src, nnz, R = 23, 17, 300, 4
+    eps, ips, sps = make_multilink(rng, n_dst, n_src, nnz, R)
+    plan = MultiLinkPlan(eps, ips, sps, n_src, "cpu")
+    assert plan.nnz == nnz
+    c_indptr, c_idx, c_w, c_q = (t.numpy() for t in (plan.c_indptr, plan.c_idx, plan.c_w, plan.c_q))
+    for i in range(n_dst):
+        for r in range(R):
+            a, b = c_indptr[i * R + r], c_indptr[i * R + r + 1]
+            assert np.array_equal(c_idx[a:b], eps[r][ips[r][i]:ips[r][i + 1]])
+            assert np.array_equal(c_w[a:b], sps[r][ips[r][i]:ips[r][i + 1]])
+            assert np.array_equal(c_q[a:b], c_idx[a:b] * R + r)
+    # dense check of both CSRs against the same (n_dst*R, n_src) matrix
+    A = np.zeros((n_dst * R, n_src))
+    for s in range(n_dst * R):
+        for j in range(c_indptr[s], c_indptr[s + 1]):
+            A[s, c_idx[j]] += c_w[j]
+    t_indptr, t_idx, t_w, t_q = (t.numpy() for t in (plan.t_indptr, plan.t_idx, plan.t_w, plan.t_q))
+    B = np.zeros_like(A)
+    for n in range(n_src):
+        for r in range(R):
+            seg = slice(t_indptr[n * R + r], t_indptr[n * R + r + 1])
+            assert np.all(np.diff(t_idx[seg]) >= 0)  # destinations in increasing order = original CSR order
+            assert np.array_equal(t_q[seg], t_idx[seg] * R + r)
+            for i, w in zip(t_idx[seg], t_w[seg]):
+                B[i * R + r, n] += w
+    np.testing.assert_allclose(A, B, rtol=0, atol=1e-6)
+    assert np.array_equal(plan.d_indptr.numpy(), c_indptr[::R])
+    assert np.array_equal(plan.s_indptr.numpy(), t_indptr[::R])
+
+
+def test_ops_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from star_gcn_amd import contrib
+    with pytest.raises(L.StarGCNError):
+        contrib.seg_sum(torch.zeros(1, 4), torch.tensor([0, 4], dtype=torch.int32))
