@@ -173,4 +173,6 @@ class _TakeRows(torch.autograd.Function):
 
 def take_rows(table, take_plan):
     """out[i] = table[ids[i]] (zero row where ids[i] == -1); gradient = segment sum over the TakePlan."""
+    if take_plan.identity:
+        return table
     return _TakeRows.apply(table, take_plan)

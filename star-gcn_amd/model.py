@@ -1,0 +1,233 @@
+"""STAR-GCN network on the MI355X-native hot path: counterpart of `Net` in reference
+experiments/STAR-GCN.py:167-461 (embedding + masked input :264-300, stacked encoder blocks :196-219, decoder
+`embed_maps` :222-246 / :440-459, rating projections + InnerProductLayer :249-261 / :428-438) and of the two
+losses of its training loop (:610-628).
+
+Host work is split from device work: `make_plan()` runs the reference's top-down planning once (numpy + native
+helpers) and leaves every index structure resident in HBM; `run()` is pure device work, so a training step
+re-uses the plan instead of rebuilding/uploading it (the reference rebuilds everything per iteration).
+
+The hyper-parameters that the reference reads from its global yaml config are constructor arguments here.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import dist as D
+from . import functional as SF
+from . import ops
+from .mxgraph import graph as G
+from .mxgraph.layers import (Dense, HeterGCNLayer, InnerProductLayer, LayerDictionary, StackedHeterGCNLayers,
+                             get_activation)
+from .plan import TakePlan, TransposePlan
+
+
+class PairPlan(object):
+    """(user, item) row-index pairs grouped by user into a CSR so the per-pair inner product of the rating head is
+    ONE `seg_take_k_corr` launch (and its gradients two gather launches) instead of two (#pairs, width) takes."""
+
+    def __init__(self, user_idx, item_idx, n_user, n_item, device):
+        user_idx, item_idx = np.asarray(user_idx, np.int64), np.asarray(item_idx, np.int64)
+        order = np.argsort(user_idx, kind="stable")
+        self.identity = bool(np.all(order == np.arange(order.size)))
+        indptr = np.zeros(n_user + 1, np.int64)
+        np.cumsum(np.bincount(user_idx, minlength=n_user), out=indptr[1:])
+        self.n_user, self.n_item, self.n_pairs = int(n_user), int(n_item), int(order.size)
+        items = np.ascontiguousarray(item_idx[order], dtype=np.int32)
+        indptr = indptr.astype(np.int32)
+        self.indptr = torch.from_numpy(indptr).to(device)
+        self.items = torch.from_numpy(items if items.size else np.zeros(1, np.int32)).to(device)
+        inv = np.empty_like(order)
+        inv[order] = np.arange(order.size)
+        self.inv_order = None if self.identity else torch.from_numpy(inv).to(device)
+        self.order = None if self.identity else torch.from_numpy(order).to(device)
+        self.tplan = TransposePlan(items, indptr, n_item, device)
+
+
+class _PairDot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pu, pi, pp):
+        pu, pi = L.f32c(pu), L.f32c(pi)
+        ctx.pp = pp
+        ctx.save_for_backward(pu, pi)
+        return ops.seg_take_k_corr(pu.unsqueeze(0), pi.unsqueeze(0), pp.items, pp.indptr).view(-1)[:pp.n_pairs]
+
+    @staticmethod
+    def backward(ctx, g):
+        pu, pi = ctx.saved_tensors
+        pp = ctx.pp
+        g = L.f32c(g).view(1, -1)
+        if g.shape[1] < pp.items.numel():
+            g = torch.nn.functional.pad(g, (0, pp.items.numel() - g.shape[1]))
+        d_u = ops.seg_weighted_pool(pi.unsqueeze(0), g, pp.items, pp.indptr)[0] if ctx.needs_input_grad[0] else None
+        d_i = (ops.seg_weighted_pool_bwd_data(g, pu.unsqueeze(0), pp.tplan, pp.n_item)[0]
+               if ctx.needs_input_grad[1] else None)
+        return d_u, d_i, None
+
+
+def pair_inner_product(pu, pi, pair_plan):
+    """score[p] = <pu[user_p], pi[item_p]> in the ORIGINAL pair order."""
+    s = _PairDot.apply(pu, pi, pair_plan)
+    return s if pair_plan.identity else s[pair_plan.inv_order]
+
+
+class Net(nn.Module):
+    def __init__(self, graph, name_user, name_item, embed_units=64, agg_units=(250,), out_units=(75,), nblocks=2,
+                 use_dae=True, use_recurrent=False, gcn_recurrent=False, activation="leaky", dropout=0.0,
+                 agg_accum="sum", norm_symm=True, rating_mid_map=64, agg_order="auto"):
+        super().__init__()
+        self._name_user, self._name_item = name_user, name_item
+        self._nblocks, self._use_dae, self._use_recurrent = nblocks, use_dae, use_recurrent
+        self._norm_symm = norm_symm
+        self._act_name = activation
+        self.embed_layers = LayerDictionary()
+        self._n_nodes = dict()
+        for key, ids in graph.node_ids_dict.items():
+            emb = nn.Embedding(ids.size, embed_units)
+            nn.init.uniform_(emb.weight, -0.1, 0.1)          # mx.init.Uniform(0.1), reference STAR-GCN.py:180
+            self.embed_layers[key] = emb
+            self._n_nodes[key] = int(ids.size)
+        self.encoders = nn.ModuleList()
+        for _ in range(1 if use_recurrent else nblocks):
+            enc = StackedHeterGCNLayers(recurrent_layer_num=len(agg_units) if gcn_recurrent else None)
+            for au, ou in zip(agg_units, out_units):
+                enc.add(HeterGCNLayer(meta_graph=graph.meta_graph,
+                                      multi_link_structure=graph.get_multi_link_structure(),
+                                      dropout_rate=dropout, agg_units=au, out_units=ou,
+                                      source_keys=list(graph.meta_graph.keys()), agg_accum=agg_accum,
+                                      agg_act=activation, out_act=activation, agg_order=agg_order))
+                if gcn_recurrent:
+                    break
+            self.encoders.append(enc)
+        if use_dae:
+            self.embed_maps = nn.ModuleList()
+            for _ in range(1 if use_recurrent else nblocks):
+                m = LayerDictionary()
+                for key in graph.meta_graph:
+                    m[key] = nn.Sequential(Dense(embed_units, activation=activation), Dense(embed_units))
+                self.embed_maps.append(m)
+        nproj = 1 if use_recurrent else nblocks
+        self.rating_user_projs = nn.ModuleList([Dense(rating_mid_map) for _ in range(nproj)])
+        self.rating_item_projs = nn.ModuleList([Dense(rating_mid_map) for _ in range(nproj)])
+        self.gen_ratings = InnerProductLayer()
+        self.pair_partition = None   # dist.NodePartition when node-partitioned across GPUs
+
+    def local_region_parameters(self):
+        """Parameters that receive PARTIAL gradients in a node-partitioned run (see dist.py): everything that
+        touches rank-local user rows or rank-local edges.  Item-side modules downstream of the all-reduce and the
+        embedding tables (item: replicated with total gradients; user: row-sharded) are excluded."""
+        part = self.pair_partition
+        rep = set() if part is None else part.replicated_keys
+        skip = set()
+        for key in rep:
+            for enc in self.encoders:
+                for layer in enc._blocks:
+                    if key in layer._out_fcs:
+                        skip.update(id(p) for p in layer._out_fcs[key].parameters())
+            if self._use_dae:
+                for m in self.embed_maps:
+                    skip.update(id(p) for p in m[key].parameters())
+        if self._name_item in rep:
+            skip.update(id(p) for p in self.rating_item_projs.parameters())
+        if self._name_user in rep:
+            skip.update(id(p) for p in self.rating_user_projs.parameters())
+        skip.update(id(p) for p in self.embed_layers.parameters())
+        return [p for p in self.parameters() if id(p) not in skip]
+
+    # ---- embeddings (reference STAR-GCN.py:264-300) ---------------------------------------------------
+    def _embed_plan(self, node_ids_dict, embed_noise_dict, use_mask, device):
+        plans = dict()
+        for key, ids in node_ids_dict.items():
+            ids = np.asarray(ids, np.int32)
+            if use_mask:
+                ids = np.asarray(embed_noise_dict[key], np.int32)[ids]   # -1 = zero-mask
+            plans[key] = TakePlan(ids, self._n_nodes[key], device)
+        return plans
+
+    def get_embed(self, embed_plans):
+        return {key: SF.take_rows(self.embed_layers[key].weight, p) for key, p in embed_plans.items()}
+
+    # ---- host-side planning (reference STAR-GCN.py:373-397) -------------------------------------------
+    def make_plan(self, graph, rating_node_pairs=None, embed_noise_dict=None, recon_node_ids_dict=None,
+                  graph_sampler_args=None, symm=None, device="cuda"):
+        symm = self._norm_symm if symm is None else symm
+        if rating_node_pairs is None and recon_node_ids_dict is None:
+            raise NotImplementedError
+        nb = self._nblocks
+        plan = dict(enc=[None] * nb, idx=[None] * nb, device=torch.device(device))
+        req = dict()
+        for b in range(nb - 1, -1, -1):
+            parts, names = [], []
+            if rating_node_pairs is not None:
+                parts.append({self._name_user: rating_node_pairs[0], self._name_item: rating_node_pairs[1]})
+                names.append("rating")
+            if recon_node_ids_dict is not None:
+                parts.append(recon_node_ids_dict)
+                names.append("recon")
+            parts.append(req)
+            names.append("req")
+            uniq, idx_l = G.merge_node_ids_dict(parts)
+            plan["idx"][b] = dict(zip(names, idx_l))
+            enc = self.encoders[0] if self._use_recurrent else self.encoders[b]
+            req, plan["enc"][b] = enc.gen_plan(graph=graph, sel_node_ids_dict=uniq,
+                                               graph_sampler_args=graph_sampler_args, symm=symm, device=device)
+            plan["idx"][b]["n_out"] = {k: int(v.shape[0]) for k, v in uniq.items()}
+        plan["input"] = self._embed_plan(req, embed_noise_dict, embed_noise_dict is not None, device)
+        plan["gt"] = (self._embed_plan(recon_node_ids_dict, None, False, device)
+                      if recon_node_ids_dict is not None else None)
+        for b in range(nb):      # resident index plans for the heads
+            idx, n_out = plan["idx"][b], plan["idx"][b]["n_out"]
+            if "rating" in idx:
+                idx["pair"] = PairPlan(idx["rating"][self._name_user], idx["rating"][self._name_item],
+                                       n_out[self._name_user], n_out[self._name_item], device)
+            if "recon" in idx:
+                idx["recon_take"] = {k: TakePlan(v, n_out[k], device) for k, v in idx["recon"].items()}
+            if b < nb - 1 and self._use_dae:
+                idx["req_take"] = {k: TakePlan(v, n_out[k], device) for k, v in idx["req"].items()}
+        return plan
+
+    # ---- device work (reference STAR-GCN.py:399-461) --------------------------------------------------
+    def run(self, plan):
+        pred_ratings, pred_embeddings = [], []
+        gt = self.get_embed(plan["gt"]) if plan["gt"] is not None else dict()
+        x = self.get_embed(plan["input"])
+        for b in range(self._nblocks):
+            enc = self.encoders[0] if self._use_recurrent else self.encoders[b]
+            out = enc.heter_sage(x, plan["enc"][b])
+            idx = plan["idx"][b]
+            k = 0 if self._use_recurrent else b
+            if "pair" in idx:   # Dense is row-wise, so project the unique rows first, then pair them up
+                pu = self.rating_user_projs[k](out[self._name_user])
+                pi = self.rating_item_projs[k](out[self._name_item])
+                if self.pair_partition is not None:   # replicated projections meet rank-local rating pairs
+                    if self._name_item in self.pair_partition.replicated_keys:
+                        pi = D.copy_to_local(pi)
+                    if self._name_user in self.pair_partition.replicated_keys:
+                        pu = D.copy_to_local(pu)
+                pred_ratings.append(pair_inner_product(pu, pi, idx["pair"]).view(-1, 1))
+            if "recon_take" in idx and self._use_dae:
+                m = self.embed_maps[k]
+                pred_embeddings.append({key: m[key](SF.take_rows(out[key], tp))
+                                        for key, tp in idx["recon_take"].items()})
+            if b < self._nblocks - 1 and self._use_dae:
+                m = self.embed_maps[k]
+                x = {key: m[key](SF.take_rows(out[key], tp)) for key, tp in idx["req_take"].items()}
+        return pred_ratings, pred_embeddings, gt
+
+    def forward(self, graph, rating_node_pairs=None, embed_noise_dict=None, recon_node_ids_dict=None,
+                graph_sampler_args=None, symm=None, device="cuda"):
+        return self.run(self.make_plan(graph, rating_node_pairs, embed_noise_dict, recon_node_ids_dict,
+                                       graph_sampler_args, symm, device))
+
+
+def star_gcn_loss(pred_ratings, pred_embeddings, gt_embeddings, gt_ratings_std, recon_lambda=0.1):
+    """reference STAR-GCN.py:610-628: sum over blocks of L2Loss(pred, standardised rating).mean()  [= 0.5*(x-y)^2]
+    + recon_lambda * sum over blocks and keys of mean_nodes( sum_c (gt - pred)^2 ); the target is NOT detached."""
+    loss = 0.0
+    for pr in pred_ratings:
+        loss = loss + (0.5 * (pr.view(-1) - gt_ratings_std.view(-1)) ** 2).mean()
+    for block in pred_embeddings:
+        for key, pred in block.items():
+            loss = loss + recon_lambda * ((gt_embeddings[key] - pred) ** 2).sum(dim=1).mean()
+    return loss

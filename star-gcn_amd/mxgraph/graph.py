@@ -1,0 +1,286 @@
+"""Graph containers that produce the integer inputs of the hot path: a minimal counterpart of reference
+mxgraph/graph.py (CSRMat :262-755, HeterGraph :758-1100, merge_nodes :142-164, merge_node_ids_dict :166-219,
+unordered_unique :63-68, empty_as_zero :221-222), numpy on the host with the heavy loops in native code
+(libstargcn_hip `_cpu` entry points instead of the reference's `mxgraph._graph_sampler` CPython extension).
+
+Semantics kept: support uses the degrees of the CURRENT matrix over all rating levels;
+multi_link levels are matched by exact float equality against the sorted unique values; each level keeps CSR
+order and a full-length indptr; the reverse direction of a HeterGraph is the transpose with rows sorted by
+column index; `num_neighbors < 0` copies whole rows (deterministic, RNG-free).
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+
+from ._native import _lib as L
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def unordered_unique(data, return_counts=False, return_inverse=False):
+    """Unique values in FIRST-OCCURRENCE order (what the reference's hash-based unique yields for n <= 10000,
+    graph_sampler.h:465-534; above that its order depends on the OpenMP schedule)."""
+    data = _i32(data)
+    uniq_sorted, first, inverse, counts = np.unique(data, return_index=True, return_inverse=True, return_counts=True)
+    order = np.argsort(first, kind="stable")
+    uniq = uniq_sorted[order].astype(np.int32)
+    if return_counts:
+        return uniq, counts[order].astype(np.int32)
+    if return_inverse:
+        rank = np.empty_like(order)
+        rank[order] = np.arange(order.size)
+        return uniq, rank[inverse].astype(np.int32)
+    raise NotImplementedError
+
+
+def merge_nodes(node_ids):
+    if isinstance(node_ids, np.ndarray):
+        return unordered_unique(node_ids, return_inverse=True)
+    sizes = [int(np.asarray(a).size) for a in node_ids]
+    flat = np.concatenate([_i32(a).ravel() for a in node_ids]) if node_ids else np.zeros(0, np.int32)
+    uniq, inv = unordered_unique(flat, return_inverse=True)
+    out, pos = [], 0
+    for s in sizes:
+        out.append(inv[pos:pos + s])
+        pos += s
+    return uniq, out
+
+
+def merge_node_ids_dict(data):
+    """data: sequence of {key: ids}; returns ({key: unique ids}, [ {key: index of every id in the unique list} ])."""
+    per_key = dict()
+    for d in data:
+        for key, ids in d.items():
+            per_key.setdefault(key, []).append(_i32(ids))
+    uniq, inds = dict(), dict()
+    for key, lst in per_key.items():
+        uniq[key], inds[key] = merge_nodes(lst)
+    counter = {key: 0 for key in per_key}
+    out = []
+    for d in data:
+        nd = dict()
+        for key in d:
+            nd[key] = inds[key][counter[key]]
+            counter[key] += 1
+        out.append(nd)
+    return uniq, out
+
+
+def empty_as_zero(l, dtype):
+    return [np.asarray(e, dtype=dtype) if np.asarray(e).size > 0 else np.zeros((1,), dtype=dtype) for e in l]
+
+
+class _IdMap(object):
+    def __init__(self, ids):
+        ids = _i32(ids)
+        self._lo = int(ids.min()) if ids.size else 0
+        hi = int(ids.max()) if ids.size else -1
+        self._map = -np.ones(hi - self._lo + 1, dtype=np.int32)
+        self._map[ids - self._lo] = np.arange(ids.size, dtype=np.int32)
+
+    def __getitem__(self, ids):
+        return self._map[_i32(ids) - self._lo]
+
+
+class CSRMat(object):
+    def __init__(self, end_points, ind_ptr, row_ids, col_ids, values=None, multi_link=None, support_row_degrees=None,
+                 support_col_degrees=None):
+        """support_*_degrees: degrees to use in `get_support` instead of this matrix's own (a rank-local block of a
+        node-partitioned graph must normalise with the GLOBAL degrees of the replicated side)."""
+        self._sup_rd = None if support_row_degrees is None else _i32(support_row_degrees)
+        self._sup_cd = None if support_col_degrees is None else _i32(support_col_degrees)
+        self.end_points, self.ind_ptr = _i32(end_points), _i32(ind_ptr)
+        assert self.ind_ptr[0] == 0 and self.ind_ptr[-1] == self.end_points.shape[0]
+        self.values = (np.ones(self.end_points.shape, np.float32) if values is None
+                       else np.ascontiguousarray(values, dtype=np.float32))
+        self.multi_link = np.sort(np.asarray(multi_link, dtype=np.float32)) if multi_link is not None else None
+        self.row_ids, self.col_ids = _i32(row_ids), _i32(col_ids)
+        assert self.ind_ptr.size == self.row_ids.size + 1
+        self._row_map, self._col_map = _IdMap(self.row_ids), _IdMap(self.col_ids)
+        self._support = dict()
+        self._col_deg = None
+
+    @classmethod
+    def from_edges(cls, row_ind, col_ind, values, n_rows, n_cols, row_ids=None, col_ids=None, multi_link=None):
+        """COO -> CSR with rows sorted by column index (what scipy `tocsr()` of a duplicate-free COO gives)."""
+        row_ind, col_ind = _i32(row_ind), _i32(col_ind)
+        order = np.lexsort((col_ind, row_ind))
+        ind_ptr = np.zeros(n_rows + 1, np.int64)
+        np.cumsum(np.bincount(row_ind, minlength=n_rows), out=ind_ptr[1:])
+        return cls(col_ind[order], ind_ptr.astype(np.int32),
+                   np.arange(n_rows, dtype=np.int32) if row_ids is None else row_ids,
+                   np.arange(n_cols, dtype=np.int32) if col_ids is None else col_ids,
+                   None if values is None else np.asarray(values)[order], multi_link)
+
+    @property
+    def shape(self):
+        return self.row_ids.size, self.col_ids.size
+
+    @property
+    def nnz(self):
+        return int(self.end_points.size)
+
+    @property
+    def row_degrees(self):
+        return np.ascontiguousarray(np.diff(self.ind_ptr).astype(np.int32))
+
+    @property
+    def col_degrees(self):
+        if self._col_deg is None:
+            self._col_deg = np.bincount(self.end_points, minlength=self.col_ids.size).astype(np.int32)
+        return self._col_deg
+
+    @property
+    def edge_row_indices(self):
+        return np.repeat(np.arange(self.shape[0], dtype=np.int32), np.diff(self.ind_ptr))
+
+    def row_id_to_ind(self, ids):
+        return self._row_map[ids]
+
+    def col_id_to_ind(self, ids):
+        return self._col_map[ids]
+
+    def get_support(self, symm=True):
+        """reference graph.py:414-429 -> graph_sampler.cpp:393-420 (native: sg_get_support_cpu)."""
+        if symm not in self._support:
+            out = np.empty(max(self.nnz, 1), np.float32)
+            cd = (self.col_degrees if self._sup_cd is None else self._sup_cd) if symm \
+                else np.zeros(self.col_ids.size, np.int32)
+            rd = self.row_degrees if self._sup_rd is None else self._sup_rd
+            L.check(L.lib().sg_get_support_cpu(_vp(out), _vp(rd), _vp(_i32(cd)), _vp(self.end_points),
+                                               _vp(self.ind_ptr), self.shape[0], int(bool(symm))), "sg_get_support_cpu")
+            self._support[symm] = out[:self.nnz]
+        return self._support[symm]
+
+    @property
+    def T(self):
+        """Transpose with rows sorted by column index (reference graph.py:585-593 via scipy)."""
+        order = np.argsort(self.end_points, kind="stable")
+        ind_ptr = np.zeros(self.shape[1] + 1, np.int64)
+        np.cumsum(self.col_degrees, out=ind_ptr[1:])
+        return CSRMat(self.edge_row_indices[order], ind_ptr.astype(np.int32), self.col_ids, self.row_ids,
+                      self.values[order], self.multi_link, support_row_degrees=self._sup_cd,
+                      support_col_degrees=self._sup_rd)
+
+    def multi_link_split(self, values, ind_ptr):
+        """reference graph_sampler.cpp:277-376 (native: sg_multi_link_split_cpu)."""
+        values, ind_ptr = np.ascontiguousarray(values, np.float32), _i32(ind_ptr)
+        n, nl = ind_ptr.size - 1, self.multi_link.size
+        pos = np.empty(max(values.size, 1), np.int32)
+        ips = np.empty((nl, n + 1), np.int32)
+        off = np.empty(nl + 1, np.int64)
+        L.check(L.lib().sg_multi_link_split_cpu(_vp(pos), _vp(ips), _vp(off), _vp(values), _vp(ind_ptr),
+                                                _vp(self.multi_link), n, nl), "sg_multi_link_split_cpu")
+        return [pos[off[l]:off[l + 1]] for l in range(nl)], [np.ascontiguousarray(ips[l]) for l in range(nl)]
+
+    def sample_neighbors(self, src_ids=None, symm=True, use_multi_link=True, num_neighbors=None, rng=None):
+        """reference graph.py:677-748.  num_neighbors None / < 0: whole rows, deterministic."""
+        src = np.arange(self.shape[0], dtype=np.int32) if src_ids is None else self.row_id_to_ind(src_ids)
+        beg, end = self.ind_ptr[src].astype(np.int64), self.ind_ptr[src + 1].astype(np.int64)
+        lens = end - beg
+        if num_neighbors is not None and num_neighbors >= 0:
+            rng = np.random.default_rng() if rng is None else rng
+            take = np.minimum(lens, num_neighbors)
+            sampled = np.concatenate([np.sort(b + rng.choice(l, t, replace=False)) if t else np.zeros(0, np.int64)
+                                      for b, l, t in zip(beg, lens, take)] or [np.zeros(0, np.int64)])
+            lens = take
+        else:
+            dst_ptr = np.concatenate([[0], np.cumsum(lens)])
+            sampled = np.repeat(beg - dst_ptr[:-1], lens) + np.arange(int(dst_ptr[-1]))
+        dst_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        sampled = sampled.astype(np.int64)
+        ep_ids = self.col_ids[self.end_points[sampled]]
+        values = self.values[sampled]
+        support = self.get_support(symm)[sampled]
+        if not use_multi_link:
+            return ep_ids, values, dst_ptr, support
+        assert self.multi_link is not None
+        split, ptr_l = self.multi_link_split(values, dst_ptr)
+        return [ep_ids[s] for s in split], [values[s] for s in split], ptr_l, [support[s] for s in split]
+
+    def remove_edges_by_id(self, node_pair_ids):
+        """reference graph.py:660-675: drop the listed (row id, col id) pairs; a NEW CSRMat (fresh degree caches)."""
+        r, c = self.row_id_to_ind(node_pair_ids[0]).astype(np.int64), self.col_id_to_ind(node_pair_ids[1]).astype(np.int64)
+        ncol = self.shape[1]
+        drop = np.isin(self.edge_row_indices.astype(np.int64) * ncol + self.end_points, r * ncol + c)
+        keep = ~drop
+        ind_ptr = np.zeros(self.shape[0] + 1, np.int64)
+        np.cumsum(np.bincount(self.edge_row_indices[keep], minlength=self.shape[0]), out=ind_ptr[1:])
+        return CSRMat(self.end_points[keep], ind_ptr.astype(np.int32), self.row_ids, self.col_ids, self.values[keep],
+                      self.multi_link)
+
+    def check_consistency(self):
+        rows = self.edge_row_indices.astype(np.int64) * self.shape[1] + self.end_points
+        if np.unique(rows).size != rows.size:
+            raise ValueError('Found duplicates in end_points')
+
+
+class HeterGraph(object):
+    """Both directions of every edge type (reference graph.py:758-1100).
+
+    node_ids_dict: {key: ids};  csr_mat_dict: {(src_key, dst_key): CSRMat}; the reverse (dst_key, src_key) matrix
+    is added as the transpose when absent.  `features` is kept as an opaque dict (shapes only matter here)."""
+
+    def __init__(self, node_ids_dict, csr_mat_dict, features=None):
+        self.node_ids_dict = {k: _i32(v) for k, v in node_ids_dict.items()}
+        self.features = features if features is not None else dict()
+        self.csr_mat_dict = dict(csr_mat_dict)
+        for (a, b), m in list(self.csr_mat_dict.items()):
+            if (b, a) not in self.csr_mat_dict:
+                self.csr_mat_dict[(b, a)] = m.T
+        self.meta_graph = dict()
+        for (a, b) in self.csr_mat_dict:
+            self.meta_graph.setdefault(a, dict())[b] = 1
+        for k in self.node_ids_dict:
+            self.meta_graph.setdefault(k, dict())
+
+    def __getitem__(self, pair_keys):
+        return self.csr_mat_dict[tuple(pair_keys)]
+
+    def get_multi_link_structure(self):
+        return {k: (None if m.multi_link is None else int(m.multi_link.size)) for k, m in self.csr_mat_dict.items()}
+
+    def remove_edges_by_id(self, src_key, dst_key, node_pair_ids):
+        """reference graph.py:952-974: remove in BOTH directions; returns a new HeterGraph."""
+        node_pair_ids = np.asarray(node_pair_ids)
+        new = dict(self.csr_mat_dict)
+        new[(src_key, dst_key)] = self.csr_mat_dict[(src_key, dst_key)].remove_edges_by_id(node_pair_ids)
+        new[(dst_key, src_key)] = self.csr_mat_dict[(dst_key, src_key)].remove_edges_by_id(node_pair_ids[::-1])
+        return HeterGraph(self.node_ids_dict, new, self.features)
+
+    def check_continous_node_ids(self):
+        for key, ids in self.node_ids_dict.items():
+            np.testing.assert_array_equal(ids, np.arange(ids.size, dtype=np.int32))
+
+    def save(self, dir_name):
+        """npz/json layout of reference graph.py:898-915 (meta_graph.json + one CSR npz per direction)."""
+        os.makedirs(dir_name, exist_ok=True)
+        with open(os.path.join(dir_name, 'meta_graph.json'), 'w') as f:
+            json.dump({k: sorted(v) for k, v in self.meta_graph.items()}, f)
+        for key, ids in self.node_ids_dict.items():
+            np.savez_compressed(os.path.join(dir_name, '{}.npz'.format(key)), node_ids=ids)
+        for (a, b), m in self.csr_mat_dict.items():
+            np.savez_compressed(os.path.join(dir_name, '{}_{}_csr.npz'.format(a, b)), end_points=m.end_points,
+                                ind_ptr=m.ind_ptr, values=m.values, row_ids=m.row_ids, col_ids=m.col_ids,
+                                multi_link=m.multi_link if m.multi_link is not None else np.zeros(0, np.float32))
+
+    @classmethod
+    def load(cls, dir_name):
+        with open(os.path.join(dir_name, 'meta_graph.json')) as f:
+            meta = json.load(f)
+        node_ids = {k: np.load(os.path.join(dir_name, '{}.npz'.format(k)))['node_ids'] for k in meta}
+        mats = dict()
+        for a in meta:
+            for b in meta[a]:
+                d = np.load(os.path.join(dir_name, '{}_{}_csr.npz'.format(a, b)))
+                ml = d['multi_link'] if d['multi_link'].size else None
+                mats[(a, b)] = CSRMat(d['end_points'], d['ind_ptr'], d['row_ids'], d['col_ids'], d['values'], ml)
+        return cls(node_ids, mats)

@@ -1,0 +1,218 @@
+"""Heterogeneous graph-conv layers with the API of reference mxgraph/layers/layers.py:
+HeterGCNLayer (:42-208), InnerProductLayer (:210-222), StackedHeterGCNLayers.gen_plan / heter_sage (:224-385).
+
+Differences that matter for speed, not for results:
+  * `gen_plan` builds, per (depth, node type, neighbour type), ONE resident `MultiLinkPlan` (fused CSR + transpose on
+    the device) instead of lists of numpy arrays; `heter_sage` therefore uploads nothing (the reference re-uploads
+    every index/support/edge-value array on every call, layers.py:366-377, and the edge values are never used).
+  * row `take`s go through `functional.take_rows` (coalesced copy forward, atomic-free segment-sum backward).
+  * the reference's debugging `print(...)`/`input()` inside gen_plan (layers.py:319-320) is not reproduced.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import graph as G
+from .._native import dist as D
+from .._native import functional as SF
+from .._native import plan as P
+from .aggregators import GCNAggregator, MultiLinkGCNAggregator
+from .common import Dense, LayerDictionary, get_activation
+
+
+class HeterGCNLayer(nn.Module):
+    def __init__(self, meta_graph, multi_link_structure, agg_units, out_units, source_keys=None, dropout_rate=0.0,
+                 agg_ordinal_sharing=False, agg_accum='stack', agg_act='relu', layer_accum='stack', accum_self=False,
+                 out_act=None, agg_order='auto'):
+        super().__init__()
+        self._meta_graph = meta_graph
+        source_keys = list(meta_graph.keys()) if source_keys is None else list(source_keys)
+        self._source_keys = source_keys
+        if not isinstance(out_units, dict):
+            out_units = {k: out_units for k in source_keys}
+        if not isinstance(agg_units, dict):
+            agg_units = {k: agg_units for k in meta_graph}
+        self._layer_accum, self._accum_self = layer_accum, accum_self
+        self.partition = None   # set to a dist.NodePartition for multi-GPU node-partitioned execution
+        self._out_act = get_activation(out_act)
+        self.dropout = nn.Dropout(dropout_rate)
+        self._aggregators = LayerDictionary()
+        for src_key in source_keys:
+            for dst_key in meta_graph[src_key]:
+                nlinks = multi_link_structure[(src_key, dst_key)]
+                if nlinks is None:
+                    agg = GCNAggregator(units=agg_units[src_key], act=agg_act, dropout_rate=dropout_rate)
+                else:
+                    agg = MultiLinkGCNAggregator(units=agg_units[src_key], num_links=nlinks, act=agg_act,
+                                                 dropout_rate=dropout_rate, ordinal_sharing=agg_ordinal_sharing,
+                                                 accum=agg_accum, order=agg_order)
+                self._aggregators[(src_key, dst_key)] = agg
+        self._out_fcs = LayerDictionary()
+        for key, units in out_units.items():
+            if units is not None:   # output activation fused into the GEMM epilogue
+                self._out_fcs[key] = Dense(units, activation=self._out_act)
+        if accum_self:
+            self._self_fcs = LayerDictionary()
+            for key, units in out_units.items():
+                if units is not None:
+                    self._self_fcs[key] = nn.Sequential(nn.Dropout(dropout_rate), Dense(units),
+                                                        nn.Dropout(dropout_rate))
+
+    @property
+    def aggregators(self):
+        return self._aggregators
+
+    def forward_single(self, key, base_feas, neighbor_data):
+        """neighbor_data: {neighbor_key: (feas, end_points, edge_values, indptr, support)} as in the reference, or
+        {neighbor_key: (feas, MultiLinkPlan)}."""
+        outs = []
+        part = self.partition
+        for dst_key in self._meta_graph[key]:
+            item = neighbor_data[dst_key]
+            agg = self._aggregators[(key, dst_key)]
+            feas = item[0]
+            defer = False
+            if part is not None:   # node-partitioned run (dist.py): wrap the two kinds of crossing
+                if part.crossing_in(key, dst_key):
+                    feas = D.copy_to_local(feas)
+                defer = part.crossing_out(key, dst_key)
+            if len(item) == 2:
+                out = agg(feas, item[1], defer_act=defer)
+            else:
+                _f, end_points, _edge_values, indptr, support = item
+                out = agg(feas, end_points, indptr, support, defer_act=defer)
+            if defer:   # partial sums over this rank's sources -> all-reduce, THEN the aggregator activation
+                out = agg.activation(D.reduce_from_local(out))
+            outs.append(self.dropout(out))
+        if self._accum_self:
+            outs.append(self._self_fcs[key](base_feas))
+        if len(outs) == 1:
+            out = outs[0]
+        elif self._layer_accum == 'stack':
+            out = torch.cat(outs, dim=1)
+        elif self._layer_accum == 'sum':
+            out = torch.stack(outs, dim=0).sum(dim=0)
+        else:
+            raise NotImplementedError(self._layer_accum)
+        if key in self._out_fcs:
+            return self._out_fcs[key](out)
+        return self._out_act(out)
+
+    def forward(self, base_feas, neighbor_data):
+        return {key: self.forward_single(key, feas, neighbor_data[key]) for key, feas in base_feas.items()}
+
+
+class InnerProductLayer(nn.Module):
+    """score = sum_c mid(data1) * mid(data2)   (reference layers.py:210-222; the SAME mid map on both sides)."""
+
+    def __init__(self, mid_units=None):
+        super().__init__()
+        self._mid_units = mid_units
+        if mid_units is not None:
+            self._mid_map = Dense(mid_units)
+
+    def forward(self, data1, data2):
+        if self._mid_units is not None:
+            data1, data2 = self._mid_map(data1), self._mid_map(data2)
+        return (data1 * data2).sum(dim=1, keepdim=True)
+
+
+class StackedHeterGCNLayers(nn.Module):
+    """A stack of HeterGCNLayers sharing one plan (or ONE layer applied `recurrent_layer_num` times)."""
+
+    def __init__(self, recurrent_layer_num=None):
+        super().__init__()
+        self._recurrent_layer_num = recurrent_layer_num
+        self._blocks = nn.ModuleList()
+
+    def __len__(self):
+        if self._recurrent_layer_num is None:
+            return len(self._blocks)
+        return 0 if len(self._blocks) == 0 else self._recurrent_layer_num
+
+    def __getitem__(self, key):
+        if self._recurrent_layer_num is not None:
+            if key < self._recurrent_layer_num:
+                return self._blocks[0]
+            raise KeyError('{} is out of range. Layer number={}'.format(key, len(self)))
+        return self._blocks[key]
+
+    def add(self, *blocks):
+        if self._recurrent_layer_num is not None and (len(self._blocks) == 1 or len(blocks) > 1):
+            raise ValueError('Only a single block can be added when the recurrent flag is on')
+        for block in blocks:
+            assert isinstance(block, HeterGCNLayer)
+            self._blocks.append(block)
+
+    # ------------------------------------------------------------------------------------------------
+    def gen_plan(self, graph, sel_node_ids_dict, graph_sampler_args=None, symm=True, device=None):
+        """Top-down plan construction (reference layers.py:260-337).
+
+        Returns (req_node_ids_dict, computing_plan); computing_plan[depth] = [prev_level_ids_dict, agg_args_dict]
+        with agg_args_dict[src_key] = [uniq_sel_node_inds, sel_node_idx, {dst_key: MultiLinkPlan}] -- the
+        reference keeps [end_points, edge_values, ind_ptr, support] lists in that slot."""
+        device = torch.device('cuda') if device is None else torch.device(device)
+        if graph_sampler_args is None:
+            graph_sampler_args = {}
+        computing_plan = [None] * len(self)
+        for depth in range(len(self) - 1, -1, -1):
+            agg_args, nbr_ids, src_ids = dict(), dict(), dict()
+            raw = dict()
+            for src_key, sel_node_ids in sel_node_ids_dict.items():
+                if depth == len(self) - 1:
+                    uniq_ids, sel_idx = G.unordered_unique(sel_node_ids, return_inverse=True)
+                else:
+                    uniq_ids, sel_idx = np.asarray(sel_node_ids, dtype=np.int32), None
+                agg_args[src_key] = [uniq_ids, sel_idx, dict()]
+                src_ids[src_key] = uniq_ids
+                for dst_key in graph.meta_graph[src_key]:
+                    use_ml = self[depth].aggregators[(src_key, dst_key)].use_multi_link
+                    ep_ids, _vals, ind_ptr, support = graph[src_key, dst_key].sample_neighbors(
+                        src_ids=uniq_ids, symm=symm, use_multi_link=use_ml,
+                        num_neighbors=graph_sampler_args.get((src_key, dst_key), -1))
+                    if not use_ml:
+                        ep_ids, ind_ptr, support = [ep_ids], [ind_ptr], [support]
+                    raw[(src_key, dst_key)] = (ind_ptr, support)
+                    nbr_ids.setdefault(dst_key, dict())[src_key] = ep_ids
+            prev_ids = dict()
+            for key in set(nbr_ids) | set(src_ids):     # map neighbour ids to row indices of the previous level
+                pieces = []
+                for _src, eps in nbr_ids.get(key, {}).items():
+                    pieces.extend(eps)
+                if key in src_ids:
+                    pieces.append(src_ids[key])
+                uniq, inds = G.merge_nodes(pieces)
+                prev_ids[key] = uniq
+                cur = 0
+                for src_key, eps in nbr_ids.get(key, {}).items():
+                    ind_ptr, support = raw[(src_key, key)]
+                    agg_args[src_key][2][key] = P.MultiLinkPlan(inds[cur:cur + len(eps)], ind_ptr, support,
+                                                                n_src=uniq.shape[0], device=device)
+                    cur += len(eps)
+                if key in src_ids:
+                    agg_args[key][0] = inds[cur]
+            for src_key in agg_args:                    # resident take plans (base rows / inverse of unique)
+                a = agg_args[src_key]
+                a[0] = P.TakePlan(a[0], prev_ids[src_key].shape[0], device)
+                if a[1] is not None:
+                    a[1] = P.TakePlan(a[1], a[0].n, device)
+            computing_plan[depth] = [prev_ids, agg_args]
+            sel_node_ids_dict = prev_ids
+        return computing_plan[0][0], computing_plan
+
+    def heter_sage(self, input_dict, computing_plan):
+        """Bottom-up execution of the plan (reference layers.py:339-385)."""
+        ret = dict()
+        for depth in range(len(self)):
+            ret = dict()
+            _prev_ids, agg_args = computing_plan[depth]
+            layer = self[depth]
+            for src_key, (base_take, sel_take, plans) in agg_args.items():
+                base = SF.take_rows(input_dict[src_key], base_take) if layer._accum_self else None
+                neighbor_data = {dst_key: (input_dict[dst_key], plan) for dst_key, plan in plans.items()}
+                out = layer.forward_single(key=src_key, base_feas=base, neighbor_data=neighbor_data)
+                if depth == len(self) - 1 and sel_take is not None:
+                    out = SF.take_rows(out, sel_take)
+                ret[src_key] = out
+            input_dict = ret
+        return ret

@@ -9,6 +9,9 @@ from . import _lib as L
 from ._lib import ACT, REQ_ADD, REQ_NULL, REQ_WRITE  # noqa: F401  (re-exported)
 
 
+GATHER_TIMELINE = None   # set to a list by bench.py to collect (start_event, end_event, nnz, C, segs) per launch
+
+
 def _act_id(act):
     if isinstance(act, int):
         return act
@@ -27,9 +30,16 @@ def gather_sum(dst, src, indices, indptr, weights, seg_num, feat_dim, dst_group=
     lib = L.lib()
     wsb = lib.sg_seg_weighted_pool_workspace_bytes(1, seg_num, nnz, feat_dim)
     ws, wsn = L.workspace(wsb, dst.device)
+    ev = None
+    if GATHER_TIMELINE is not None:   # bench.py: HIP events on the launch stream around the dominant kernel
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     L.check(lib.sg_seg_gather_sum_hip(L.ptr(dst), dst_group, dst_ld, L.ptr(src), src_group, src_ld, L.ptr(weights),
                                       L.ptr(indices), L.ptr(indptr), seg_num, nnz, feat_dim, req, _act_id(act),
                                       float(slope), L.ptr(ws), wsn, L.stream_ptr()), "sg_seg_gather_sum_hip")
+    if ev is not None:
+        ev[1].record()
+        GATHER_TIMELINE.append((ev[0], ev[1], int(nnz), int(feat_dim), int(seg_num)))
     return dst
 
 

@@ -134,6 +134,8 @@ class TakePlan(object):
         ids = _np_i32(ids)
         n = ids.shape[0]
         self.n, self.n_rows = n, int(n_rows)
+        # identity takes (full-graph plans: unique ids are already 0..n-1 in order) cost nothing
+        self.identity = bool(n == self.n_rows and np.array_equal(ids, np.arange(n, dtype=np.int32)))
         valid = ids >= 0
         order = np.nonzero(valid)[0].astype(np.int32)
         order = order[np.argsort(ids[order], kind="stable")]
