@@ -1,0 +1,102 @@
+"""Multi-process CPU test (gloo, world_size 2) of the node-partition communication pattern in star-gcn_amd/dist.py:
+`copy_to_local` / `reduce_from_local` crossings + `allreduce_grads` must reproduce the single-process gradients of a
+2-layer bipartite GCN whose users are sharded and whose items are replicated.  The sparse/dense math here is plain
+torch-CPU (the HIP kernels need a GPU); what is under test is exactly the collective placement that bench.py uses
+at N > 1."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(A, x_user, x_item, params, cross_in, cross_out, leaky):
+    """A: (n_user_local, n_item) dense weights.  Two layers, both directions, then a pair loss over A's edges."""
+    W_ui, W_iu, O_u, O_i, P_u, P_i = params
+    for l in range(2):
+        h_user = leaky(A @ (cross_in(x_item) @ W_ui[l].t()))                 # local aggregation over replicated items
+        h_item = leaky(cross_out(A.t() @ (x_user @ W_iu[l].t())))            # partial over local users -> all-reduce
+        x_user, x_item = leaky(h_user @ O_u[l].t()), leaky(h_item @ O_i[l].t())
+    pu, pi = x_user @ P_u.t(), cross_in(x_item @ P_i.t())
+    score = pu @ pi.t()
+    return 0.5 * (((score - 1.0) ** 2) * (A != 0)).sum()
+
+
+def _make(seed=0, nu=12, ni=7, d=5):
+    g = torch.Generator().manual_seed(seed)
+    A = (torch.rand(nu, ni, generator=g) < 0.4).double() * torch.rand(nu, ni, generator=g).double()
+    xu, xi = torch.randn(nu, d, generator=g).double(), torch.randn(ni, d, generator=g).double()
+    mk = lambda *s: (torch.randn(*s, generator=g).double() * 0.5)
+    params = [[mk(d, d), mk(d, d)], [mk(d, d), mk(d, d)], [mk(d, d), mk(d, d)], [mk(d, d), mk(d, d)], mk(3, d), mk(3, d)]
+    return A, xu, xi, params
+
+
+def _flat(params):
+    return [p for grp in params for p in (grp if isinstance(grp, list) else [grp])]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import star_gcn_amd.dist as SD
+    assert SD.world() == world and SD.rank() == rank
+    A, xu, xi, params = _make()
+    blocks = [(0, 5), (5, 12)]
+    lo, hi = blocks[rank]
+    leaky = lambda x: torch.where(x > 0, x, 0.1 * x)
+    flat = _flat(params)
+    for p in flat:
+        p.requires_grad_(True)
+    xu_l = xu[lo:hi].clone().requires_grad_(True)     # user embeddings: row-sharded
+    xi_r = xi.clone().requires_grad_(True)            # item embeddings: replicated
+    loss = _model(A[lo:hi], xu_l, xi_r, params, SD.copy_to_local, SD.reduce_from_local, leaky)
+    loss.backward()
+    W_ui, W_iu, O_u, O_i, P_u, P_i = params
+    local_region = W_ui + W_iu + O_u + [P_u]          # item-side O_i / P_i sit in the replicated region
+    SD.allreduce_grads(local_region)
+    tot = loss.detach().clone()
+    dist.all_reduce(tot)
+    torch.save({"loss": tot, "grads": [p.grad for p in flat], "gxu": xu_l.grad, "gxi": xi_r.grad, "lo": lo, "hi": hi},
+               os.path.join(out_dir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_partition_pattern_matches_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    A, xu, xi, params = _make()
+    flat = _flat(params)
+    for p in flat:
+        p.requires_grad_(True)
+    xu.requires_grad_(True)
+    xi.requires_grad_(True)
+    ident = lambda x: x
+    loss = _model(A, xu, xi, params, ident, ident, lambda x: torch.where(x > 0, x, 0.1 * x))
+    loss.backward()
+    for r in range(2):
+        got = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
+        assert torch.allclose(got["loss"], loss.detach(), rtol=1e-10, atol=1e-10)
+        for g_ref, g in zip([p.grad for p in flat], got["grads"]):
+            assert torch.allclose(g, g_ref, rtol=1e-9, atol=1e-10)           # every rank ends with the TOTAL gradient
+        assert torch.allclose(got["gxu"], xu.grad[got["lo"]:got["hi"]], rtol=1e-9, atol=1e-10)
+        assert torch.allclose(got["gxi"], xi.grad, rtol=1e-9, atol=1e-10)    # replicated table: total, no extra reduce
+
+
+def test_single_process_helpers_are_identity():
+    import star_gcn_amd.dist as SD
+    x = torch.randn(3, 2, requires_grad=True)
+    assert SD.copy_to_local(x) is x and SD.reduce_from_local(x) is x
+    SD.allreduce_grads([x])
+    assert SD.world() == 1 and SD.rank() == 0

@@ -1,0 +1,172 @@
+"""CPU tests of the host side: graph containers (counterparts of reference mxgraph/graph.py), plan construction
+(reference layers.py:260-337 gen_plan) and the synthetic generator.  Integer outputs are checked exactly against
+brute-force numpy restatements."""
+import numpy as np
+import pytest
+
+import star_gcn_amd.synthetic as S
+from star_gcn_amd.mxgraph import graph as G
+
+
+def small_graph(seed=0, nu=30, ni=20, ne=200, R=4):
+    return S.make_graph("custom", seed=seed, n_user=nu, n_item=ni, n_edges=ne, n_levels=R)
+
+
+def test_unordered_unique_first_occurrence_order():
+    data = np.array([7, 3, 7, 9, 3, 1, 9, 9], np.int32)
+    u, inv = G.unordered_unique(data, return_inverse=True)
+    assert u.tolist() == [7, 3, 9, 1]
+    assert np.array_equal(u[inv], data)
+    u2, cnt = G.unordered_unique(data, return_counts=True)
+    assert u2.tolist() == [7, 3, 9, 1] and cnt.tolist() == [2, 2, 3, 1]
+
+
+def test_merge_nodes_and_dicts():
+    a, b = np.array([5, 2, 5], np.int32), np.array([2, 8], np.int32)
+    u, inds = G.merge_nodes([a, b])
+    assert u.tolist() == [5, 2, 8]
+    assert np.array_equal(u[inds[0]], a) and np.array_equal(u[inds[1]], b)
+    uniq, idx_l = G.merge_node_ids_dict([{"user": a, "movie": b}, {"user": b}, {}])
+    assert uniq["user"].tolist() == [5, 2, 8] and uniq["movie"].tolist() == [2, 8]
+    assert np.array_equal(uniq["user"][idx_l[1]["user"]], b) and idx_l[2] == {}
+
+
+def test_csr_transpose_support_and_split():
+    graph, eu, ei, vals = small_graph()
+    m = graph["user", "movie"]
+    m.check_consistency()
+    assert np.all(np.diff(m.ind_ptr) >= 1) and np.all(m.col_degrees >= 1)          # degree >= 1 everywhere
+    for i in range(m.shape[0]):                                                     # rows sorted by column
+        assert np.all(np.diff(m.end_points[m.ind_ptr[i]:m.ind_ptr[i + 1]]) > 0)
+    t = graph["movie", "user"]
+    dense = np.zeros(m.shape)
+    dense[eu, ei] = vals
+    dt = np.zeros(t.shape)
+    dt[t.edge_row_indices, t.end_points] = t.values
+    assert np.array_equal(dense.T, dt)
+    for j in range(t.shape[0]):
+        assert np.all(np.diff(t.end_points[t.ind_ptr[j]:t.ind_ptr[j + 1]]) > 0)
+    # symmetric support: sqrt(1/dr/dc) in float32 exactly as the reference computes it
+    dr, dc = m.row_degrees, m.col_degrees
+    exp = np.sqrt(np.float32(1.0) / dr[eu].astype(np.float32) / dc[ei].astype(np.float32)).astype(np.float32)
+    assert np.array_equal(m.get_support(True), exp)
+    assert np.array_equal(m.get_support(False), (np.float32(1.0) / dr[eu].astype(np.float32)).astype(np.float32))
+    # under symm the reverse direction carries the same value edge for edge
+    st = np.zeros(t.shape)
+    st[t.edge_row_indices, t.end_points] = t.get_support(True)
+    sm = np.zeros(m.shape)
+    sm[eu, ei] = m.get_support(True)
+    np.testing.assert_allclose(sm.T, st, rtol=2e-7, atol=0)   # (1/dr)/dc vs (1/dc)/dr: last-ulp float32 difference
+
+
+def test_sample_neighbors_full_and_subset():
+    graph, eu, ei, vals = small_graph(seed=3)
+    m = graph["user", "movie"]
+    src = np.array([4, 0, 17, 4], np.int32)
+    eps, vs, ips, sps = m.sample_neighbors(src_ids=src, symm=True, use_multi_link=True, num_neighbors=-1)
+    sup = m.get_support(True)
+    for l, lvl in enumerate(m.multi_link):
+        assert ips[l].shape[0] == src.size + 1 and ips[l][0] == 0
+        for k, s in enumerate(src):
+            row = slice(m.ind_ptr[s], m.ind_ptr[s + 1])
+            sel = m.values[row] == lvl
+            seg = slice(ips[l][k], ips[l][k + 1])
+            assert np.array_equal(eps[l][seg], m.col_ids[m.end_points[row][sel]])   # CSR order kept inside a level
+            assert np.array_equal(sps[l][seg], sup[row][sel])
+            assert np.all(vs[l][seg] == lvl)
+    ep, v, ip, sp = m.sample_neighbors(src_ids=src, use_multi_link=False)
+    assert ip[-1] == sum(m.row_degrees[s] for s in src)
+    # fixed-size sampling: at most k per row, without replacement, a subset of the row
+    rng = np.random.default_rng(0)
+    ep, v, ip, sp = m.sample_neighbors(src_ids=src, use_multi_link=False, num_neighbors=3, rng=rng)
+    for k, s in enumerate(src):
+        got = ep[ip[k]:ip[k + 1]]
+        assert got.size == min(3, m.row_degrees[s]) and np.unique(got).size == got.size
+        assert np.all(np.isin(got, m.end_points[m.ind_ptr[s]:m.ind_ptr[s + 1]]))
+
+
+def test_remove_edges_both_directions():
+    graph, eu, ei, vals = small_graph(seed=5)
+    drop = np.stack([eu[::7], ei[::7]])
+    g2 = graph.remove_edges_by_id("user", "movie", drop)
+    m, t = g2["user", "movie"], g2["movie", "user"]
+    assert m.nnz == graph["user", "movie"].nnz - drop.shape[1] == t.nnz
+    keys = set(zip(m.edge_row_indices.tolist(), m.end_points.tolist()))
+    assert not any((u, i) in keys for u, i in zip(*drop))
+    assert keys == set(zip(t.end_points.tolist(), t.edge_row_indices.tolist()))
+    # degrees (hence support) follow the CURRENT matrix
+    assert np.array_equal(m.row_degrees, np.bincount(m.edge_row_indices, minlength=m.shape[0]))
+
+
+def test_save_load_roundtrip(tmp_path):
+    graph, *_ = small_graph(seed=6)
+    graph.save(str(tmp_path / "g"))
+    g2 = G.HeterGraph.load(str(tmp_path / "g"))
+    for key, m in graph.csr_mat_dict.items():
+        n = g2[key]
+        assert np.array_equal(m.end_points, n.end_points) and np.array_equal(m.ind_ptr, n.ind_ptr)
+        assert np.array_equal(m.values, n.values) and np.array_equal(m.multi_link, n.multi_link)
+
+
+def test_gen_plan_full_graph_structure():
+    """gen_plan on the whole graph: every level CSR of the plan reproduces A_r exactly (dense check) and the
+    unique-node maps are consistent."""
+    import torch
+    from star_gcn_amd.mxgraph.layers import HeterGCNLayer, StackedHeterGCNLayers
+    graph, eu, ei, vals = small_graph(seed=7, nu=25, ni=18, ne=160, R=3)
+    enc = StackedHeterGCNLayers()
+    for _ in range(2):
+        enc.add(HeterGCNLayer(graph.meta_graph, graph.get_multi_link_structure(), 8, 8, agg_accum="sum",
+                              agg_act="leaky", out_act="leaky"))
+    sel = {"user": np.array([3, 3, 9, 0], np.int32), "movie": np.array([5, 1], np.int32)}
+    req, plan = enc.gen_plan(graph, sel, symm=True, device="cpu")
+    assert len(plan) == 2
+    for depth in (1, 0):
+        prev_ids, agg = plan[depth]
+        for src_key, (base_take, sel_take, plans) in agg.items():
+            for dst_key, mp in plans.items():
+                m = graph[src_key, dst_key]
+                rows = prev_ids_for(plan, depth, src_key, sel)          # ids whose outputs this depth produces
+                assert mp.n_dst == rows.size and mp.n_src == prev_ids[dst_key].size
+                R = mp.R
+                dense = np.zeros((rows.size, R, m.shape[1]))
+                sup = m.get_support(True)
+                for k, rid in enumerate(rows):
+                    r = m.row_id_to_ind(np.array([rid]))[0]
+                    for j in range(m.ind_ptr[r], m.ind_ptr[r + 1]):
+                        lvl = int(np.nonzero(m.multi_link == m.values[j])[0][0])
+                        dense[k, lvl, m.end_points[j]] += sup[j]
+                got = np.zeros_like(dense)
+                ci, cx, cw = mp.c_indptr.numpy(), mp.c_idx.numpy(), mp.c_w.numpy()
+                for s in range(rows.size * R):
+                    for j in range(ci[s], ci[s + 1]):
+                        got[s // R, s % R, prev_ids[dst_key][cx[j]]] += cw[j]
+                np.testing.assert_allclose(got, dense, rtol=0, atol=1e-7)
+    assert set(req) == {"user", "movie"}
+
+
+def prev_ids_for(plan, depth, key, sel):
+    if depth == len(plan) - 1:
+        return G.unordered_unique(sel[key], return_inverse=True)[0]
+    return plan[depth + 1][0][key]
+
+
+def test_balanced_blocks_and_user_block_support():
+    from star_gcn_amd.dist import balanced_row_blocks
+    graph, eu, ei, vals = small_graph(seed=8, nu=40, ni=15, ne=300)
+    m = graph["user", "movie"]
+    blocks = balanced_row_blocks(m.ind_ptr, 4)
+    assert blocks[0][0] == 0 and blocks[-1][1] == m.shape[0]
+    assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+    sup = m.get_support(True)
+    tot = 0
+    for lo, hi in blocks:
+        sub = S.user_block(graph, "user", "movie", lo, hi)
+        a, b = m.ind_ptr[lo], m.ind_ptr[hi]
+        assert np.array_equal(sub.get_support(True), sup[a:b])             # GLOBAL item degrees in the block
+        st, gt = sub.T, graph["movie", "user"]
+        # transposed block: same support values as the global reverse CSR restricted to these users
+        mask = (gt.end_points >= lo) & (gt.end_points < hi)
+        assert np.array_equal(st.get_support(True), gt.get_support(True)[mask])
+        tot += sub.nnz
+    assert tot == m.nnz
