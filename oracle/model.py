@@ -75,3 +75,63 @@ def masked_embed(table, ids, noise=None):
 def c_seg_weighted_pool(data, weights, indices, indptr):
     """fp32 numpy in/out through the C restatement (bit-level reference order)."""
     return O.seg_weighted_pool(data[None], weights[None], indices, indptr)[0]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Whole-network dense oracle (independent of any plan / unique / re-indexing logic).
+# With NUM_NEIGHBORS = -1 (every shipped yaml, SURVEY appendix B) the sampled computation of reference
+# Net.forward (STAR-GCN.py:311-461) equals the full-graph computation restricted to the requested rows, so it can be
+# restated with dense per-level adjacency matrices: A[(dst, src)][r] (n_dst, n_src) holding the support of the
+# level-r edges (reference graph.py:414-429 / graph_sampler.cpp:393-420 for the support formula).
+# ------------------------------------------------------------------------------------------------------------------
+def dense_level_adjacency(row_ind, col_ind, values, levels, n_rows, n_cols, symm=True, dtype=torch.float64):
+    row_ind, col_ind = np.asarray(row_ind), np.asarray(col_ind)
+    dr = np.bincount(row_ind, minlength=n_rows).astype(np.float32)
+    dc = np.bincount(col_ind, minlength=n_cols).astype(np.float32)
+    if symm:
+        sup = np.sqrt(np.float32(1.0) / dr[row_ind] / dc[col_ind]).astype(np.float32)
+    else:
+        sup = (np.float32(1.0) / dr[row_ind]).astype(np.float32)
+    out = []
+    for lv in levels:
+        a = torch.zeros((n_rows, n_cols), dtype=dtype)
+        sel = np.asarray(values) == lv
+        a[torch.as_tensor(row_ind[sel], dtype=torch.long), torch.as_tensor(col_ind[sel], dtype=torch.long)] = \
+            torch.as_tensor(sup[sel], dtype=dtype)
+        out.append(a)
+    return out
+
+
+def dense_star_gcn(tables, noise, adj, blocks, maps, projs, rating_pairs, recon_ids, accum="sum", act="leaky"):
+    """tables {key: (n, D)}; noise {key: int array or None}; adj {(dst, src): [A_r]};
+    blocks[b] = list of layers, layer = {dst: dict(src=..., W=[..], b=[..], ow=, ob=)};
+    maps[b] = {key: (w0, b0, w1, b1)} or None; projs[b] = {key: (w, b)};
+    rating_pairs (user_key, item_key, u_idx, i_idx) or None; recon_ids {key: ids} or None."""
+    f = ACTS[act]
+    x = {k: masked_embed(t, np.arange(t.shape[0]), noise.get(k) if noise else None) for k, t in tables.items()}
+    gt = {k: tables[k][torch.as_tensor(np.asarray(v), dtype=torch.long)] for k, v in (recon_ids or {}).items()}
+    preds, recons = [], []
+    for b, layers in enumerate(blocks):
+        for layer in layers:
+            nxt = {}
+            for dst, p in layer.items():
+                outs = []
+                for r, a in enumerate(adj[(dst, p["src"])]):
+                    outs.append(a @ (x[p["src"]] @ p["W"][r].t() + p["b"][r]))   # FullyConnected, then seg_weighted_pool
+                h = f(torch.cat(outs, dim=1) if accum == "stack" else sum(outs))
+                nxt[dst] = f(h @ p["ow"].t() + p["ob"])
+            x = nxt
+        out = x
+        if rating_pairs is not None:
+            uk, ik, ui, ii = rating_pairs
+            pu = dense(out[uk], *projs[b][uk])[torch.as_tensor(np.asarray(ui), dtype=torch.long)]
+            pi = dense(out[ik], *projs[b][ik])[torch.as_tensor(np.asarray(ii), dtype=torch.long)]
+            preds.append((pu * pi).sum(dim=1, keepdim=True))
+        if maps is not None and maps[b] is not None:
+            emap = lambda k, t: dense(dense(t, maps[b][k][0], maps[b][k][1], act), maps[b][k][2], maps[b][k][3])
+            if recon_ids is not None:
+                recons.append({k: emap(k, out[k][torch.as_tensor(np.asarray(v), dtype=torch.long)])
+                               for k, v in recon_ids.items()})
+            if b < len(blocks) - 1:
+                x = {k: emap(k, out[k]) for k in out}
+    return preds, recons, gt

@@ -107,3 +107,34 @@ def test_graph_helpers_hand_cases():
     pos, ips = O.multi_link_split(vals, ip, np.array([1, 2, 3], np.float32))
     assert [p.tolist() for p in pos] == [[0, 4], [3], [1, 2, 5]]
     assert [p.tolist() for p in ips] == [[0, 1, 1, 2], [0, 0, 0, 1], [0, 1, 1, 3]]
+
+
+def test_layer_oracles_agree_dense_vs_segment_order():
+    """oracle/model.py: the dense whole-network restatement and the per-level FullyConnected -> seg_weighted_pool
+    restatement (reference aggregators.py:141-149 order) must agree; so must the C seg_weighted_pool."""
+    import torch
+    from oracle import model as OM
+    from tests.test_abi_and_host import make_multilink
+    rng = np.random.default_rng(12)
+    n_dst, n_src, nnz, R, D, Uo = 17, 13, 120, 3, 6, 5
+    eps, ips, sps = make_multilink(rng, n_dst, n_src, nnz, R)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n_src, D, generator=g, dtype=torch.float64)
+    ws = [torch.randn(Uo, D, generator=g, dtype=torch.float64) for _ in range(R)]
+    bs = [torch.randn(Uo, generator=g, dtype=torch.float64) for _ in range(R)]
+    for accum in ("sum", "stack"):
+        a = OM.multilink_aggregator(x, ws, bs, eps, ips, sps, accum=accum, act="leaky")
+        outs = []
+        for r in range(R):
+            A = torch.zeros(n_dst, n_src, dtype=torch.float64)
+            for i in range(n_dst):
+                for j in range(ips[r][i], ips[r][i + 1]):
+                    A[i, eps[r][j]] += float(sps[r][j])
+            outs.append(A @ (x @ ws[r].t() + bs[r]))
+        b = OM.leaky(torch.cat(outs, 1) if accum == "stack" else sum(outs))
+        assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
+    h = (x @ ws[0].t() + bs[0]).float().numpy()
+    c = OM.c_seg_weighted_pool(h, sps[0][:ips[0][-1]] if ips[0][-1] else np.zeros(1, np.float32),
+                               eps[0][:max(ips[0][-1], 1)], ips[0])
+    t = OM.seg_weighted_pool(torch.from_numpy(h).double(), torch.from_numpy(sps[0]).double(), eps[0], ips[0])
+    np.testing.assert_allclose(c, t.numpy(), rtol=1e-5, atol=1e-6)

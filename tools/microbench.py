@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on one MI355X (HIP events, median of N): fp32 MFMA GEMM shapes of the ML-10M step,
+the gather kernel at cache-resident and HBM-bound sizes, and seg_take_k_corr.  Development aid; not a test."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from star_gcn_amd import ops  # noqa: E402
+
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e-3)
+    return float(np.median(ts))
+
+
+def gemm_cases():
+    nu, ni, R, D = 69878, 10677, 10, 256
+    ld = R * D + 16
+    cases = [("TF fwd   H=X Wcat^T", ni, R * D, D, False, True), ("AF fwd   Zext Wext^T", ni, D, ld, False, True),
+             ("out_fc user", nu, D, D, False, True), ("dX = dH Wcat (NN)", ni, D, R * D, False, False),
+             ("dW = dH^T X (TN)", R * D, D, ni, True, False), ("dZ = dpre Wext (NN)", ni, ld, D, False, False),
+             ("dWext = dpre^T Zext (TN)", D, ld, ni, True, False), ("dW out_fc user (TN)", D, D, nu, True, False),
+             ("square 4096", 4096, 4096, 4096, False, True)]
+    for name, M, N, K, ta, tb in cases:
+        a = torch.randn((K, M) if ta else (M, K), device="cuda")
+        b = torch.randn((N, K) if tb else (K, N), device="cuda")
+        t = timeit(lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb))
+        tt = timeit(lambda: torch.matmul(a.t() if ta else a, b.t() if tb else b))
+        print("gemm %-28s M=%6d N=%5d K=%6d  %7.3f ms  %6.1f TF/s   (torch/rocBLAS %7.3f ms %6.1f TF/s)" %
+              (name, M, N, K, t * 1e3, 2.0 * M * N * K / t / 1e12, tt * 1e3, 2.0 * M * N * K / tt / 1e12))
+
+
+def gather_cases():
+    g = torch.Generator().manual_seed(0)
+    for name, S, T, nnz, C in [("ml-10m users<-items", 69878, 10677, 10_000_000, 256),
+                               ("ml-10m items<-users", 10677, 69878, 10_000_000, 256),
+                               ("hbm-bound 2M src rows", 400_000, 2_000_000, 20_000_000, 256),
+                               ("ml-1m C=128", 6040, 3706, 1_000_000, 128), ("pair width 64", 69878, 10677, 10_000_000, 64)]:
+        lens = torch.distributions.Multinomial(nnz, torch.rand(S, generator=g) ** 2 + 1e-3).sample().long()
+        indptr = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)]).int().cuda()
+        idx = torch.randint(0, T, (nnz,), generator=g).int().cuda()
+        w = torch.rand(1, nnz, generator=g).cuda()
+        x = torch.randn(1, T, C, device="cuda")
+        out = torch.empty(1, S, C, device="cuda")
+        t = timeit(lambda: ops.seg_weighted_pool(x, w, idx, indptr, out=out))
+        by = (8 + 4 * C) * nnz
+        print("gather %-24s S=%7d T=%8d nnz=%9d C=%3d  %7.3f ms  %7.1f GB/s algorithmic (%.2f of 8 TB/s)" %
+              (name, S, T, nnz, C, t * 1e3, by / t / 1e9, by / t / 8e12))
+        if C == 64:
+            e1 = torch.randn(1, S, C, device="cuda")
+            t = timeit(lambda: ops.seg_take_k_corr(e1, x, idx, indptr))
+            print("take_k_corr %-19s %7.3f ms  %7.1f GB/s (4C+8 B/edge)" % (name, t * 1e3, (4 * C + 8) * nnz / t / 1e9))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemm", "gather"]
+    if "gemm" in which:
+        gemm_cases()
+    if "gather" in which:
+        gather_cases()
