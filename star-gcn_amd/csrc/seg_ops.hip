@@ -30,33 +30,63 @@ constexpr int kBlock = 256;             // 4 waves per workgroup
 constexpr int kWavesPerBlock = kBlock / kWave;
 
 // ---------------------------------------------------------------------------------------------------
-// seg_take_k_corr: one wave per segment; 64/LPR edge groups; per edge an LPR-lane dot product.
+// seg_take_k_corr: edge-balanced like the gather kernel -- one wave per chunk of 256 consecutive edges,
+// walking the segments the chunk overlaps.  Each edge's dot product is taken by LPR lanes holding VEC
+// consecutive channels each (float4 -> a 64-wide row is 16 lanes, 4 edges per wave step); partial dots
+// are combined inside the lane group with __shfl_xor.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void take_k_corr_kernel(float* __restrict__ dst, const float* __restrict__ e1,
-                                                             const float* __restrict__ e2,
-                                                             const int32_t* __restrict__ ids,
-                                                             const int32_t* __restrict__ indptr, int node_num,
-                                                             long long nbr_num, long long nnz, int C, int lpr, int add) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const long long seg = static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
-  if (seg >= node_num) return;
+constexpr int kCorrChunk = 256;
+
+template <int VEC>
+__global__ __launch_bounds__(kWave) void take_k_corr_kernel(float* __restrict__ dst, const float* __restrict__ e1,
+                                                            const float* __restrict__ e2,
+                                                            const int32_t* __restrict__ ids,
+                                                            const int32_t* __restrict__ indptr, int node_num,
+                                                            long long nbr_num, long long nnz, int C, int lpr, int add) {
+  const int lane = threadIdx.x;
   const int k = blockIdx.y;
+  const int E = indptr[node_num];
+  const long long cb64 = static_cast<long long>(blockIdx.x) * kCorrChunk;
+  if (cb64 >= E) return;
+  const int cb = static_cast<int>(cb64);
+  const int ce = min(cb + kCorrChunk, E);
   const int epg = kWave / lpr;
   const int grp = lane / lpr, slot = lane % lpr;
-  const float* row1 = e1 + (static_cast<long long>(k) * node_num + seg) * C;
-  const int pb = indptr[seg], pe = indptr[seg + 1];
-  for (int j0 = pb; j0 < pe; j0 += epg) {
-    const int j = j0 + grp;
-    float acc = 0.f;
-    if (j < pe) {
-      const float* row2 = e2 + (static_cast<long long>(k) * nbr_num + ids[j]) * C;
-      for (int c = slot; c < C; c += lpr) acc = fmaf(row1[c], row2[c], acc);
+  // segment containing edge cb: largest s with indptr[s] <= cb  (uniform binary search)
+  int lo = 0, hi = node_num;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (indptr[mid] <= cb) lo = mid; else hi = mid;
+  }
+  int s = lo;
+  const float* base1 = e1 + static_cast<long long>(k) * node_num * C;
+  const float* base2 = e2 + static_cast<long long>(k) * nbr_num * C;
+  float* out = dst + static_cast<long long>(k) * nnz;
+  int e = cb;
+  while (e < ce) {
+    const int pe = indptr[s + 1];
+    if (pe <= e) { ++s; continue; }   // skip exhausted / empty segments
+    const int end = min(pe, ce);
+    const float* row1 = base1 + static_cast<long long>(s) * C;
+    for (int j0 = e; j0 < end; j0 += epg) {
+      const int j = j0 + grp;
+      float acc = 0.f;
+      if (j < end) {
+        const float* row2 = base2 + static_cast<long long>(ids[j]) * C;
+        for (int c = slot * VEC; c < C; c += lpr * VEC) {
+          if (VEC == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(row1 + c);
+            const float4 b = *reinterpret_cast<const float4*>(row2 + c);
+            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+          } else {
+            acc = fmaf(row1[c], row2[c], acc);
+          }
+        }
+      }
+      for (int off = 1; off < lpr; off <<= 1) acc += __shfl_xor(acc, off);
+      if (j < end && slot == 0) out[j] = add ? (out[j] + acc) : acc;
     }
-    for (int off = 1; off < lpr; off <<= 1) acc += __shfl_xor(acc, off);
-    if (j < pe && slot == 0) {
-      float* o = dst + static_cast<long long>(k) * nnz + j;
-      *o = add ? (*o + acc) : acc;
-    }
+    e = end;
   }
 }
 
@@ -248,13 +278,20 @@ SG_API int sg_seg_take_k_corr_hip(float* dst, const float* embed1, const float* 
   if (req == SG_REQ_WRITE)
     hipLaunchKernelGGL(zero_uncovered_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256), static_cast<unsigned>(K)),
                        dim3(256), 0, st, dst, neighbor_indptr, static_cast<int>(node_num), static_cast<long long>(nnz));
-  if (node_num > 0) {
+  if (node_num > 0 && feat_dim > 0) {
+    const bool v4 = (feat_dim % 4 == 0) && aligned(embed1, 16) && aligned(embed2, 16);
+    const int64_t per_row = v4 ? feat_dim / 4 : feat_dim;
     int lpr = 1;
-    while (lpr < kWave && lpr < feat_dim) lpr <<= 1;
-    hipLaunchKernelGGL(take_k_corr_kernel, seg_grid(node_num, K), dim3(kBlock), 0, st, dst, embed1, embed2,
-                       neighbor_ids, neighbor_indptr, static_cast<int>(node_num),
-                       static_cast<long long>(neighbor_node_num), static_cast<long long>(nnz),
-                       static_cast<int>(feat_dim), lpr, req == SG_REQ_ADD);
+    while (lpr < kWave && lpr < per_row) lpr <<= 1;
+    dim3 grid(static_cast<unsigned>((nnz + kCorrChunk - 1) / kCorrChunk), static_cast<unsigned>(K));
+    if (v4)
+      hipLaunchKernelGGL(take_k_corr_kernel<4>, grid, dim3(kWave), 0, st, dst, embed1, embed2, neighbor_ids,
+                         neighbor_indptr, static_cast<int>(node_num), static_cast<long long>(neighbor_node_num),
+                         static_cast<long long>(nnz), static_cast<int>(feat_dim), lpr, req == SG_REQ_ADD);
+    else
+      hipLaunchKernelGGL(take_k_corr_kernel<1>, grid, dim3(kWave), 0, st, dst, embed1, embed2, neighbor_ids,
+                         neighbor_indptr, static_cast<int>(node_num), static_cast<long long>(neighbor_node_num),
+                         static_cast<long long>(nnz), static_cast<int>(feat_dim), lpr, req == SG_REQ_ADD);
   }
   return check_launch("seg_take_k_corr");
 }
