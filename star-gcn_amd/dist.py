@@ -27,6 +27,19 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def all_reduce_sum(t):
+    """Sum `t` over ranks, returning a NEW tensor (never mutates autograd-owned buffers).  RCCL ('nccl') reduces
+    device tensors in place over xGMI; with the 'gloo' backend (CPU tests, or two test ranks sharing one GPU) device
+    tensors are staged through the host explicitly."""
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        h = t.detach().cpu().contiguous()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        return h.to(t.device)
+    y = t.detach().contiguous().clone()
+    dist.all_reduce(y, op=dist.ReduceOp.SUM)
+    return y
+
+
 class _CopyToLocal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -34,17 +47,13 @@ class _CopyToLocal(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        return g
+        return all_reduce_sum(g)
 
 
 class _ReduceFromLocal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        y = x.contiguous().clone()
-        dist.all_reduce(y, op=dist.ReduceOp.SUM)
-        return y
+        return all_reduce_sum(x)
 
     @staticmethod
     def backward(ctx, g):
@@ -66,8 +75,7 @@ def allreduce_grads(params):
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat = all_reduce_sum(torch.cat([g.reshape(-1) for g in grads]))
     off = 0
     for g in grads:
         n = g.numel()

@@ -157,8 +157,14 @@ class Net(nn.Module):
         nb = self._nblocks
         plan = dict(enc=[None] * nb, idx=[None] * nb, device=torch.device(device))
         req = dict()
+        full = None
+        if self.pair_partition is not None:   # replicated node types: every node, same order, on every rank
+            full = {k: graph.node_ids_dict[k] for k in graph.meta_graph if k in self.pair_partition.replicated_keys}
         for b in range(nb - 1, -1, -1):
             parts, names = [], []
+            if full is not None:
+                parts.append(full)
+                names.append("full")
             if rating_node_pairs is not None:
                 parts.append({self._name_user: rating_node_pairs[0], self._name_item: rating_node_pairs[1]})
                 names.append("rating")
@@ -171,7 +177,8 @@ class Net(nn.Module):
             plan["idx"][b] = dict(zip(names, idx_l))
             enc = self.encoders[0] if self._use_recurrent else self.encoders[b]
             req, plan["enc"][b] = enc.gen_plan(graph=graph, sel_node_ids_dict=uniq,
-                                               graph_sampler_args=graph_sampler_args, symm=symm, device=device)
+                                               graph_sampler_args=graph_sampler_args, symm=symm, device=device,
+                                               full_node_ids=full)
             plan["idx"][b]["n_out"] = {k: int(v.shape[0]) for k, v in uniq.items()}
         plan["input"] = self._embed_plan(req, embed_noise_dict, embed_noise_dict is not None, device)
         plan["gt"] = (self._embed_plan(recon_node_ids_dict, None, False, device)

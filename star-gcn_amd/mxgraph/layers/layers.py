@@ -145,8 +145,12 @@ class StackedHeterGCNLayers(nn.Module):
             self._blocks.append(block)
 
     # ------------------------------------------------------------------------------------------------
-    def gen_plan(self, graph, sel_node_ids_dict, graph_sampler_args=None, symm=True, device=None):
+    def gen_plan(self, graph, sel_node_ids_dict, graph_sampler_args=None, symm=True, device=None,
+                 full_node_ids=None):
         """Top-down plan construction (reference layers.py:260-337).
+
+        full_node_ids {key: all ids}: node types that are REPLICATED in a node-partitioned run keep every node, in
+        this order, at every depth, so the all-reduced tensors have the same shape and row order on every rank.
 
         Returns (req_node_ids_dict, computing_plan); computing_plan[depth] = [prev_level_ids_dict, agg_args_dict]
         with agg_args_dict[src_key] = [uniq_sel_node_inds, sel_node_idx, {dst_key: MultiLinkPlan}] -- the
@@ -175,13 +179,20 @@ class StackedHeterGCNLayers(nn.Module):
                     raw[(src_key, dst_key)] = (ind_ptr, support)
                     nbr_ids.setdefault(dst_key, dict())[src_key] = ep_ids
             prev_ids = dict()
-            for key in set(nbr_ids) | set(src_ids):     # map neighbour ids to row indices of the previous level
+            # map neighbour ids to row indices of the previous level.  Keys in the graph's own (deterministic) order:
+            # iterating a set of strings would follow per-process hash randomisation and let two ranks of a
+            # node-partitioned run build / execute their plans in different orders.
+            for key in [k for k in graph.meta_graph if k in nbr_ids or k in src_ids]:
                 pieces = []
+                if full_node_ids is not None and key in full_node_ids:
+                    pieces.append(np.asarray(full_node_ids[key], dtype=np.int32))   # fixed row order on every rank
                 for _src, eps in nbr_ids.get(key, {}).items():
                     pieces.extend(eps)
                 if key in src_ids:
                     pieces.append(src_ids[key])
                 uniq, inds = G.merge_nodes(pieces)
+                if full_node_ids is not None and key in full_node_ids:
+                    inds = inds[1:]
                 prev_ids[key] = uniq
                 cur = 0
                 for src_key, eps in nbr_ids.get(key, {}).items():

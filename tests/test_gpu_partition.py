@@ -40,6 +40,8 @@ def _run(net, graph, sub, y_all_mean_std, E_total, dev):
     preds, _, _ = net.run(plan)
     loss = (0.5 * (preds[0].view(-1) - y) ** 2).sum() / E_total
     loss.backward()
+    if os.environ.get("SG_TEST_SYNC") == "1":
+        torch.cuda.synchronize()
     return loss
 
 
@@ -63,6 +65,8 @@ def _worker(rank, world, port, out_dir):
     ref = _build(graph, dev)
     _run(ref, graph, csr, (vals.mean(), vals.std()), csr.nnz, dev)          # materialises the lazy parameters
     state = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    ref_loss = _run(ref, graph, csr, (vals.mean(), vals.std()), csr.nnz, dev)   # single-process reference
+    ref_grads = {k: p.grad.detach().cpu().clone() for k, p in ref.named_parameters()}
     lo, hi = SD.balanced_row_blocks(csr.ind_ptr, world)[rank]
     sub = S.user_block(graph, U, I, lo, hi)
     lgraph = HeterGraph({U: np.arange(hi - lo, dtype=np.int32), I: np.arange(csr.shape[1], dtype=np.int32)}, {(U, I): sub})
@@ -78,29 +82,26 @@ def _worker(rank, world, port, out_dir):
     net.load_state_dict(state)
     loss = _run(net, lgraph, sub, (vals.mean(), vals.std()), csr.nnz, dev)
     SD.allreduce_grads(net.local_region_parameters())
-    tot = loss.detach().clone()
-    dist.all_reduce(tot)
+    tot = SD.all_reduce_sum(loss.detach().view(1))   # host-staged: gloo's own CUDA path is unreliable with 2 ranks/GPU
     grads = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
-    torch.save({"loss": tot.cpu(), "grads": grads, "lo": lo, "hi": hi, "ukey": ukey}, os.path.join(out_dir, "r%d.pt" % rank))
+    torch.save({"loss": tot.cpu(), "grads": grads, "lo": lo, "hi": hi, "ukey": ukey, "ref_grads": ref_grads,
+                "ref_loss": ref_loss.detach().cpu()}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.destroy_process_group()
 
 
 def test_two_rank_partition_equals_single_process(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    dev = torch.device("cuda", 0)
-    graph, vals = _global_problem()
-    csr = graph[U, I]
-    ref = _build(graph, dev)
-    _run(ref, graph, csr, (vals.mean(), vals.std()), csr.nnz, dev)
-    loss = _run(ref, graph, csr, (vals.mean(), vals.std()), csr.nnz, dev)
-    ref_grads = {k: p.grad.detach().cpu() for k, p in ref.named_parameters()}
+    bad = []
     for r in range(2):
         got = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
-        assert abs(float(got["loss"]) - float(loss)) <= 1e-6 * max(1.0, abs(float(loss)))
-        for k, g_ref in ref_grads.items():
+        assert abs(float(got["loss"]) - float(got["ref_loss"])) <= 1e-6 * max(1.0, abs(float(got["ref_loss"])))
+        for k, g_ref in got["ref_grads"].items():
             g = got["grads"][k]
-            if k.replace(".weight", "") == got["ukey"].replace(".weight", ""):
+            if k == got["ukey"]:
                 g_ref = g_ref[got["lo"]:got["hi"]]
-            scale = max(float(g_ref.abs().max()), 1e-6)
-            assert float((g - g_ref).abs().max()) <= 2e-5 * scale + 1e-9, k
+            scale = float(g_ref.abs().max())
+            err = float((g - g_ref).abs().max())
+            if err > 1e-4 * scale + 1e-12:   # fp32 sums in a different order across ranks, tiny gradient magnitudes
+                bad.append("rank %d %s: |g|max %.3e |ref|max %.3e err %.3e" % (r, k, float(g.abs().max()), scale, err))
+    assert not bad, "\n".join(bad)

@@ -1,8 +1,12 @@
 """CPU tests of the host side: graph containers (counterparts of reference mxgraph/graph.py), plan construction
 (reference layers.py:260-337 gen_plan) and the synthetic generator.  Integer outputs are checked exactly against
 brute-force numpy restatements."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 import star_gcn_amd.synthetic as S
 from star_gcn_amd.mxgraph import graph as G
@@ -170,3 +174,24 @@ def test_balanced_blocks_and_user_block_support():
         assert np.array_equal(st.get_support(True), gt.get_support(True)[mask])
         tot += sub.nnz
     assert tot == m.nnz
+
+
+def test_plan_order_is_independent_of_hash_randomisation():
+    """Two ranks of a node-partitioned run are separate processes with different string-hash seeds; the order in
+    which gen_plan visits node types (hence the order of collectives and of lazy parameter creation) must not
+    depend on it."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, star_gcn_amd.synthetic as S\n"
+        "from star_gcn_amd.mxgraph.layers import HeterGCNLayer, StackedHeterGCNLayers\n"
+        "g, eu, ei, v = S.make_graph('custom', seed=7, n_user=25, n_item=18, n_edges=160, n_levels=3)\n"
+        "enc = StackedHeterGCNLayers()\n"
+        "[enc.add(HeterGCNLayer(g.meta_graph, g.get_multi_link_structure(), 9, 8)) for _ in range(2)]\n"
+        "req, plan = enc.gen_plan(g, {'user': eu, 'movie': ei}, device='cpu', full_node_ids={'movie': g.node_ids_dict['movie']})\n"
+        "print([(list(p[0].keys()), list(p[1].keys())) for p in plan], list(req.keys()))\n")
+    outs = set()
+    for seed in ("1", "2", "3", "77"):
+        env = dict(os.environ, PYTHONHASHSEED=seed, PYTHONPATH=ROOT)
+        outs.add(subprocess.check_output([sys.executable, "-c", code], env=env, cwd=ROOT).decode())
+    assert len(outs) == 1, outs
