@@ -18,6 +18,9 @@
 // tile t and written to the other LDS buffer afterwards: one barrier per K tile.  Workgroups are remapped so
 // that the tiles sharing an A row-panel run on the same XCD (private 4 MiB L2 each).  Small-tile-count /
 // large-K problems (weight gradients: K = #nodes) use deterministic split-K through a workspace.
+#include <cmath>
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace sg {
@@ -56,14 +59,15 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   }
 }
 
-// Loads the (rows x BK) slab of a K-CONTIGUOUS operand (element (r,k) at p[r*ld + k]) for this thread:
-// 4 float4 = rows (t/8 + 32*i), k = 4*(t%8)..+3.
+// Loads the (EXT x BK) slab of a K-CONTIGUOUS operand (element (r,k) at p[r*ld + k]) for this thread:
+// EXT/32 float4 = rows (t/8 + 32*i), k = 4*(t%8)..+3.
+template <int EXT>
 __device__ __forceinline__ void gload_kcontig(float (&r)[4][4], const float* __restrict__ p, long long ld, int row0,
                                               int k0, int R, int K, int vec, int t) {
   const int kc = (t & 7) * 4;
   const int rr = t >> 3;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < EXT / 32; ++i) {
     const int row = row0 + rr + 32 * i;
     const int k = k0 + kc;
     if (row < R && vec && k + 3 < K) {
@@ -76,24 +80,28 @@ __device__ __forceinline__ void gload_kcontig(float (&r)[4][4], const float* __r
     }
   }
 }
+template <int EXT>
 __device__ __forceinline__ void sstore_kcontig(float* __restrict__ s, const float (&r)[4][4], int t) {
   const int kc = (t & 7) * 4;
   const int rr = t >> 3;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < EXT / 32; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[(kc + j) * LD_T + rr + 32 * i] = r[i][j];
+    for (int j = 0; j < 4; ++j) s[(kc + j) * (EXT + 1) + rr + 32 * i] = r[i][j];
 }
 
-// Loads the (BK x cols) slab of an M/N-CONTIGUOUS operand (element (k,c) at p[k*ld + c]):
-// 4 float4 = k rows (t/32 + 8*i), c = 4*(t%32)..+3.
+// Loads the (BK x EXT) slab of an M/N-CONTIGUOUS operand (element (k,c) at p[k*ld + c]):
+// EXT/32 float4 = k rows (t/(EXT/4) + (1024/EXT)*i), c = 4*(t%(EXT/4))..+3.
+template <int EXT>
 __device__ __forceinline__ void gload_mcontig(float (&r)[4][4], const float* __restrict__ p, long long ld, int col0,
                                               int k0, int Ccols, int K, int vec, int t) {
-  const int cc = (t & 31) * 4;
-  const int kr = t >> 5;
+  constexpr int TPR = EXT / 4;          // threads per k row
+  constexpr int KSTEP = kThreads / TPR; // k rows per pass
+  const int cc = (t % TPR) * 4;
+  const int kr = t / TPR;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = k0 + kr + 8 * i;
+  for (int i = 0; i < EXT / 32; ++i) {
+    const int k = k0 + kr + KSTEP * i;
     const int c = col0 + cc;
     if (k < K && vec && c + 3 < Ccols) {
       const float4 v = *reinterpret_cast<const float4*>(p + static_cast<long long>(k) * ld + c);
@@ -105,23 +113,28 @@ __device__ __forceinline__ void gload_mcontig(float (&r)[4][4], const float* __r
     }
   }
 }
+template <int EXT>
 __device__ __forceinline__ void sstore_mcontig(float* __restrict__ s, const float (&r)[4][4], int t) {
-  const int cc = (t & 31) * 4;
-  const int kr = t >> 5;
+  constexpr int TPR = EXT / 4;
+  constexpr int KSTEP = kThreads / TPR;
+  const int cc = (t % TPR) * 4;
+  const int kr = t / TPR;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < EXT / 32; ++i) {
     float4 v = make_float4(r[i][0], r[i][1], r[i][2], r[i][3]);
-    *reinterpret_cast<float4*>(s + (kr + 8 * i) * LD_D + cc) = v;
+    *reinterpret_cast<float4*>(s + (kr + KSTEP * i) * (EXT + 4) + cc) = v;
   }
 }
 
 // TA: A is stored (K,M) (M-contiguous).  TB: B is stored (N,K) (K-contiguous, Linear weight layout).
-template <bool TA, bool TB>
-__global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float sA[2][BK * LD_MAX];
+// TM: tile rows (128 -> each wave a 64x64 sub-tile, 2 resident workgroups per CU; 64 -> 32x64 sub-tiles, 3 per CU).
+template <bool TA, bool TB, int TM>
+__global__ __launch_bounds__(kThreads, TM == 128 ? 2 : 3) void gemm_f32_kernel(const GemmArgs g) {
+  constexpr int MT = TM / 64;               // MFMA tiles per wave along M
+  constexpr int LDA_S = TA ? TM + 4 : TM + 1;   // A K-contiguous (TA = false) -> transposing store
+  constexpr int LDB_S = TB ? LD_T : LD_D;       // B K-contiguous (TB = true)  -> transposing store
+  __shared__ __attribute__((aligned(16))) float sA[2][BK * (TM + 4)];
   __shared__ __attribute__((aligned(16))) float sB[2][BK * LD_MAX];
-  constexpr int LDA_S = TA ? LD_D : LD_T;   // A K-contiguous (TA = false) -> transposing store
-  constexpr int LDB_S = TB ? LD_T : LD_D;   // B K-contiguous (TB = true)  -> transposing store
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -136,32 +149,69 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(const GemmArgs g)
   const int xcd = bid & 7;
   const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int tm = wg / g.tiles_n, tn = wg - tm * g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * TM, n0 = tn * BN;
 
   const int z = blockIdx.y;
   const int ktiles = (g.K + BK - 1) / BK;
   const int kt_begin = z * g.tiles_per_split;
   const int kt_end = min(ktiles, kt_begin + g.tiles_per_split);
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   float ra[4][4], rb[4][4];
+  // interior tiles (the vast majority) take unguarded 16-byte loads: no per-load branches in the K loop
+  const bool full_mn = (m0 + TM <= g.M) && (n0 + BN <= g.N) && g.vecA && g.vecB;
   auto gload = [&](int kt) {
     const int k0 = kt * BK;
-    if (TA) gload_mcontig(ra, g.A, g.lda, m0, k0, g.M, g.K, g.vecA, t);
-    else gload_kcontig(ra, g.A, g.lda, m0, k0, g.M, g.K, g.vecA, t);
-    if (TB) gload_kcontig(rb, g.B, g.ldb, n0, k0, g.N, g.K, g.vecB, t);
-    else gload_mcontig(rb, g.B, g.ldb, n0, k0, g.N, g.K, g.vecB, t);
+    if (full_mn && k0 + BK <= g.K) {
+      if (TA) {
+        constexpr int TPR = TM / 4, KSTEP = kThreads / TPR;
+        const float* p = g.A + static_cast<long long>(k0 + t / TPR) * g.lda + m0 + (t % TPR) * 4;
+#pragma unroll
+        for (int i = 0; i < TM / 32; ++i) {
+          const float4 v = *reinterpret_cast<const float4*>(p + static_cast<long long>(KSTEP * i) * g.lda);
+          ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
+        }
+      } else {
+        const float* p = g.A + static_cast<long long>(m0 + (t >> 3)) * g.lda + k0 + (t & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < TM / 32; ++i) {
+          const float4 v = *reinterpret_cast<const float4*>(p + static_cast<long long>(32 * i) * g.lda);
+          ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
+        }
+      }
+      if (TB) {
+        const float* p = g.B + static_cast<long long>(n0 + (t >> 3)) * g.ldb + k0 + (t & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+          const float4 v = *reinterpret_cast<const float4*>(p + static_cast<long long>(32 * i) * g.ldb);
+          rb[i][0] = v.x; rb[i][1] = v.y; rb[i][2] = v.z; rb[i][3] = v.w;
+        }
+      } else {
+        constexpr int TPR = BN / 4, KSTEP = kThreads / TPR;
+        const float* p = g.B + static_cast<long long>(k0 + t / TPR) * g.ldb + n0 + (t % TPR) * 4;
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+          const float4 v = *reinterpret_cast<const float4*>(p + static_cast<long long>(KSTEP * i) * g.ldb);
+          rb[i][0] = v.x; rb[i][1] = v.y; rb[i][2] = v.z; rb[i][3] = v.w;
+        }
+      }
+      return;
+    }
+    if (TA) gload_mcontig<TM>(ra, g.A, g.lda, m0, k0, g.M, g.K, g.vecA, t);
+    else gload_kcontig<TM>(ra, g.A, g.lda, m0, k0, g.M, g.K, g.vecA, t);
+    if (TB) gload_kcontig<BN>(rb, g.B, g.ldb, n0, k0, g.N, g.K, g.vecB, t);
+    else gload_mcontig<BN>(rb, g.B, g.ldb, n0, k0, g.N, g.K, g.vecB, t);
   };
   auto sstore = [&](int buf) {
-    if (TA) sstore_mcontig(sA[buf], ra, t); else sstore_kcontig(sA[buf], ra, t);
-    if (TB) sstore_kcontig(sB[buf], rb, t); else sstore_mcontig(sB[buf], rb, t);
+    if (TA) sstore_mcontig<TM>(sA[buf], ra, t); else sstore_kcontig<TM>(sA[buf], ra, t);
+    if (TB) sstore_kcontig<BN>(sB[buf], rb, t); else sstore_mcontig<BN>(sB[buf], rb, t);
   };
 
   if (kt_begin < kt_end) {
@@ -175,18 +225,34 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(const GemmArgs g)
     const int buf = (kt - kt_begin) & 1;
     const bool more = (kt + 1 < kt_end);
     if (more) gload(kt + 1);
-    const float* pa = sA[buf] + wm * 64 + l31;
+    const float* pa = sA[buf] + wm * (TM / 2) + l31;
     const float* pb = sB[buf] + wn * 64 + l31;
+    // operand reads run one k-pair ahead of the MFMAs (register double buffer) so LDS latency hides under them
+    float av[MT], b0, b1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) av[i] = pa[kh * LDA_S + 32 * i];
+    b0 = pb[kh * LDB_S];
+    b1 = pb[kh * LDB_S + 32];
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = pa[(kk + kh) * LDA_S];
-      const float a1 = pa[(kk + kh) * LDA_S + 32];
-      const float b0 = pb[(kk + kh) * LDB_S];
-      const float b1 = pb[(kk + kh) * LDB_S + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float an[MT], bn0 = 0.f, bn1 = 0.f;
+      if (kk + 2 < BK) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) an[i] = pa[(kk + 2 + kh) * LDA_S + 32 * i];
+        bn0 = pb[(kk + 2 + kh) * LDB_S];
+        bn1 = pb[(kk + 2 + kh) * LDB_S + 32];
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1, acc[i][1], 0, 0, 0);
+      }
+      if (kk + 2 < BK) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) av[i] = an[i];
+        b0 = bn0;
+        b1 = bn1;
+      }
     }
     if (more) sstore(buf ^ 1);
     __syncthreads();
@@ -197,7 +263,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(const GemmArgs g)
   float* out = partial ? g.ws + static_cast<long long>(z) * g.M * g.N : g.C;
   const long long ldo = partial ? g.N : g.ldc;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MT; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 64 + j * 32 + l31;
@@ -205,7 +271,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(const GemmArgs g)
       const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const int row = m0 + wm * (TM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
         if (row >= g.M) continue;
         float v = acc[i][j][e];
         float* o = out + static_cast<long long>(row) * ldo + col;
@@ -232,6 +298,15 @@ __global__ void splitk_reduce_kernel(const GemmArgs g) {
   float* o = g.C + static_cast<long long>(row) * g.ldc + col;
   if (g.accumulate) v += *o;
   *o = apply_act(v, g.act, g.slope);
+}
+
+// 128-row tiles have the better MFMA/LDS ratio; 64-row tiles quantise less at the tail (more, smaller tiles and 3
+// resident workgroups per CU).  Pick by a simple "rounds of resident workgroups x work per tile" model.
+static int choose_tm(int64_t M, int64_t N, int splits) {
+  const int64_t tn = (N + BN - 1) / BN;
+  const double r128 = std::ceil(static_cast<double>(((M + 127) / 128) * tn * splits) / (256.0 * 2)) * 1.00;
+  const double r64 = std::ceil(static_cast<double>(((M + 63) / 64) * tn * splits) / (256.0 * 3)) * 0.56;
+  return r64 < r128 ? 64 : 128;
 }
 
 static void plan_split(int64_t M, int64_t N, int64_t K, int* splits, int* tiles_per_split) {
@@ -322,11 +397,13 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.M = static_cast<int>(M); g.N = static_cast<int>(N); g.K = static_cast<int>(K);
   g.act = act; g.slope = slope; g.accumulate = accumulate ? 1 : 0;
-  g.tiles_m = static_cast<int>((M + BM - 1) / BM);
-  g.tiles_n = static_cast<int>((N + BN - 1) / BN);
-  if (static_cast<int64_t>(g.tiles_m) * g.tiles_n >= (1ll << 31)) return fail(SG_ERR_INVALID, "too many tiles");
   plan_split(M, N, K, &g.splits, &g.tiles_per_split);
   if (K == 0) { g.splits = 1; g.tiles_per_split = 1; }
+  int tm = choose_tm(M, N, g.splits);
+  if (const char* force = getenv("SG_GEMM_TM")) tm = atoi(force) == 64 ? 64 : 128;   // tuning aid
+  g.tiles_m = static_cast<int>((M + tm - 1) / tm);
+  g.tiles_n = static_cast<int>((N + BN - 1) / BN);
+  if (static_cast<int64_t>(g.tiles_m) * g.tiles_n >= (1ll << 31)) return fail(SG_ERR_INVALID, "too many tiles");
   if (g.splits > 1) {
     const size_t need = static_cast<size_t>(g.splits) * M * N * sizeof(float);
     if (!workspace || workspace_bytes < need)
@@ -337,13 +414,17 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
   g.vecB = (ldb % 4 == 0) && aligned(B, 16);
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(static_cast<unsigned>(g.tiles_m * g.tiles_n), static_cast<unsigned>(g.splits));
+#define SG_LAUNCH_GEMM(TA_, TB_)                                                                         \
+  do {                                                                                                  \
+    if (tm == 128) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, 128>), grid, dim3(kThreads), 0, st, g); \
+    else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, 64>), grid, dim3(kThreads), 0, st, g);            \
+  } while (0)
   if (transA) {
-    if (transB) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(kThreads), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(kThreads), 0, st, g);
+    if (transB) SG_LAUNCH_GEMM(true, true); else SG_LAUNCH_GEMM(true, false);
   } else {
-    if (transB) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(kThreads), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(kThreads), 0, st, g);
+    if (transB) SG_LAUNCH_GEMM(false, true); else SG_LAUNCH_GEMM(false, false);
   }
+#undef SG_LAUNCH_GEMM
   if (g.splits > 1) {
     const long long total = static_cast<long long>(M) * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, g);

@@ -22,8 +22,10 @@ def rel_close(got, ref, tol=1e-5, what=""):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1, 1, 1), (130, 250, 75), (257, 64, 2570), (64, 515, 64),
                                    (1000, 75, 250), (5, 300, 1027)])
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
-def test_gemm_layouts_and_edges(M, N, K, ta, tb):
+@pytest.mark.parametrize("tile_rows", ["64", "128"])
+def test_gemm_layouts_and_edges(M, N, K, ta, tb, tile_rows, monkeypatch):
     from star_gcn_amd import ops
+    monkeypatch.setenv("SG_GEMM_TM", tile_rows)   # exercise both tile shapes (normally picked by a wave-count model)
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     A = torch.randn((K, M) if ta else (M, K), generator=g)
     B = torch.randn((N, K) if tb else (K, N), generator=g)   # asymmetric random operands (transpose-detecting)
