@@ -48,11 +48,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SG_BENCH_BACKEND=gloo lets several ranks share ONE GPU (development check of the N > 1 code path on a 1-GPU
+    # box); the real multi-GPU run uses nccl == RCCL with one rank per GPU.
+    backend = os.environ.get("SG_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -118,7 +125,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timeline, ops.GATHER_TIMELINE = ops.GATHER_TIMELINE, None
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev)
+        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -129,8 +136,16 @@ def main():
         avg = sum(t for t, _, _ in agg) / len(agg)
         bytes_per_launch = (8 + 4 * D) * E_local          # idx + support + one fp32 row per edge visit
         ach = bytes_per_launch / avg
+        traffic = None   # PMC bytes per launch come from separate rocprofv3 --pmc passes (committed summary)
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                rec = json.load(f).get("%s:%d" % (args.shape, D))
+            if rec and world == 1:
+                traffic = rec["traffic_bytes_per_launch_mean"] * (E_local / rec["edges_per_launch"])
+        except (OSError, ValueError, KeyError):
+            pass
         roof = {"bound": "hbm", "kernel": "seg_gather_kernel", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None, "launches_per_step": len(agg) / args.steps,
+                "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic, "launches_per_step": len(agg) / args.steps,
                 "avg_launch_ms": avg * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "note": "gathered matrices (<=72 MB) fit the 256 MB Infinity Cache at this shape, so the algorithmic "
                         "rate can exceed what HBM itself delivers; traffic (PMC) is in profiles/"}
@@ -148,7 +163,7 @@ def main():
                                                                                           E_total, R, D),
                    "partition": "single GPU" if world == 1 else "1-D user-block node partition, items replicated, "
                                 "RCCL all-reduce of item-side partials", "order": args.order,
-                   "plan_build_s": round(t_plan, 2), "loss": float(loss)},
+                   "plan_build_s": round(t_plan, 2), "loss": float(loss.detach())},
         "roofline": roof,
         "step_roofline_frac": value * 8 * (8 + 4 * D) / (world * HBM_PEAK),
     }

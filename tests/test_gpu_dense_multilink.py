@@ -148,3 +148,45 @@ def test_take_rows_and_masked_embed():
     tr = table.double().requires_grad_(True)
     OM.masked_embed(tr, ids, noise).backward(gy.double())
     rel_close(t.grad, tr.grad, 1e-5, "dtable")
+
+
+def test_fused_aggregator_properties_at_ml10m_size():
+    """BASELINE config 4 size (69878 x 10677, 10 M ratings, 10 levels, dim 256): the oracle cannot run this in seconds,
+    so check size-independent properties of the fused aggregation: (1) both association orders agree, (2) linearity in
+    the features (activation off), (3) the adjoint identity <A x, y> == <x, A^T y> through autograd, (4) rows of users
+    without any rating of a level get no bias of that level (empty segment => 0)."""
+    import star_gcn_amd.synthetic as S
+    from star_gcn_amd import functional as F
+    from star_gcn_amd.plan import MultiLinkPlan
+    graph, eu, ei, vals = S.make_graph("ml-10m")
+    m = graph["user", "movie"]
+    eps, _, ips, sps = m.sample_neighbors(symm=True, use_multi_link=True, num_neighbors=-1)
+    plan = MultiLinkPlan(eps, ips, sps, m.shape[1], "cuda")
+    R, D, U = plan.R, 256, 256
+    assert plan.nnz == m.nnz and plan.n_dst == 69878 and plan.n_src == 10677 and R == 10
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x1 = torch.randn(plan.n_src, D, device="cuda", generator=g) * 0.1
+    x2 = torch.randn(plan.n_src, D, device="cuda", generator=g) * 0.1
+    ws = [torch.randn(U, D, device="cuda", generator=g) * (3.0 / D) ** 0.5 for _ in range(R)]
+    bz = [torch.zeros(U, device="cuda") for _ in range(R)]
+    bs = [torch.randn(U, device="cuda", generator=g) * 0.1 for _ in range(R)]
+    f = lambda x, b, order: F.multilink_aggregate(x, ws, b, plan, accum="sum", act=None, order=order)
+    a_tf, a_af = f(x1, bs, "transform_first"), f(x1, bs, "aggregate_first")
+    scale = float(a_tf.abs().max())
+    assert float((a_tf - a_af).abs().max()) <= 1e-5 * scale                        # (1)
+    lin = f(2 * x1 - 3 * x2, bz, "transform_first")
+    ref = 2 * f(x1, bz, "transform_first") - 3 * f(x2, bz, "transform_first")
+    assert float((lin - ref).abs().max()) <= 2e-5 * float(ref.abs().max())         # (2)
+    for order in ("transform_first", "aggregate_first"):                           # (3)
+        xg = x1.clone().requires_grad_(True)
+        y = torch.randn(plan.n_dst, U, device="cuda", generator=g)
+        out = f(xg, bz, order)
+        out.backward(y)
+        lhs = float((out.detach().double() * y.double()).sum())
+        rhs = float((xg.grad.double() * x1.double()).sum())
+        assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs)), (order, lhs, rhs)
+    zero_x = torch.zeros_like(x1)                                                   # (4) bias only through non-empty levels
+    only_bias = f(zero_x, bs, "transform_first")
+    rowsum = plan.rowsum                                                            # (n_dst, R) sum of supports per level
+    expect = rowsum @ torch.stack(bs)                                               # plumbing-level check, fp32
+    assert float((only_bias - expect).abs().max()) <= 1e-5 * float(expect.abs().max())
