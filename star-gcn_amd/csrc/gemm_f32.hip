@@ -347,20 +347,40 @@ __global__ void act_bwd_kernel(float* __restrict__ dpre, const float* __restrict
 }
 
 constexpr int kColRows = 512;  // rows per workgroup in pass 1 of colsum
-// pass 1: partial[chunk][col] = sum over the chunk's rows; 256 threads = 64 columns x 4 row lanes
+// pass 1: partial[chunk][col] = sum over the chunk's rows.  256 threads = 4 waves; a wave reads whole row
+// segments of 64*VEC consecutive floats (1 KiB with float4) so each load instruction is one coalesced burst;
+// the 4 waves take rows r, r+4, ... and are combined through LDS.
+template <int VEC>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(float* __restrict__ partial, const float* __restrict__ X,
                                                              long long ldx, long long M, int N) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
+  __shared__ float red[4][64 * VEC];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 * VEC + lane * VEC;
   const long long r0 = static_cast<long long>(blockIdx.y) * kColRows;
   const long long r1 = min(M, r0 + kColRows);
-  float acc = 0.f;
-  if (col < N)
-    for (long long r = r0 + rl; r < r1; r += 4) acc += X[r * ldx + col];
-  red[rl][cl] = acc;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  if (col < N) {
+    for (long long r = r0 + w; r < r1; r += 4) {
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(X + r * ldx + col);
+        acc[0] += t.x; acc[1 % VEC] += t.y; acc[2 % VEC] += t.z; acc[3 % VEC] += t.w;
+      } else {
+        acc[0] += X[r * ldx + col];
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) red[w][lane * VEC + v] = acc[v];
   __syncthreads();
-  if (rl == 0 && col < N) partial[static_cast<long long>(blockIdx.y) * N + col] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+  if (w == 0 && col < N) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const int i = lane * VEC + v;
+      partial[static_cast<long long>(blockIdx.y) * N + col + v] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+  }
 }
 __global__ void colsum_final_kernel(float* __restrict__ dst, const float* __restrict__ partial, int chunks, int N,
                                     int add) {
@@ -460,9 +480,14 @@ SG_API int sg_colsum_hip(float* dst, const float* X, int64_t ldx, int64_t M, int
   if (chunks > 0) {
     if (!workspace || workspace_bytes < sg_colsum_workspace_bytes(M, N))
       return fail(SG_ERR_WORKSPACE, "colsum workspace too small");
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(static_cast<unsigned>((N + 63) / 64), static_cast<unsigned>(chunks)),
-                       dim3(256), 0, st, static_cast<float*>(workspace), X, static_cast<long long>(ldx),
-                       static_cast<long long>(M), static_cast<int>(N));
+    if (N % 4 == 0 && ldx % 4 == 0 && aligned(X, 16))
+      hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(static_cast<unsigned>((N + 255) / 256), static_cast<unsigned>(chunks)),
+                         dim3(256), 0, st, static_cast<float*>(workspace), X, static_cast<long long>(ldx),
+                         static_cast<long long>(M), static_cast<int>(N));
+    else
+      hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(static_cast<unsigned>((N + 63) / 64), static_cast<unsigned>(chunks)),
+                         dim3(256), 0, st, static_cast<float*>(workspace), X, static_cast<long long>(ldx),
+                         static_cast<long long>(M), static_cast<int>(N));
   }
   hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, st, dst,
                      static_cast<const float*>(workspace), static_cast<int>(chunks), static_cast<int>(N),
