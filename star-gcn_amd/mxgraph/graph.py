@@ -142,6 +142,21 @@ class CSRMat(object):
     def edge_row_indices(self):
         return np.repeat(np.arange(self.shape[0], dtype=np.int32), np.diff(self.ind_ptr))
 
+    @property
+    def node_pair_ids(self):
+        """(2, nnz): row id and column id of every stored edge, in CSR order."""
+        return np.stack([self.row_ids[self.edge_row_indices], self.col_ids[self.end_points]], axis=0)
+
+    def fetch_edges_by_id(self, node_pair_ids):
+        """Edge values of the given (row id, col id) pairs (every pair must exist)."""
+        r = self.row_id_to_ind(node_pair_ids[0]).astype(np.int64)
+        c = self.col_id_to_ind(node_pair_ids[1]).astype(np.int64)
+        key = self.edge_row_indices.astype(np.int64) * self.shape[1] + self.end_points   # sorted: CSR rows are sorted
+        pos = np.searchsorted(key, r * self.shape[1] + c)
+        if np.any(pos >= key.size) or np.any(key[np.minimum(pos, key.size - 1)] != r * self.shape[1] + c):
+            raise ValueError("fetch_edges_by_id: some node pairs are not edges of this matrix")
+        return self.values[pos]
+
     def row_id_to_ind(self, ids):
         return self._row_map[ids]
 
@@ -255,6 +270,9 @@ class HeterGraph(object):
         new[(src_key, dst_key)] = self.csr_mat_dict[(src_key, dst_key)].remove_edges_by_id(node_pair_ids)
         new[(dst_key, src_key)] = self.csr_mat_dict[(dst_key, src_key)].remove_edges_by_id(node_pair_ids[::-1])
         return HeterGraph(self.node_ids_dict, new, self.features)
+
+    def fetch_edges_by_id(self, src_key, dst_key, node_pair_ids):
+        return self.csr_mat_dict[(src_key, dst_key)].fetch_edges_by_id(np.asarray(node_pair_ids))
 
     def check_continous_node_ids(self):
         for key, ids in self.node_ids_dict.items():

@@ -53,15 +53,23 @@ def bipartite_edges(n_user, n_item, n_edges, rng):
 
 
 def make_graph(shape="ml-10m", seed=None, n_user=None, n_item=None, n_edges=None, n_levels=None,
-               name_user="user", name_item="movie"):
-    """-> (HeterGraph, user_idx, item_idx, rating_values) with edges in user-major / item-minor (CSR) order."""
+               name_user="user", name_item="movie", signal=False):
+    """-> (HeterGraph, user_idx, item_idx, rating_values) with edges in user-major / item-minor (CSR) order.
+    signal=True makes the ratings learnable (quantised low-rank user x item affinity + noise, same level histogram)
+    for training demos; the benchmark keeps the i.i.d. levels of SURVEY 8(d)."""
     nu, ni, ne, R = SHAPES[shape] if shape in SHAPES else (n_user, n_item, n_edges, n_levels)
     nu, ni, ne, R = (n_user or nu), (n_item or ni), (n_edges or ne), (n_levels or R)
     cfg_id = list(SHAPES).index(shape) if shape in SHAPES else 99
     rng = np.random.default_rng(20240917 + cfg_id if seed is None else seed)
     u, i = bipartite_edges(nu, ni, ne, rng)
     levels = level_values(R)
-    vals = levels[rng.choice(R, size=u.size, p=level_probs(R))]
+    if signal:
+        pu, qi = rng.normal(size=(nu, 4)), rng.normal(size=(ni, 4))
+        score = (pu[u] * qi[i]).sum(axis=1) + 0.5 * rng.normal(size=u.size)
+        cuts = np.quantile(score, np.cumsum(level_probs(R))[:-1])
+        vals = levels[np.searchsorted(cuts, score)]
+    else:
+        vals = levels[rng.choice(R, size=u.size, p=level_probs(R))]
     csr = CSRMat.from_edges(u, i, vals, nu, ni, multi_link=levels)
     graph = HeterGraph({name_user: np.arange(nu, dtype=np.int32), name_item: np.arange(ni, dtype=np.int32)},
                        {(name_user, name_item): csr})
