@@ -199,6 +199,16 @@ int sg_multilink_fuse_cpu(int32_t* c_indptr, int32_t* c_idx, int32_t* c_q, float
                           const int32_t* const* indptr_l, const float* const* support_l, int64_t num_links,
                           int64_t n_dst, int64_t n_src);
 
+/* unique_inverse / unique_cnt  graph_sampler.h:465-534 (py_ext.cpp:612-627): unique ids in FIRST-OCCURRENCE order for
+ * ids in [0, max_id]; inverse / counts may be NULL.  uniq, inverse, counts hold n entries; *n_uniq are used. */
+int sg_unique_inverse_cpu(int32_t* uniq, int32_t* inverse, int32_t* counts, int64_t* n_uniq, const int32_t* ids,
+                          int64_t n, int64_t max_id);
+/* remove_edges_by_indices  graph_sampler.cpp:154-201: drop (row index, col index) pairs from a CSR with column-sorted
+ * rows; out arrays hold ind_ptr[row_num] entries, *new_nnz are used. */
+int sg_remove_edges_cpu(int32_t* out_end_points, float* out_values, int32_t* out_ind_ptr, int64_t* new_nnz,
+                        const int32_t* end_points, const float* values, const int32_t* ind_ptr, int64_t row_num,
+                        const int32_t* rm_rows, const int32_t* rm_cols, int64_t rm_num);
+
 #ifdef __cplusplus
 }
 #endif

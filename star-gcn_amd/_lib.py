@@ -66,6 +66,8 @@ _SIGS = {
     "sg_get_support_cpu": (_INT, [_P] * 5 + [_I64, _INT]),
     "sg_multi_link_split_cpu": (_INT, [_P] * 6 + [_I64, _I64]),
     "sg_multilink_fuse_cpu": (_INT, [_P] * 11 + [_I64] * 3),
+    "sg_unique_inverse_cpu": (_INT, [_P] * 5 + [_I64, _I64]),
+    "sg_remove_edges_cpu": (_INT, [_P] * 7 + [_I64, _P, _P, _I64]),
 }
 
 _lib = None

@@ -158,3 +158,62 @@ SG_API int sg_multilink_fuse_cpu(int32_t* c_indptr, int32_t* c_idx, int32_t* c_q
   }
   return SG_OK;
 }
+
+// unique_inverse / unique_cnt of the reference (graph_sampler.h:465-534, py_ext.cpp unique_inverse / unique_cnt) for
+// non-negative ids: first-occurrence order, O(n) with a direct-address table instead of a hash map (node ids of a
+// HeterGraph are small contiguous integers).  uniq (n), inverse (n, may be NULL), counts (n, may be NULL).
+SG_API int sg_unique_inverse_cpu(int32_t* uniq, int32_t* inverse, int32_t* counts, int64_t* n_uniq, const int32_t* ids,
+                                 int64_t n, int64_t max_id) {
+  if (n < 0 || max_id < -1) return fail(SG_ERR_INVALID, "bad unique_inverse arguments");
+  std::vector<int32_t> slot(static_cast<size_t>(max_id) + 1, -1);
+  int64_t m = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t v = ids[i];
+    if (v < 0 || v > max_id) return fail(SG_ERR_VALUE, "id %d at position %lld outside [0,%lld]", v, (long long)i, (long long)max_id);
+    int32_t s = slot[v];
+    if (s < 0) {
+      s = static_cast<int32_t>(m);
+      slot[v] = s;
+      uniq[m] = v;
+      if (counts) counts[m] = 0;
+      ++m;
+    }
+    if (inverse) inverse[i] = s;
+    if (counts) counts[s]++;
+  }
+  *n_uniq = m;
+  return SG_OK;
+}
+
+// remove_edges_by_indices of the reference (graph_sampler.cpp:154-201): drop the listed (row index, col index) pairs
+// from a CSR whose rows are sorted by column.  Pairs that are not edges are ignored.  Outputs: new end_points /
+// values (nnz entries allocated by the caller, *new_nnz used) and new ind_ptr (row_num+1).
+SG_API int sg_remove_edges_cpu(int32_t* out_end_points, float* out_values, int32_t* out_ind_ptr, int64_t* new_nnz,
+                               const int32_t* end_points, const float* values, const int32_t* ind_ptr, int64_t row_num,
+                               const int32_t* rm_rows, const int32_t* rm_cols, int64_t rm_num) {
+  if (row_num < 0 || rm_num < 0) return fail(SG_ERR_INVALID, "negative dimension");
+  const int64_t nnz = ind_ptr[row_num];
+  std::vector<uint8_t> drop(static_cast<size_t>(nnz), 0);
+  for (int64_t k = 0; k < rm_num; ++k) {
+    const int32_t r = rm_rows[k];
+    if (r < 0 || r >= row_num) return fail(SG_ERR_VALUE, "row index %d out of range", r);
+    const int32_t* b = end_points + ind_ptr[r];
+    const int32_t* e = end_points + ind_ptr[r + 1];
+    const int32_t* p = std::lower_bound(b, e, rm_cols[k]);
+    if (p != e && *p == rm_cols[k]) drop[p - end_points] = 1;
+  }
+  int64_t w = 0;
+  out_ind_ptr[0] = 0;
+  for (int64_t i = 0; i < row_num; ++i) {
+    for (int64_t j = ind_ptr[i]; j < ind_ptr[i + 1]; ++j) {
+      if (!drop[j]) {
+        out_end_points[w] = end_points[j];
+        if (values) out_values[w] = values[j];
+        ++w;
+      }
+    }
+    out_ind_ptr[i + 1] = static_cast<int32_t>(w);
+  }
+  *new_nnz = w;
+  return SG_OK;
+}

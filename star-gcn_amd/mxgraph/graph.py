@@ -28,7 +28,19 @@ def _i32(a):
 def unordered_unique(data, return_counts=False, return_inverse=False):
     """Unique values in FIRST-OCCURRENCE order (what the reference's hash-based unique yields for n <= 10000,
     graph_sampler.h:465-534; above that its order depends on the OpenMP schedule)."""
-    data = _i32(data)
+    data = _i32(data).ravel()
+    if not (return_counts or return_inverse):
+        raise NotImplementedError
+    n = data.size
+    lo, hi = (int(data.min()), int(data.max())) if n else (0, -1)
+    if n and lo >= 0 and hi <= 16 * n + (1 << 20):   # native O(n) direct-address path (sg_unique_inverse_cpu)
+        uniq = np.empty(n, np.int32)
+        other = np.empty(n, np.int32)
+        m = ctypes.c_int64(0)
+        L.check(L.lib().sg_unique_inverse_cpu(_vp(uniq), None if return_counts else _vp(other),
+                                              _vp(other) if return_counts else None, ctypes.byref(m), _vp(data), n, hi),
+                "sg_unique_inverse_cpu")
+        return (uniq[:m.value].copy(), other[:m.value].copy()) if return_counts else (uniq[:m.value].copy(), other)
     uniq_sorted, first, inverse, counts = np.unique(data, return_index=True, return_inverse=True, return_counts=True)
     order = np.argsort(first, kind="stable")
     uniq = uniq_sorted[order].astype(np.int32)
@@ -223,14 +235,16 @@ class CSRMat(object):
 
     def remove_edges_by_id(self, node_pair_ids):
         """reference graph.py:660-675: drop the listed (row id, col id) pairs; a NEW CSRMat (fresh degree caches)."""
-        r, c = self.row_id_to_ind(node_pair_ids[0]).astype(np.int64), self.col_id_to_ind(node_pair_ids[1]).astype(np.int64)
-        ncol = self.shape[1]
-        drop = np.isin(self.edge_row_indices.astype(np.int64) * ncol + self.end_points, r * ncol + c)
-        keep = ~drop
-        ind_ptr = np.zeros(self.shape[0] + 1, np.int64)
-        np.cumsum(np.bincount(self.edge_row_indices[keep], minlength=self.shape[0]), out=ind_ptr[1:])
-        return CSRMat(self.end_points[keep], ind_ptr.astype(np.int32), self.row_ids, self.col_ids, self.values[keep],
-                      self.multi_link)
+        r, c = _i32(self.row_id_to_ind(node_pair_ids[0])), _i32(self.col_id_to_ind(node_pair_ids[1]))
+        ep = np.empty(max(self.nnz, 1), np.int32)
+        vals = np.empty(max(self.nnz, 1), np.float32)
+        ind_ptr = np.empty(self.shape[0] + 1, np.int32)
+        m = ctypes.c_int64(0)
+        L.check(L.lib().sg_remove_edges_cpu(_vp(ep), _vp(vals), _vp(ind_ptr), ctypes.byref(m), _vp(self.end_points),
+                                            _vp(self.values), _vp(self.ind_ptr), self.shape[0], _vp(r), _vp(c), r.size),
+                "sg_remove_edges_cpu")
+        return CSRMat(ep[:m.value], ind_ptr, self.row_ids, self.col_ids, vals[:m.value], self.multi_link,
+                      support_row_degrees=None, support_col_degrees=None)
 
     def check_consistency(self):
         rows = self.edge_row_indices.astype(np.int64) * self.shape[1] + self.end_points
