@@ -346,7 +346,7 @@ __global__ void act_bwd_kernel(float* __restrict__ dpre, const float* __restrict
   }
 }
 
-constexpr int kColRows = 512;  // rows per workgroup in pass 1 of colsum
+constexpr int kColRows = 64;   // rows per workgroup in pass 1 of colsum
 // pass 1: partial[chunk][col] = sum over the chunk's rows.  256 threads = 4 waves; a wave reads whole row
 // segments of 64*VEC consecutive floats (1 KiB with float4) so each load instruction is one coalesced burst;
 // the 4 waves take rows r, r+4, ... and are combined through LDS.
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(float* __restrict__
                                                              long long ldx, long long M, int N) {
   __shared__ float red[4][64 * VEC];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 * VEC + lane * VEC;
-  const long long r0 = static_cast<long long>(blockIdx.y) * kColRows;
+  const int col = blockIdx.y * 64 * VEC + lane * VEC;
+  const long long r0 = static_cast<long long>(blockIdx.x) * kColRows;
   const long long r1 = min(M, r0 + kColRows);
   float acc[VEC];
 #pragma unroll
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(float* __restrict__
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const int i = lane * VEC + v;
-      partial[static_cast<long long>(blockIdx.y) * N + col + v] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+      partial[static_cast<long long>(blockIdx.x) * N + col + v] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
     }
   }
 }
@@ -476,16 +476,16 @@ SG_API int sg_colsum_hip(float* dst, const float* X, int64_t ldx, int64_t M, int
   if (M < 0 || ldx < N || N >= (1ll << 31)) return fail(SG_ERR_INVALID, "bad colsum shape");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t chunks = (M + kColRows - 1) / kColRows;
-  if (chunks > 65535) return fail(SG_ERR_INVALID, "colsum: too many rows");
+  if (chunks >= (1ll << 31) || (N + 63) / 64 > 65535) return fail(SG_ERR_INVALID, "colsum: shape too large");
   if (chunks > 0) {
     if (!workspace || workspace_bytes < sg_colsum_workspace_bytes(M, N))
       return fail(SG_ERR_WORKSPACE, "colsum workspace too small");
     if (N % 4 == 0 && ldx % 4 == 0 && aligned(X, 16))
-      hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(static_cast<unsigned>((N + 255) / 256), static_cast<unsigned>(chunks)),
+      hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>((N + 255) / 256)),
                          dim3(256), 0, st, static_cast<float*>(workspace), X, static_cast<long long>(ldx),
                          static_cast<long long>(M), static_cast<int>(N));
     else
-      hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(static_cast<unsigned>((N + 63) / 64), static_cast<unsigned>(chunks)),
+      hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>((N + 63) / 64)),
                          dim3(256), 0, st, static_cast<float*>(workspace), X, static_cast<long long>(ldx),
                          static_cast<long long>(M), static_cast<int>(N));
   }

@@ -116,10 +116,7 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
   int e = ea + grp;
-#ifndef SG_GATHER_U
-#define SG_GATHER_U 4
-#endif
-  constexpr int U = SG_GATHER_U;
+  constexpr int U = 4;
   for (; e + (U - 1) * epg < eb; e += U * epg) {
     float x[U][VEC];
     float wv[U];
@@ -272,53 +269,45 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
   if (lane == 0) *tailseg = tail_s;
 }
 
-// Adds, in chunk order, the partial rows of every segment that straddles chunk boundaries.  One wavefront scans
-// the tail-segment flags of 64 chunks (one per lane), then walks the few set lanes -- 64x fewer workgroups than
-// one per chunk, which matters because almost every chunk has nothing to fix.
+// Adds, in chunk order, the partial rows of every segment that straddles chunk boundaries.
 template <int VEC>
 __global__ __launch_bounds__(kWave) void seg_gather_fixup_kernel(const GatherArgs a) {
-  const int lane = threadIdx.x;
+  const int k = blockIdx.x;
   const int b = blockIdx.y;
+  const int s = a.ws_tailseg[static_cast<long long>(b) * a.n_chunks + k];
+  if (s < 0) return;
+  const int lane = threadIdx.x;
+  const int pb = a.indptr[s];
+  const int pe = a.indptr[s + 1];
   const long long base = static_cast<long long>(b) * a.n_chunks;
-  const int k_mine = blockIdx.x * kWave + lane;
-  const int s_mine = (k_mine < a.n_chunks) ? a.ws_tailseg[base + k_mine] : -1;
-  unsigned long long todo = __ballot(s_mine >= 0);
-  while (todo) {
-    const int l = __ffsll(static_cast<long long>(todo)) - 1;
-    todo &= todo - 1;
-    const int k = blockIdx.x * kWave + l;
-    const int s = __shfl(s_mine, l);
-    const int pb = a.indptr[s];
-    const int pe = a.indptr[s + 1];
-    const int dg = s / a.dst_group;
-    float* out = a.dst + static_cast<long long>(b) * a.dst_bs + static_cast<long long>(dg) * a.dst_ld +
-                 static_cast<long long>(s - dg * a.dst_group) * a.C;
-    const float scale = (a.mean && pe > pb) ? 1.f / static_cast<float>(pe - pb) : 1.f;
-    for (int c = lane * VEC; c < a.C; c += kWave * VEC) {
-      float acc[VEC];
-      ld_vec<VEC>(acc, a.ws_tail + (base + k) * a.C + c);
-      for (int kk = k + 1; kk < a.n_chunks && static_cast<long long>(kk) * kChunk < pe; ++kk) {
-        float h[VEC];
-        ld_vec<VEC>(h, a.ws_head + (base + kk) * a.C + c);
+  const int dg = s / a.dst_group;
+  float* out = a.dst + static_cast<long long>(b) * a.dst_bs + static_cast<long long>(dg) * a.dst_ld +
+               static_cast<long long>(s - dg * a.dst_group) * a.C;
+  const float scale = (a.mean && pe > pb) ? 1.f / static_cast<float>(pe - pb) : 1.f;
+  for (int c = lane * VEC; c < a.C; c += kWave * VEC) {
+    float acc[VEC];
+    ld_vec<VEC>(acc, a.ws_tail + (base + k) * a.C + c);
+    for (int kk = k + 1; kk < a.n_chunks && static_cast<long long>(kk) * kChunk < pe; ++kk) {
+      float h[VEC];
+      ld_vec<VEC>(h, a.ws_head + (base + kk) * a.C + c);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] += h[v];
-      }
-      if (a.mean) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] *= scale;
-      }
-      if (a.req == SG_REQ_ADD) {
-        float old[VEC];
-        ld_vec<VEC>(old, out + c);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] += old[v];
-      }
-      if (a.act) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = gather_act(acc[v], a.act, a.slope);
-      }
-      st_vec<VEC>(out + c, acc);
+      for (int v = 0; v < VEC; ++v) acc[v] += h[v];
     }
+    if (a.mean) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] *= scale;
+    }
+    if (a.req == SG_REQ_ADD) {
+      float old[VEC];
+      ld_vec<VEC>(old, out + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += old[v];
+    }
+    if (a.act) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = gather_act(acc[v], a.act, a.slope);
+    }
+    st_vec<VEC>(out + c, acc);
   }
 }
 
@@ -341,8 +330,7 @@ static void launch_variants(const GatherArgs& a, dim3 grid, hipStream_t st, bool
     if (uni) hipLaunchKernelGGL((seg_gather_kernel<VEC, false, true>), grid, dim3(kWave), 0, st, a);
     else hipLaunchKernelGGL((seg_gather_kernel<VEC, false, false>), grid, dim3(kWave), 0, st, a);
   }
-  dim3 fgrid((grid.x + kWave - 1) / kWave, grid.y);
-  hipLaunchKernelGGL((seg_gather_fixup_kernel<VEC>), fgrid, dim3(kWave), 0, st, a);
+  hipLaunchKernelGGL((seg_gather_fixup_kernel<VEC>), grid, dim3(kWave), 0, st, a);
 }
 
 // Generic launcher shared by every public entry point built on the gather kernel.

@@ -112,6 +112,37 @@ int main(int argc, char** argv) {
                        0, nullptr, 0, nullptr));
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); if (it) ms_g2 += ms;
   }
+  // ---- overlap experiment: the fabric-bound gather and the MFMA-bound contraction on ONE stream vs TWO streams ----
+  {
+    hipStream_t sa, sb;
+    CK(hipStreamCreate(&sa));
+    CK(hipStreamCreate(&sb));
+    void* ws2;
+    CK(hipMalloc(&ws2, wsb + 16));
+    float* d_out2;
+    CK(hipMalloc(&d_out2, (size_t)n_dst * D * 4));
+    hipEvent_t f0, f1, g1;
+    CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1)); CK(hipEventCreate(&g1));
+    float serial = 0, par = 0;
+    for (int it = 0; it < reps + 1; ++it) {
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(f0, sa));
+      SG(sg_seg_gather_sum_hip(d_out, 1, D, d_h, R, (int64_t)R * D, d_w, d_q, d_dip, n_dst, nnz, D, SG_REQ_WRITE,
+                               SG_ACT_LEAKY, 0.1f, ws, wsb + 16, sa));
+      SG(sg_gemm_f32_hip(d_pre, D, d_zext, ld, 0, d_wext, ld, 1, n_dst, D, ld, nullptr, SG_ACT_LEAKY, 0.1f, 0, nullptr, 0, sa));
+      CK(hipEventRecord(f1, sa)); CK(hipEventSynchronize(f1)); CK(hipEventElapsedTime(&ms, f0, f1)); if (it) serial += ms;
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(f0, sa));
+      CK(hipStreamWaitEvent(sb, f0, 0));
+      SG(sg_seg_gather_sum_hip(d_out2, 1, D, d_h, R, (int64_t)R * D, d_w, d_q, d_dip, n_dst, nnz, D, SG_REQ_WRITE,
+                               SG_ACT_LEAKY, 0.1f, ws2, wsb + 16, sa));
+      SG(sg_gemm_f32_hip(d_pre, D, d_zext, ld, 0, d_wext, ld, 1, n_dst, D, ld, nullptr, SG_ACT_LEAKY, 0.1f, 0, nullptr, 0, sb));
+      CK(hipEventRecord(g1, sb));
+      CK(hipStreamWaitEvent(sa, g1, 0));
+      CK(hipEventRecord(f1, sa)); CK(hipEventSynchronize(f1)); CK(hipEventElapsedTime(&ms, f0, f1)); if (it) par += ms;
+    }
+    printf("overlap: gather + gemm serial %.3f ms, on two streams %.3f ms\n", serial / reps, par / reps);
+  }
   const double bytes = (8.0 + 4.0 * D) * nnz;
   printf("n_dst %lld n_src %lld nnz %lld R %d D %d reps %d\n", (long long)n_dst, (long long)n_src, (long long)nnz, R, D, reps);
   printf("gather transform-first : %.3f ms  %.1f GB/s algorithmic\n", ms_tf / reps, bytes / (ms_tf / reps) / 1e6);
