@@ -166,6 +166,8 @@ class _TakeRows(torch.autograd.Function):
     def backward(ctx, dout):
         tp = ctx.tplan
         dout = L.f32c(dout)
+        if tp.inv_ids is not None:
+            return ops.masked_embed(dout, tp.inv_ids, None), None
         dt = torch.empty(ctx.shape, dtype=torch.float32, device=dout.device)
         ops.gather_sum(dt, dout, tp.t_pos, tp.t_indptr, None, tp.n_rows, ctx.shape[1])
         return dt, None

@@ -146,3 +146,10 @@ class TakePlan(object):
         self.t_indptr = torch.from_numpy(indptr).to(device)
         self.t_pos = torch.from_numpy(np.ascontiguousarray(order if order.size else np.zeros(1, np.int32))).to(device)
         self.covered = int(order.size)
+        # every row taken at most once (permutations, subsets): the gradient is a row copy through the inverse
+        # index (-1 = row not taken -> zero), one fully parallel coalesced pass instead of 1-edge segments
+        self.inv_ids = None
+        if counts.size == 0 or counts.max() <= 1:
+            inv = -np.ones(self.n_rows, np.int32)
+            inv[ids[valid]] = np.nonzero(valid)[0].astype(np.int32)
+            self.inv_ids = torch.from_numpy(inv).to(device)

@@ -148,6 +148,21 @@ def test_take_rows_and_masked_embed():
     tr = table.double().requires_grad_(True)
     OM.masked_embed(tr, ids, noise).backward(gy.double())
     rel_close(t.grad, tr.grad, 1e-5, "dtable")
+    # every row taken at most once (a partial permutation with masked entries): inverse-index gradient path
+    pids = rng.permutation(n_rows)[:60].astype(np.int32)
+    pids[::7] = -1
+    tp2 = TakePlan(pids, n_rows, "cuda")
+    assert tp2.inv_ids is not None and tp.inv_ids is None
+    t2 = table.cuda().requires_grad_(True)
+    gy2 = torch.randn(60, dim)
+    out2 = F.take_rows(t2, tp2)
+    out2.backward(gy2.cuda())
+    safe = np.where(pids < 0, 0, pids)
+    ref2 = table[torch.from_numpy(safe.astype(np.int64))] * torch.from_numpy((pids >= 0).astype(np.float32))[:, None]
+    assert torch.equal(out2.detach().cpu(), ref2)
+    gref = torch.zeros(n_rows, dim)
+    gref[torch.from_numpy(pids[pids >= 0].astype(np.int64))] = gy2[torch.from_numpy(np.nonzero(pids >= 0)[0])]
+    assert torch.equal(t2.grad.cpu(), gref)
 
 
 def test_fused_aggregator_properties_at_ml10m_size():
