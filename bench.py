@@ -147,8 +147,11 @@ def main():
         roof = {"bound": "hbm", "kernel": "seg_gather_kernel", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic, "launches_per_step": len(agg) / args.steps,
                 "avg_launch_ms": avg * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
-                "note": "gathered matrices (<=72 MB) fit the 256 MB Infinity Cache at this shape, so the algorithmic "
-                        "rate can exceed what HBM itself delivers; traffic (PMC) is in profiles/"}
+                "note": ("gathered matrices (%d-%d MB) fit the 256 MB Infinity Cache at this shape: the rate is a die-level "
+                         "fabric rate (PMC traffic in profiles/), the HBM-bound case is --shape hbm-stress"
+                         if max(max(n_user, n_item) * D * 4, min(n_user, n_item) * R * D * 4) < 256 * 2 ** 20 else
+                         "gathered matrices (%d-%d MB) exceed the 256 MB Infinity Cache: HBM-bound") %
+                        (max(n_user, n_item) * D * 4 // 2 ** 20, min(n_user, n_item) * R * D * 4 // 2 ** 20)}
 
     ms = elapsed / args.steps * 1e3
     value = E_total / (elapsed / args.steps)

@@ -12,6 +12,9 @@ SHAPES = {   # name: (n_user, n_item, n_edges, n_levels)   -- SURVEY.md section 
     "ml-1m": (6040, 3706, 1000209, 5),
     "ml-10m": (69878, 10677, 10000054, 10),
     "tiny": (60, 45, 900, 5),
+    # HBM-bound stress in the spirit of BASELINE config 5 (10M x 1M nodes, 1B edges, 16 levels, 8 GPUs), scaled to what
+    # one GPU's host can plan in about a minute: every gathered matrix (0.5-8 GB) is far beyond the 256 MB Infinity Cache
+    "hbm-stress": (600000, 500000, 60000000, 16),
 }
 
 
