@@ -1,0 +1,104 @@
+"""Edge cases of the segment operators on the GPU (C ABI path) against the CPU oracle: empty and ragged inputs, odd
+feature widths (scalar / float2 / float4 kernels), batches, colliding indices, single giant segment."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import seg as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(a, b, tol=1e-5):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
+    assert a.shape == b.shape
+    if b.size:
+        assert float(np.abs(a.astype(np.float64) - b).max()) <= tol * scale
+
+
+@pytest.mark.parametrize("C", [1, 2, 3, 6, 10, 50, 66, 130, 250, 257, 512, 1000])
+@pytest.mark.parametrize("B", [1, 3])
+def test_widths_and_batches(C, B):
+    from star_gcn_amd import contrib
+    rng = np.random.default_rng(C * 10 + B)
+    S, T, nnz = 37, 29, 900
+    cuts = np.sort(rng.integers(0, nnz + 1, S - 1))
+    indptr = np.concatenate([[0], cuts, [nnz]]).astype(np.int32)
+    idx = rng.integers(0, T, nnz).astype(np.int32)            # many collisions: 900 edges onto 29 rows
+    data = rng.normal(size=(B, T, C)).astype(np.float32)
+    w = rng.normal(size=(B, nnz)).astype(np.float32)
+    og = rng.normal(size=(B, S, C)).astype(np.float32)
+    x = dev(data).requires_grad_(True)
+    ww = dev(w).requires_grad_(True)
+    out = contrib.seg_weighted_pool(x, ww, dev(idx), dev(indptr))
+    close(out, O.seg_weighted_pool(data, w, idx, indptr))
+    out.backward(dev(og))
+    close(x.grad, O.seg_weighted_pool_bwd_data(w, og, idx, indptr, T), 2e-5)
+    close(ww.grad, O.seg_take_k_corr(og, data, idx, indptr), 2e-5)
+    for pt in ("sum", "avg", "max"):
+        ref = O.seg_pool(data, idx, indptr, pt)
+        close(contrib.seg_pool(dev(data), dev(idx), dev(indptr), pool_type=pt), ref[0] if pt == "max" else ref)
+
+
+def test_no_edges_and_all_empty_segments():
+    from star_gcn_amd import contrib, ops
+    S, T, C = 11, 7, 20
+    data = np.random.default_rng(0).normal(size=(2, T, C)).astype(np.float32)
+    indptr = np.zeros(S + 1, np.int32)
+    # nnz = 0 is represented, as the reference does (graph.py:221-222), by one padding element with weight 0
+    out = contrib.seg_weighted_pool(dev(data), dev(np.zeros((2, 1), np.float32)), dev(np.zeros(1, np.int32)), dev(indptr))
+    assert out.shape == (2, S, C) and float(out.abs().max()) == 0.0
+    val, arg = ops.seg_pool(dev(data), dev(np.zeros(1, np.int32)), dev(indptr), "max")
+    assert float(val.abs().max()) == 0.0 and int(arg.max()) == -1      # empty segment -> value 0, index -1
+    for pt in ("sum", "avg"):
+        v, _ = ops.seg_pool(dev(data), dev(np.zeros(1, np.int32)), dev(indptr), pt)
+        assert float(v.abs().max()) == 0.0
+    sm = contrib.seg_softmax(dev(np.ones((2, 1), np.float32)), dev(indptr))
+    assert float(sm.abs().max()) == 0.0                                  # positions outside every segment stay 0
+    ss = contrib.seg_sum(dev(np.ones((2, 1), np.float32)), dev(indptr))
+    assert ss.shape == (2, S) and float(ss.abs().max()) == 0.0
+    # gradient w.r.t. data of an op with no covered edge is exactly zero
+    x = dev(data).requires_grad_(True)
+    contrib.seg_weighted_pool(x, dev(np.zeros((2, 1), np.float32)), dev(np.zeros(1, np.int32)), dev(indptr)).sum().backward()
+    assert float(x.grad.abs().max()) == 0.0
+
+
+def test_one_giant_segment_and_trailing_empties():
+    """A single 300k-edge segment (spans ~1200 chunks: partial rows + fix-up) followed by empty segments."""
+    from star_gcn_amd import contrib
+    rng = np.random.default_rng(5)
+    S, T, nnz, C = 6, 5000, 300_000, 64
+    indptr = np.array([0, 0, nnz, nnz, nnz, nnz, nnz], np.int32)
+    idx = rng.integers(0, T, nnz).astype(np.int32)
+    data = rng.normal(size=(1, T, C)).astype(np.float32)
+    w = (rng.normal(size=(1, nnz)) / np.sqrt(nnz)).astype(np.float32)
+    out = contrib.seg_weighted_pool(dev(data), dev(w), dev(idx), dev(indptr)).cpu().numpy()
+    ref64 = (data[0, idx].astype(np.float64) * w[0].astype(np.float64)[:, None]).sum(axis=0)
+    assert float(np.abs(out[0, 1] - ref64).max()) <= 1e-5 * max(1.0, float(np.abs(ref64).max()))
+    assert float(np.abs(out[0, [0, 2, 3, 4, 5]]).max()) == 0.0
+    pooled = contrib.seg_pool(dev(data), dev(idx), dev(indptr), pool_type="avg").cpu().numpy()
+    avg64 = data[0, idx].astype(np.float64).mean(axis=0)
+    assert float(np.abs(pooled[0, 1] - avg64).max()) <= 1e-5
+
+
+def test_errors_are_python_exceptions():
+    """Shape / req violations surface as StarGCNError with the native message (the reference LOG(FATAL)s or exits)."""
+    from star_gcn_amd import _lib as L
+    from star_gcn_amd import ops
+    data = torch.zeros(1, 4, 8, device="cuda")
+    w = torch.zeros(1, 3, device="cuda")
+    idx = torch.zeros(3, dtype=torch.int32, device="cuda")
+    indptr = torch.tensor([0, 3], dtype=torch.int32, device="cuda")
+    with pytest.raises(L.StarGCNError, match="req"):
+        ops.seg_weighted_pool(data, w, idx, indptr, req=2)
+    with pytest.raises(L.StarGCNError, match="AddTo"):
+        L.check(L.lib().sg_seg_softmax_hip(L.ptr(w), L.ptr(w), L.ptr(indptr), 1, 1, 3, 3, None), "sg_seg_softmax_hip")
+    with pytest.raises(L.StarGCNError, match="inner dimensions"):
+        ops.gemm(torch.zeros(3, 4, device="cuda"), torch.zeros(5, 6, device="cuda"))
+    with pytest.raises(L.StarGCNError, match="CUDA/HIP tensor"):
+        ops.seg_sum(torch.zeros(1, 3), indptr)
