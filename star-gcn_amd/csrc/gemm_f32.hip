@@ -33,6 +33,10 @@ constexpr int LD_MAX = LD_D;
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+#ifndef SG_GEMM_DEFAULT_BF16X6
+#define SG_GEMM_DEFAULT_BF16X6 0
+#endif
+
 struct GemmArgs {
   float* C;
   const float* A;
@@ -48,6 +52,8 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int vecA, vecB;  // 16-byte vector loads allowed
 };
+
+void launch_gemm_bf16x6(const GemmArgs& g, bool transA, bool transB, hipStream_t st);   // gemm_bf16x6.hip
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {
@@ -421,6 +427,12 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
   if (K == 0) { g.splits = 1; g.tiles_per_split = 1; }
   int tm = choose_tm(M, N, g.splits);
   if (const char* force = getenv("SG_GEMM_TM")) tm = atoi(force) == 64 ? 64 : 128;   // tuning aid
+  // backend: exact-fp32 MFMA (this file) or the fp32-accurate bf16x6 split on the bf16 matrix cores (gemm_bf16x6.hip)
+  // measured (profiles/): bf16x6 wins for row-major A (forward / data-gradient GEMMs), fp32 MFMA for the transposed-A
+  // weight gradients; tiny K has nothing to amortise the split
+  bool use_bx6 = SG_GEMM_DEFAULT_BF16X6 && !transA && K >= 128;
+  if (const char* be = getenv("SG_GEMM_BACKEND")) use_bx6 = (be[0] == 'b') && K >= 1;
+  if (use_bx6) tm = 128;
   g.tiles_m = static_cast<int>((M + tm - 1) / tm);
   g.tiles_n = static_cast<int>((N + BN - 1) / BN);
   if (static_cast<int64_t>(g.tiles_m) * g.tiles_n >= (1ll << 31)) return fail(SG_ERR_INVALID, "too many tiles");
@@ -439,7 +451,9 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
     if (tm == 128) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, 128>), grid, dim3(kThreads), 0, st, g); \
     else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, 64>), grid, dim3(kThreads), 0, st, g);            \
   } while (0)
-  if (transA) {
+  if (use_bx6) {
+    launch_gemm_bf16x6(g, transA != 0, transB != 0, st);
+  } else if (transA) {
     if (transB) SG_LAUNCH_GEMM(true, true); else SG_LAUNCH_GEMM(true, false);
   } else {
     if (transB) SG_LAUNCH_GEMM(false, true); else SG_LAUNCH_GEMM(false, false);

@@ -40,6 +40,32 @@ def test_gemm_layouts_and_edges(M, N, K, ta, tb, tile_rows, monkeypatch):
     rel_close(out, ref + c0.double(), 2e-6 * max(1, K ** 0.5), "accumulate")
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1, 1, 1), (130, 250, 75), (257, 64, 2570), (64, 515, 64),
+                                   (1000, 75, 250), (5, 300, 1027), (700, 2576, 256)])
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_bf16x6_backend_is_fp32_accurate(M, N, K, ta, tb, monkeypatch):
+    """The bf16 matrix-core backend (three bf16 planes per operand, six MFMAs per product group) must meet the SAME
+    fp64-referenced tolerance as the exact-fp32 MFMA kernel, on every layout and on ragged edges."""
+    from star_gcn_amd import ops
+    monkeypatch.setenv("SG_GEMM_BACKEND", "bf16x6")
+    g = torch.Generator().manual_seed(M * 5 + N * 11 + K)
+    scale_rows = torch.logspace(-3, 3, M)   # rows of op(A) span six decades
+    A = torch.randn((K, M) if ta else (M, K), generator=g) * (scale_rows.view(1, -1) if ta else scale_rows.view(-1, 1))
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    out = ops.gemm(A.cuda(), B.cuda(), trans_a=ta, trans_b=tb, bias=bias.cuda(), act="leaky", slope=0.1)
+    want = OM.leaky(ref + bias.double())
+    # per-row scale: rows of A span 6 decades, so a per-row relative bound is the meaningful one
+    err = (out.double().cpu() - want).abs()
+    mag = (A.double().abs().t() if ta else A.double().abs()) @ (B.double().abs().t() if tb else B.double().abs()) + bias.abs().double()
+    assert float((err / (mag + 1e-30)).max()) <= 4e-7 * max(1.0, K ** 0.5), float((err / (mag + 1e-30)).max())
+    monkeypatch.setenv("SG_GEMM_BACKEND", "fp32")
+    out32 = ops.gemm(A.cuda(), B.cuda(), trans_a=ta, trans_b=tb, bias=bias.cuda(), act="leaky", slope=0.1)
+    e32 = float(((out32.double().cpu() - want).abs() / (mag + 1e-30)).max())
+    assert float((err / (mag + 1e-30)).max()) <= 4 * e32 + 2e-7     # same accuracy class as the exact-fp32 MFMA kernel
+
+
 def test_gemm_split_k_and_strided_views():
     from star_gcn_amd import ops
     g = torch.Generator().manual_seed(1)
