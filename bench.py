@@ -88,7 +88,6 @@ def main():
     D = args.dim
     net = M.Net(lgraph, U, I, embed_units=D, agg_units=(D, D), out_units=(D, D), nblocks=1, use_dae=False,
                 activation="leaky", dropout=0.0, agg_accum="sum", agg_order=args.order).to(dev)
-    local_params = None
     if world > 1:
         part = SD.NodePartition([U], [I])
         for enc in net.encoders:
