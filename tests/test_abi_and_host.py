@@ -146,3 +146,17 @@ def test_ops_fail_loudly_without_gpu():
     from star_gcn_amd import contrib
     with pytest.raises(L.StarGCNError):
         contrib.seg_sum(torch.zeros(1, 4), torch.tensor([0, 4], dtype=torch.int32))
+
+
+def test_drop_in_import_path():
+    """PYTHONPATH=star-gcn_amd makes `import mxgraph.layers` / `mxgraph.graph` resolve to the mirror."""
+    import subprocess
+    import sys
+    code = ("import mxgraph.layers as L, mxgraph.graph as G, mxgraph.iterators as I\n"
+            "assert all(hasattr(L, n) for n in ('MultiLinkGCNAggregator', 'GCNAggregator', 'HeterGCNLayer',"
+            " 'StackedHeterGCNLayers', 'InnerProductLayer', 'LayerDictionary', 'get_activation'))\n"
+            "assert all(hasattr(G, n) for n in ('CSRMat', 'HeterGraph', 'merge_nodes', 'merge_node_ids_dict',"
+            " 'unordered_unique', 'empty_as_zero'))\nprint('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "star-gcn_amd"))
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, cwd="/tmp").decode()
+    assert out.strip().endswith("ok")
