@@ -84,7 +84,10 @@ def c_seg_weighted_pool(data, weights, indices, indptr):
 # restated with dense per-level adjacency matrices: A[(dst, src)][r] (n_dst, n_src) holding the support of the
 # level-r edges (reference graph.py:414-429 / graph_sampler.cpp:393-420 for the support formula).
 # ------------------------------------------------------------------------------------------------------------------
-def dense_level_adjacency(row_ind, col_ind, values, levels, n_rows, n_cols, symm=True, dtype=torch.float64):
+def dense_level_adjacency(row_ind, col_ind, values, levels, n_rows, n_cols, symm=True, dtype=torch.float64,
+                          sparse=False):
+    """sparse=True returns torch sparse COO matrices (same values, `A @ X` still works and differentiates): lets the
+    oracle run at real MovieLens-1M size without dense (n_dst, n_src) float64 matrices."""
     row_ind, col_ind = np.asarray(row_ind), np.asarray(col_ind)
     dr = np.bincount(row_ind, minlength=n_rows).astype(np.float32)
     dc = np.bincount(col_ind, minlength=n_cols).astype(np.float32)
@@ -94,11 +97,16 @@ def dense_level_adjacency(row_ind, col_ind, values, levels, n_rows, n_cols, symm
         sup = (np.float32(1.0) / dr[row_ind]).astype(np.float32)
     out = []
     for lv in levels:
-        a = torch.zeros((n_rows, n_cols), dtype=dtype)
         sel = np.asarray(values) == lv
-        a[torch.as_tensor(row_ind[sel], dtype=torch.long), torch.as_tensor(col_ind[sel], dtype=torch.long)] = \
-            torch.as_tensor(sup[sel], dtype=dtype)
-        out.append(a)
+        r = torch.as_tensor(row_ind[sel], dtype=torch.long)
+        c = torch.as_tensor(col_ind[sel], dtype=torch.long)
+        v = torch.as_tensor(sup[sel], dtype=dtype)
+        if sparse:
+            out.append(torch.sparse_coo_tensor(torch.stack([r, c]), v, (n_rows, n_cols)).coalesce())
+        else:
+            a = torch.zeros((n_rows, n_cols), dtype=dtype)
+            a[r, c] = v
+            out.append(a)
     return out
 
 

@@ -134,3 +134,55 @@ def test_layer_api_with_reference_style_lists():
     ref = OM.multilink_aggregator(x.double(), [g._agg.weight0.detach().double().cpu()],
                                   [g._agg.bias0.detach().double().cpu()], eps[:1], ips[:1], sps[:1], act="tanh")
     rel_close(out, ref, 1e-5, "GCNAggregator")
+
+
+@pytest.mark.parametrize("shape,embed,batch", [("ml-100k", 64, 10000), ("ml-1m", 128, 100000)])
+def test_two_block_star_gcn_at_baseline_config_sizes(shape, embed, batch):
+    """BASELINE configs 2 and 3 (MovieLens-100k dim 64 / MovieLens-1M dim 128, 5 rating levels): the real 2-block
+    network with the shipped yaml widths (AGG 250, OUT 75, mask 0.1, recon lambda 0.1, symmetric support, rating
+    mini-batch) on the full-size synthetic graph, vs the float64 oracle with sparse float64 adjacency."""
+    import star_gcn_amd.model as M
+    import star_gcn_amd.synthetic as S
+    dev = torch.device("cuda", 0)
+    graph, eu, ei, vals = S.make_graph(shape)
+    nu, ni = graph[U, I].shape
+    rng = np.random.default_rng(1)
+    torch.manual_seed(3)
+    net = M.Net(graph, U, I, embed_units=embed, agg_units=(250,), out_units=(75,), nblocks=2, use_dae=True,
+                agg_accum="sum").to(dev)
+    noise, recon = {}, {}
+    for key, n in ((U, nu), (I, ni)):
+        perm = rng.permutation(n).astype(np.int32)
+        k = int(np.ceil(0.1 * n))
+        recon[key] = perm[:k]
+        noise[key] = np.arange(n, dtype=np.int32)          # P_ZERO = 0: masked nodes keep their own embedding
+    sel = rng.choice(eu.size, batch, replace=False)
+    pairs = np.stack([eu[sel], ei[sel]])
+    y = torch.from_numpy(((vals[sel] - vals.mean()) / vals.std()).astype(np.float32))
+    g = graph.remove_edges_by_id(U, I, pairs)               # the batch's own ratings are not aggregated over
+    m = g[U, I]
+    preds, recons, gt = net(g, rating_node_pairs=pairs, embed_noise_dict=noise, recon_node_ids_dict=recon, device=dev)
+    loss = M.star_gcn_loss(preds, recons, gt, y.to(dev), recon_lambda=0.1)
+    loss.backward()
+
+    tables, blocks, maps, projs, leaf = extract(net)
+    ru, ci, rv = m.edge_row_indices, m.end_points, m.values
+    adj = {(U, I): OM.dense_level_adjacency(ru, ci, rv, m.multi_link, nu, ni, sparse=True),
+           (I, U): OM.dense_level_adjacency(ci, ru, rv, m.multi_link, ni, nu, sparse=True)}
+    opreds, orecons, ogt = OM.dense_star_gcn(tables, noise, adj, blocks, maps, projs, (U, I, pairs[0], pairs[1]), recon)
+    oloss = 0.0
+    for pr in opreds:
+        oloss = oloss + (0.5 * (pr.view(-1) - y.double()) ** 2).mean()
+    for blk in orecons:
+        for key, pred in blk.items():
+            oloss = oloss + 0.1 * ((ogt[key] - pred) ** 2).sum(dim=1).mean()
+    oloss.backward()
+    for b in range(2):
+        rel_close(preds[b], opreds[b], 1e-5, "pred_ratings[%d]" % b)
+        for key in (U, I):
+            rel_close(recons[b][key], orecons[b][key], 1e-5, "pred_embeddings[%d][%s]" % (b, key))
+    rel_close(loss, oloss, 1e-5, "loss")
+    for name, p in net.named_parameters():
+        ref = leaf[id(p)].grad
+        if ref is not None:
+            rel_close(p.grad, ref, 5e-5, "grad " + name)
