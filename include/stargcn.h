@@ -209,6 +209,60 @@ int sg_remove_edges_cpu(int32_t* out_end_points, float* out_values, int32_t* out
                         const int32_t* end_points, const float* values, const int32_t* ind_ptr, int64_t row_num,
                         const int32_t* rm_rows, const int32_t* rm_cols, int64_t rm_num);
 
+/* ------------------------------------------------------------------------------------------------
+ * (8) the fused multi-link aggregator: reference MultiLinkGCNAggregator.hybrid_forward
+ *     (aggregators.py:111-163: R x FullyConnected + R x seg_weighted_pool + add_n/concat + activation,
+ *     and the FGradient graph MXNet builds from it) as ONE forward and ONE backward entry point:
+ *        out = act( accum_r  A_r ( x W_r^T + 1 b_r^T ) )        accum = add_n ('sum') | concat ('stack')
+ *     Parameters keep the reference layout (aggregators.py:86-97): `weights[r]` (units_per_level, in_dim)
+ *     and `biases[r]` (units_per_level) are HOST arrays of R DEVICE pointers.  The graph structure is the
+ *     resident plan built by sg_multilink_fuse_cpu (uploaded once by the caller).
+ *     order: SG_ORDER_TRANSFORM_FIRST  H = x Wcat^T + bcat on the source side, one grouped gather;
+ *            SG_ORDER_AGGREGATE_FIRST  Zext = [A_0 x | .. | A_{R-1} x | A_r 1 | 0] on the destination side,
+ *                                      one GEMM with the packed [W_0 | .. | b | 0] matrix.
+ *            SG_ORDER_AUTO             expansion on the smaller side (n_src <= n_dst -> transform first).
+ *     out: (n_dst, units_per_level) for 'sum', (n_dst, R*units_per_level) for 'stack'.
+ *     `saved` (sg_multilink_agg_saved_bytes; 0 for transform-first) is written by fwd and must be handed
+ *     unchanged to bwd: it holds Zext, the only intermediate the backward needs besides x and out.
+ *     bwd: dx (n_src,in_dim), dweights[r], dbiases[r] (host arrays of device pointers) may each be NULL;
+ *     gradients are WRITTEN (kWriteTo).  Deterministic: no atomics anywhere on the path.
+ * ---------------------------------------------------------------------------------------------- */
+#define SG_ORDER_AUTO 0
+#define SG_ORDER_TRANSFORM_FIRST 1
+#define SG_ORDER_AGGREGATE_FIRST 2
+#define SG_ACCUM_SUM 0
+#define SG_ACCUM_STACK 1
+#define SG_MAX_LINKS 32
+typedef struct sg_multilink_plan {      /* all pointers are DEVICE pointers; see sg_multilink_fuse_cpu */
+  const int32_t* c_indptr;              /* n_dst*R+1 */
+  const int32_t* c_idx;                 /* nnz: source node */
+  const int32_t* c_q;                   /* nnz: source node*R + r */
+  const float* c_w;                     /* nnz: support */
+  const int32_t* t_indptr;              /* n_src*R+1 */
+  const int32_t* t_idx;                 /* nnz: destination node */
+  const int32_t* t_q;                   /* nnz: destination node*R + r */
+  const float* t_w;                     /* nnz */
+  const int32_t* d_indptr;              /* n_dst+1 = c_indptr[::R] */
+  const int32_t* s_indptr;              /* n_src+1 = t_indptr[::R] */
+  const float* rowsum;                  /* (n_dst, R) support sums per (node, level); needed by aggregate-first */
+  int64_t n_dst, n_src, nnz;
+  int32_t num_links;
+} sg_multilink_plan;
+int sg_multilink_agg_resolve_order(const sg_multilink_plan* plan, int order);
+size_t sg_multilink_agg_saved_bytes(const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level,
+                                    int order, int accum);
+size_t sg_multilink_agg_workspace_bytes(const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level,
+                                        int order, int accum, int backward);
+int sg_multilink_agg_fwd_hip(float* out, void* saved, const float* x, const float* const* weights,
+                             const float* const* biases, const sg_multilink_plan* plan, int64_t in_dim,
+                             int64_t units_per_level, int order, int accum, int act, float slope,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* const* dbiases, const float* dout,
+                             const float* out, const void* saved, const float* x, const float* const* weights,
+                             const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level, int order,
+                             int accum, int act, float slope, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

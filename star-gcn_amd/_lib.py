@@ -68,7 +68,19 @@ _SIGS = {
     "sg_multilink_fuse_cpu": (_INT, [_P] * 11 + [_I64] * 3),
     "sg_unique_inverse_cpu": (_INT, [_P] * 5 + [_I64, _I64]),
     "sg_remove_edges_cpu": (_INT, [_P] * 7 + [_I64, _P, _P, _I64]),
+    "sg_multilink_agg_resolve_order": (_INT, [_P, _INT]),
+    "sg_multilink_agg_saved_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT]),
+    "sg_multilink_agg_workspace_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT, _INT]),
+    "sg_multilink_agg_fwd_hip": (_INT, [_P] * 6 + [_I64, _I64, _INT, _INT, _INT, _F32, _P, _SZ, _P]),
+    "sg_multilink_agg_bwd_hip": (_INT, [_P] * 9 + [_I64, _I64, _INT, _INT, _INT, _F32, _P, _SZ, _P]),
 }
+
+
+class MultiLinkPlanStruct(_c.Structure):
+    """`sg_multilink_plan` of include/stargcn.h (device pointers of a resident MultiLinkPlan)."""
+    _fields_ = [(n, _P) for n in ("c_indptr", "c_idx", "c_q", "c_w", "t_indptr", "t_idx", "t_q", "t_w", "d_indptr",
+                                  "s_indptr", "rowsum")] + \
+               [("n_dst", _I64), ("n_src", _I64), ("nnz", _I64), ("num_links", _c.c_int32)]
 
 _lib = None
 

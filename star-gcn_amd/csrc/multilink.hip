@@ -1,0 +1,374 @@
+// multilink.hip -- the fused multi-link aggregator behind ONE forward and ONE backward C-ABI call.
+//
+// Reference: MultiLinkGCNAggregator.hybrid_forward (mxgraph/layers/aggregators.py:111-163) issues, per layer and
+// direction, R FullyConnected ops, R seg_weighted_pool ops, an add_n/concat and an activation, and MXNet's autograd
+// replays the mirror image.  Here the whole thing is two entry points that sequence the library's own kernels on the
+// caller's stream (no host synchronisation, no allocation: every intermediate lives in the caller's workspace):
+//
+//   transform first   H = x Wcat^T + bcat  (n_src, R*U')      -> ONE gather with R-grouped source rows (+ activation)
+//   aggregate first   Zext = [A_0 x | .. | A_{R-1} x | A_r 1]  -> ONE MFMA contraction with [W_0 | .. | b | 0] (+ act)
+//
+// The per-level parameters keep the reference layout (R separate (U', D) weights and (U') biases); a pack kernel lays
+// them out as Wcat / Wext in the workspace and an unpack kernel scatters the packed gradient back, so a caller that
+// owns reference-shaped parameters (MXNet NDArrays, torch Parameters) needs no glue of its own.
+#include "common.hpp"
+
+namespace sg {
+namespace {
+
+struct PtrTable {
+  const float* p[SG_MAX_LINKS];
+};
+struct MutPtrTable {
+  float* p[SG_MAX_LINKS];
+};
+
+// ---- parameter packing --------------------------------------------------------------------------------------------
+// Wcat[(r*U + u), d] = W_r[u, d];  bcat[r*U + u] = b_r[u]
+__global__ void pack_cat_kernel(float* __restrict__ wcat, float* __restrict__ bcat, PtrTable w, PtrTable b, int R,
+                                int U, int D) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long per = static_cast<long long>(U) * D;
+  if (i < per * R) {
+    const int r = static_cast<int>(i / per);
+    wcat[i] = w.p[r][i - r * per];
+  }
+  if (bcat && i < static_cast<long long>(R) * U) {
+    const int r = static_cast<int>(i / U);
+    bcat[i] = b.p[r] ? b.p[r][i - static_cast<long long>(r) * U] : 0.f;
+  }
+}
+__global__ void unpack_cat_kernel(MutPtrTable dw, MutPtrTable db, const float* __restrict__ dwcat,
+                                  const float* __restrict__ dbcat, int R, int U, int D) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long per = static_cast<long long>(U) * D;
+  if (dwcat && i < per * R) {
+    const int r = static_cast<int>(i / per);
+    if (dw.p[r]) dw.p[r][i - r * per] = dwcat[i];
+  }
+  if (dbcat && i < static_cast<long long>(R) * U) {
+    const int r = static_cast<int>(i / U);
+    if (db.p[r]) db.p[r][i - static_cast<long long>(r) * U] = dbcat[i];
+  }
+}
+// Wext (rows, ld): 'sum'   rows = U    row u        : [W_0[u,:] | .. | W_{R-1}[u,:] | b_0[u] .. b_{R-1}[u] | 0]
+//                  'stack' rows = R*U  row r*U + u  : W_r[u,:] in column block r, b_r[u] in column R*D + r, else 0
+__global__ void pack_ext_kernel(float* __restrict__ wext, PtrTable w, PtrTable b, int R, int U, int D, int ld,
+                                int stack) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int rows = stack ? R * U : U;
+  if (i >= static_cast<long long>(rows) * ld) return;
+  const int row = static_cast<int>(i / ld), col = static_cast<int>(i - static_cast<long long>(row) * ld);
+  const int rr = stack ? row / U : -1, u = stack ? row - rr * U : row;
+  float v = 0.f;
+  if (col < R * D) {
+    const int rc = col / D, d = col - rc * D;
+    if (!stack || rc == rr) v = w.p[rc][static_cast<long long>(u) * D + d];
+  } else if (col < R * D + R) {
+    const int rc = col - R * D;
+    if ((!stack || rc == rr) && b.p[rc]) v = b.p[rc][u];
+  }
+  wext[i] = v;
+}
+__global__ void unpack_ext_kernel(MutPtrTable dw, MutPtrTable db, const float* __restrict__ dwext, int R, int U, int D,
+                                  int ld, int stack) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long per = static_cast<long long>(U) * D;
+  if (i < per * R) {
+    const int r = static_cast<int>(i / per);
+    const long long e = i - r * per;
+    const int u = static_cast<int>(e / D), d = static_cast<int>(e - static_cast<long long>(u) * D);
+    const long long row = stack ? static_cast<long long>(r) * U + u : u;
+    if (dw.p[r]) dw.p[r][e] = dwext[row * ld + static_cast<long long>(r) * D + d];
+  }
+  if (i < static_cast<long long>(R) * U) {
+    const int r = static_cast<int>(i / U), u = static_cast<int>(i - static_cast<long long>(r) * U);
+    const long long row = stack ? static_cast<long long>(r) * U + u : u;
+    if (db.p[r]) db.p[r][u] = dwext[row * ld + static_cast<long long>(R) * D + r];
+  }
+}
+// Zext[i, R*D + c] = c < R ? rowsum[i, c] : 0     (the bias rides on the support row sums; tail = alignment pad)
+__global__ void fill_rowsum_kernel(float* __restrict__ zext, const float* __restrict__ rowsum, long long n_dst, int R,
+                                   int D, int ld) {
+  const int extra = ld - R * D;
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_dst * extra) return;
+  const long long row = i / extra;
+  const int c = static_cast<int>(i - row * extra);
+  zext[row * ld + static_cast<long long>(R) * D + c] = c < R ? rowsum[row * R + c] : 0.f;
+}
+
+inline unsigned blocks_for(long long n) { return static_cast<unsigned>((n + 255) / 256); }
+inline size_t al(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
+inline size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+
+struct Dims {
+  int64_t n_dst, n_src, nnz, D, U, ld, outw, RU;
+  int R, order, stack;
+};
+
+int resolve_order(const sg_multilink_plan* p, int order) {
+  if (order == SG_ORDER_AUTO) return p->n_src <= p->n_dst ? SG_ORDER_TRANSFORM_FIRST : SG_ORDER_AGGREGATE_FIRST;
+  return order;
+}
+
+int make_dims(Dims* d, const sg_multilink_plan* p, int64_t in_dim, int64_t upl, int order, int accum) {
+  if (!p) return fail(SG_ERR_INVALID, "plan is null");
+  if (p->num_links < 1 || p->num_links > SG_MAX_LINKS)
+    return fail(SG_ERR_INVALID, "num_links %d outside [1, %d]", p->num_links, SG_MAX_LINKS);
+  if (p->n_dst < 0 || p->n_src < 0 || p->nnz < 0 || in_dim < 1 || upl < 1) return fail(SG_ERR_INVALID, "negative / empty size");
+  if (order < SG_ORDER_AUTO || order > SG_ORDER_AGGREGATE_FIRST) return fail(SG_ERR_INVALID, "order %d", order);
+  if (accum != SG_ACCUM_SUM && accum != SG_ACCUM_STACK) return fail(SG_ERR_INVALID, "accum %d", accum);
+  d->n_dst = p->n_dst; d->n_src = p->n_src; d->nnz = p->nnz; d->D = in_dim; d->U = upl; d->R = p->num_links;
+  d->order = resolve_order(p, order);
+  d->stack = accum == SG_ACCUM_STACK;
+  d->RU = d->R * upl;
+  d->outw = d->stack ? d->RU : upl;
+  const int64_t used = d->R * in_dim + d->R;
+  d->ld = used + ((4 - used % 4) % 4);
+  return SG_OK;
+}
+
+// workspace layout, shared by the size query and the launchers
+struct Layout {
+  size_t wpack, bpack, a, b, c, scratch, scratch_bytes, total;
+};
+Layout make_layout(const Dims& d, bool backward) {
+  Layout L{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+  const size_t f = sizeof(float);
+  size_t sc = 0;
+  if (d.order == SG_ORDER_TRANSFORM_FIRST) {
+    L.wpack = take(d.RU * d.D * f);
+    L.bpack = take(d.RU * f);
+    if (!backward) {
+      L.a = take(d.n_src * d.RU * f);                                              // H
+      sc = max2(sg_gemm_f32_workspace_bytes(d.n_src, d.RU, d.D, 0),
+                sg_seg_weighted_pool_workspace_bytes(1, d.stack ? d.n_dst * d.R : d.n_dst, d.nnz, d.U));
+    } else {
+      L.a = take(d.n_dst * d.outw * f);                                            // dpre
+      L.b = take(d.n_src * d.RU * f);                                              // dH
+      L.c = take((d.RU * d.D + d.RU) * f);                                         // dWcat | dbcat
+      sc = max2(sg_seg_weighted_pool_workspace_bytes(1, d.n_src * d.R, d.nnz, d.U),
+                max2(sg_gemm_f32_workspace_bytes(d.n_src, d.D, d.RU, 0),
+                     max2(sg_gemm_f32_workspace_bytes(d.RU, d.D, d.n_src, 1), sg_colsum_workspace_bytes(d.n_src, d.RU))));
+    }
+  } else {
+    L.wpack = take(d.outw * d.ld * f);                                             // Wext
+    if (!backward) {
+      sc = max2(sg_seg_weighted_pool_workspace_bytes(1, d.n_dst * d.R, d.nnz, d.D),
+                sg_gemm_f32_workspace_bytes(d.n_dst, d.outw, d.ld, 0));
+    } else {
+      L.a = take(d.n_dst * d.outw * f);                                            // dpre
+      L.b = take(d.n_dst * d.ld * f);                                              // dZ
+      L.c = take(d.outw * d.ld * f);                                               // dWext
+      sc = max2(sg_seg_weighted_pool_workspace_bytes(1, d.n_src, d.nnz, d.D),
+                max2(sg_gemm_f32_workspace_bytes(d.n_dst, d.ld, d.outw, 0), sg_gemm_f32_workspace_bytes(d.outw, d.ld, d.n_dst, 1)));
+    }
+  }
+  L.scratch = take(sc + 64);
+  L.scratch_bytes = sc + 64;
+  L.total = off + 256;   // slack for aligning the caller's base pointer
+  return L;
+}
+
+int fill_table(PtrTable* t, const float* const* host, int R, bool required, const char* what) {
+  for (int r = 0; r < SG_MAX_LINKS; ++r) t->p[r] = nullptr;
+  if (!host) return required ? fail(SG_ERR_INVALID, "%s is null", what) : SG_OK;
+  for (int r = 0; r < R; ++r) {
+    if (required && !host[r]) return fail(SG_ERR_INVALID, "%s[%d] is null", what, r);
+    t->p[r] = host[r];
+  }
+  return SG_OK;
+}
+
+// degenerate shapes (no destination / source nodes): the parameter gradients are exact zeros
+int zero_param_grads(const MutPtrTable& dw, const MutPtrTable& db, const Dims& d, hipStream_t st) {
+  for (int r = 0; r < d.R; ++r) {
+    if (dw.p[r] && hipMemsetAsync(dw.p[r], 0, d.U * d.D * sizeof(float), st) != hipSuccess) return fail(SG_ERR_HIP, "memset");
+    if (db.p[r] && hipMemsetAsync(db.p[r], 0, d.U * sizeof(float), st) != hipSuccess) return fail(SG_ERR_HIP, "memset");
+  }
+  return SG_OK;
+}
+
+#define SG_TRY(expr)          \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != SG_OK) return rc_; \
+  } while (0)
+
+}  // namespace
+}  // namespace sg
+
+using namespace sg;
+
+SG_API int sg_multilink_agg_resolve_order(const sg_multilink_plan* plan, int order) {
+  if (!plan) return fail(SG_ERR_INVALID, "plan is null");
+  return resolve_order(plan, order);
+}
+
+SG_API size_t sg_multilink_agg_saved_bytes(const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level,
+                                           int order, int accum) {
+  Dims d;
+  if (make_dims(&d, plan, in_dim, units_per_level, order, accum) != SG_OK) return 0;
+  return d.order == SG_ORDER_AGGREGATE_FIRST ? static_cast<size_t>(d.n_dst) * d.ld * sizeof(float) : 0;
+}
+
+SG_API size_t sg_multilink_agg_workspace_bytes(const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level,
+                                               int order, int accum, int backward) {
+  Dims d;
+  if (make_dims(&d, plan, in_dim, units_per_level, order, accum) != SG_OK) return 0;
+  return make_layout(d, backward != 0).total;
+}
+
+SG_API int sg_multilink_agg_fwd_hip(float* out, void* saved, const float* x, const float* const* weights,
+                                    const float* const* biases, const sg_multilink_plan* plan, int64_t in_dim,
+                                    int64_t units_per_level, int order, int accum, int act, float slope,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  Dims d;
+  SG_TRY(make_dims(&d, plan, in_dim, units_per_level, order, accum));
+  if (d.n_dst == 0) return SG_OK;
+  if (!out || (!x && d.n_src > 0)) return fail(SG_ERR_INVALID, "out / x is null");
+  const Layout L = make_layout(d, false);
+  if (!workspace || workspace_bytes < L.total)
+    return fail(SG_ERR_WORKSPACE, "multilink fwd workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
+  PtrTable w, b;
+  SG_TRY(fill_table(&w, weights, d.R, true, "weights"));
+  SG_TRY(fill_table(&b, biases, d.R, false, "biases"));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  void* scratch = base + L.scratch;
+
+  if (d.order == SG_ORDER_TRANSFORM_FIRST) {
+    float* wcat = reinterpret_cast<float*>(base + L.wpack);
+    float* bcat = reinterpret_cast<float*>(base + L.bpack);
+    float* h = reinterpret_cast<float*>(base + L.a);
+    hipLaunchKernelGGL(pack_cat_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, wcat, bcat, w, b, d.R,
+                       static_cast<int>(d.U), static_cast<int>(d.D));
+    SG_TRY(check_launch("pack_cat_kernel"));
+    if (d.n_src > 0)
+      SG_TRY(sg_gemm_f32_hip(h, d.RU, x, d.D, 0, wcat, d.D, 1, d.n_src, d.RU, d.D, bcat, SG_ACT_NONE, 0.f, 0, scratch,
+                             L.scratch_bytes, stream));
+    if (!d.stack)
+      return sg_seg_gather_sum_hip(out, 1, d.U, h, d.R, d.RU, plan->c_w, plan->c_q, plan->d_indptr, d.n_dst, d.nnz, d.U,
+                                   SG_REQ_WRITE, act, slope, scratch, L.scratch_bytes, stream);
+    return sg_seg_gather_sum_hip(out, d.R, d.RU, h, d.R, d.RU, plan->c_w, plan->c_q, plan->c_indptr, d.n_dst * d.R,
+                                 d.nnz, d.U, SG_REQ_WRITE, act, slope, scratch, L.scratch_bytes, stream);
+  }
+
+  if (!saved) return fail(SG_ERR_INVALID, "aggregate-first needs the `saved` buffer (sg_multilink_agg_saved_bytes)");
+  if (!plan->rowsum) return fail(SG_ERR_INVALID, "aggregate-first needs plan->rowsum");
+  float* wext = reinterpret_cast<float*>(base + L.wpack);
+  float* zext = static_cast<float*>(saved);
+  hipLaunchKernelGGL(pack_ext_kernel, dim3(blocks_for(d.outw * d.ld)), dim3(256), 0, st, wext, w, b, d.R,
+                     static_cast<int>(d.U), static_cast<int>(d.D), static_cast<int>(d.ld), d.stack);
+  SG_TRY(check_launch("pack_ext_kernel"));
+  SG_TRY(sg_seg_gather_sum_hip(zext, d.R, d.ld, x, 1, d.D, plan->c_w, plan->c_idx, plan->c_indptr, d.n_dst * d.R, d.nnz,
+                               d.D, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream));
+  hipLaunchKernelGGL(fill_rowsum_kernel, dim3(blocks_for(d.n_dst * (d.ld - d.R * d.D))), dim3(256), 0, st, zext,
+                     plan->rowsum, static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.D), static_cast<int>(d.ld));
+  SG_TRY(check_launch("fill_rowsum_kernel"));
+  return sg_gemm_f32_hip(out, d.outw, zext, d.ld, 0, wext, d.ld, 1, d.n_dst, d.outw, d.ld, nullptr, act, slope, 0,
+                         scratch, L.scratch_bytes, stream);
+}
+
+SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* const* dbiases, const float* dout,
+                                    const float* out, const void* saved, const float* x, const float* const* weights,
+                                    const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level, int order,
+                                    int accum, int act, float slope, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  Dims d;
+  SG_TRY(make_dims(&d, plan, in_dim, units_per_level, order, accum));
+  const Layout L = make_layout(d, true);
+  if (!workspace || workspace_bytes < L.total)
+    return fail(SG_ERR_WORKSPACE, "multilink bwd workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
+  if (d.n_dst > 0 && (!dout || (act != SG_ACT_NONE && !out))) return fail(SG_ERR_INVALID, "dout / out is null");
+  PtrTable w;
+  SG_TRY(fill_table(&w, weights, d.R, true, "weights"));
+  MutPtrTable dw, db;
+  bool want_w = false, want_b = false;
+  for (int r = 0; r < SG_MAX_LINKS; ++r) {
+    dw.p[r] = (dweights && r < d.R) ? dweights[r] : nullptr;
+    db.p[r] = (dbiases && r < d.R) ? dbiases[r] : nullptr;
+    want_w = want_w || dw.p[r];
+    want_b = want_b || db.p[r];
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  void* scratch = base + L.scratch;
+  float* dpre_buf = reinterpret_cast<float*>(base + L.a);
+  const float* dpre = dout;
+  if (act != SG_ACT_NONE && d.n_dst > 0) {
+    SG_TRY(sg_act_bwd_hip(dpre_buf, dout, out, d.n_dst * d.outw, act, slope, stream));
+    dpre = dpre_buf;
+  }
+  PtrTable nob;
+  for (int r = 0; r < SG_MAX_LINKS; ++r) nob.p[r] = nullptr;
+
+  if (d.order == SG_ORDER_TRANSFORM_FIRST) {
+    float* wcat = reinterpret_cast<float*>(base + L.wpack);
+    float* dh = reinterpret_cast<float*>(base + L.b);
+    float* dwcat = reinterpret_cast<float*>(base + L.c);
+    float* dbcat = dwcat + d.RU * d.D;
+    if (d.n_src == 0 || d.n_dst == 0) {
+      if (dx && d.n_src > 0 && hipMemsetAsync(dx, 0, d.n_src * d.D * sizeof(float), st) != hipSuccess)
+        return fail(SG_ERR_HIP, "memset");
+      return zero_param_grads(dw, db, d, st);
+    }
+    // dH[(n, r), :] = sum over the transposed plan of t_w * dpre[dest (, level r block)]
+    if (!d.stack)
+      SG_TRY(sg_seg_gather_sum_hip(dh, d.R, d.RU, dpre, 1, d.U, plan->t_w, plan->t_idx, plan->t_indptr, d.n_src * d.R,
+                                   d.nnz, d.U, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream));
+    else
+      SG_TRY(sg_seg_gather_sum_hip(dh, d.R, d.RU, dpre, d.R, d.RU, plan->t_w, plan->t_q, plan->t_indptr, d.n_src * d.R,
+                                   d.nnz, d.U, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream));
+    if (dx) {
+      hipLaunchKernelGGL(pack_cat_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, wcat,
+                         static_cast<float*>(nullptr), w, nob, d.R, static_cast<int>(d.U), static_cast<int>(d.D));
+      SG_TRY(check_launch("pack_cat_kernel"));
+      SG_TRY(sg_gemm_f32_hip(dx, d.D, dh, d.RU, 0, wcat, d.D, 0, d.n_src, d.D, d.RU, nullptr, SG_ACT_NONE, 0.f, 0,
+                             scratch, L.scratch_bytes, stream));
+    }
+    if (want_w) {
+      if (!x) return fail(SG_ERR_INVALID, "x is null");
+      SG_TRY(sg_gemm_f32_hip(dwcat, d.D, dh, d.RU, 1, x, d.D, 0, d.RU, d.D, d.n_src, nullptr, SG_ACT_NONE, 0.f, 0,
+                             scratch, L.scratch_bytes, stream));
+    }
+    if (want_b)
+      SG_TRY(sg_colsum_hip(dbcat, dh, d.RU, d.n_src, d.RU, SG_REQ_WRITE, scratch, L.scratch_bytes, stream));
+    if (want_w || want_b) {
+      hipLaunchKernelGGL(unpack_cat_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, dw, db,
+                         want_w ? dwcat : static_cast<const float*>(nullptr),
+                         want_b ? dbcat : static_cast<const float*>(nullptr), d.R, static_cast<int>(d.U),
+                         static_cast<int>(d.D));
+      SG_TRY(check_launch("unpack_cat_kernel"));
+    }
+    return SG_OK;
+  }
+
+  if (!saved && d.n_dst > 0) return fail(SG_ERR_INVALID, "aggregate-first backward needs the `saved` buffer of the forward");
+  float* wext = reinterpret_cast<float*>(base + L.wpack);
+  float* dz = reinterpret_cast<float*>(base + L.b);
+  float* dwext = reinterpret_cast<float*>(base + L.c);
+  const float* zext = static_cast<const float*>(saved);
+  if (dx && d.n_src > 0) {
+    hipLaunchKernelGGL(pack_ext_kernel, dim3(blocks_for(d.outw * d.ld)), dim3(256), 0, st, wext, w, nob, d.R,
+                       static_cast<int>(d.U), static_cast<int>(d.D), static_cast<int>(d.ld), d.stack);
+    SG_TRY(check_launch("pack_ext_kernel"));
+    if (d.n_dst > 0)
+      SG_TRY(sg_gemm_f32_hip(dz, d.ld, dpre, d.outw, 0, wext, d.ld, 0, d.n_dst, d.ld, d.outw, nullptr, SG_ACT_NONE, 0.f,
+                             0, scratch, L.scratch_bytes, stream));
+    SG_TRY(sg_seg_gather_sum_hip(dx, 1, d.D, dz, d.R, d.ld, plan->t_w, plan->t_q, plan->s_indptr, d.n_src, d.nnz, d.D,
+                                 SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream));
+  }
+  if ((want_w || want_b) && d.n_dst == 0) return zero_param_grads(dw, db, d, st);
+  if (want_w || want_b) {
+    SG_TRY(sg_gemm_f32_hip(dwext, d.ld, dpre, d.outw, 1, zext, d.ld, 0, d.outw, d.ld, d.n_dst, nullptr, SG_ACT_NONE, 0.f,
+                           0, scratch, L.scratch_bytes, stream));
+    hipLaunchKernelGGL(unpack_ext_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, dw, db, dwext, d.R,
+                       static_cast<int>(d.U), static_cast<int>(d.D), static_cast<int>(d.ld), d.stack);
+    SG_TRY(check_launch("unpack_ext_kernel"));
+  }
+  return SG_OK;
+}

@@ -1,8 +1,9 @@
 """Differentiable building blocks of the hot path, each backed by the C ABI (no torch math on the path):
 
   linear             Dense / FullyConnected with fused bias + activation on the fp32 MFMA GEMM
-  multilink_aggregate the multi-link graph-conv aggregation of reference aggregators.py:111-163 as ONE gather
-                     launch + ONE MFMA contraction (the reference runs R FullyConnected + R seg_weighted_pool)
+  multilink_aggregate the multi-link graph-conv aggregation of reference aggregators.py:111-163 as ONE native call
+                     (sg_multilink_agg_fwd_hip: one gather launch + one MFMA contraction; the reference runs
+                     R FullyConnected + R seg_weighted_pool + add_n/concat + activation)
   take_rows / masked_embed   row gathers with atomic-free, plan-based gradients
 
 Association order of the aggregation.  The reference computes  A_r (X W_r^T + 1 b_r^T)  ("transform first").
@@ -47,112 +48,46 @@ def linear(x, weight, bias=None, act=None, slope=0.1):
     return _Linear.apply(x, weight, bias, act, slope)
 
 
-class _TransformFirst(torch.autograd.Function):
-    """out = act( sum_r A_r (X W_r^T + b_r) )  with H = X Wcat^T + bcat (n_src, R*Uc) materialised on the SOURCE
-    side and one gather over the un-split CSR (accum 'sum') or the fused (node, level) CSR ('stack')."""
+class _MultiLinkAgg(torch.autograd.Function):
+    """out = act( accum_r A_r (x W_r^T + b_r) ) through the fused native entry points
+    sg_multilink_agg_{fwd,bwd}_hip (csrc/multilink.hip): one C call forward, one backward; the per-level
+    parameters are passed in the reference layout (R weights (U', D), R biases (U'))."""
 
     @staticmethod
-    def forward(ctx, x, wcat, bcat, plan, accum, act, slope):
-        x, wcat, bcat = L.f32c(x), L.f32c(wcat), L.f32c(bcat)
+    def forward(ctx, x, plan, accum, act, slope, order, *params):
         R = plan.R
-        uc = wcat.shape[0] // R
-        h = ops.gemm(x, wcat, trans_b=True, bias=bcat)                       # (n_src, R*uc)
-        if accum == "sum":
-            out = torch.empty((plan.n_dst, uc), dtype=torch.float32, device=x.device)
-            ops.gather_sum(out, h, plan.c_q, plan.d_indptr, plan.c_w, plan.n_dst, uc, src_group=R, src_ld=R * uc,
-                           act=act, slope=slope)
-        else:
-            out = torch.empty((plan.n_dst, R * uc), dtype=torch.float32, device=x.device)
-            ops.gather_sum(out, h, plan.c_q, plan.c_indptr, plan.c_w, plan.n_dst * R, uc, dst_group=R,
-                           dst_ld=R * uc, src_group=R, src_ld=R * uc, act=act, slope=slope)
-        ctx.plan, ctx.accum, ctx.act, ctx.slope, ctx.uc = plan, accum, act, slope, uc
-        ctx.save_for_backward(x, wcat, out)
+        x = L.f32c(x)
+        weights = [L.f32c(w) for w in params[:R]]
+        biases = [L.f32c(b) for b in params[R:]]
+        out, saved = ops.multilink_agg_fwd(x, weights, biases, plan, accum, act, slope, order)
+        ctx.plan, ctx.accum, ctx.act, ctx.slope, ctx.order = plan, accum, act, slope, order
+        ctx.saved_z = saved            # opaque native buffer (Zext of the aggregate-first order), not a graph tensor
+        ctx.save_for_backward(x, out, *weights)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, wcat, out = ctx.saved_tensors
-        plan, R, uc = ctx.plan, ctx.plan.R, ctx.uc
-        dpre = ops.act_bwd(L.f32c(dout), out, ctx.act, ctx.slope)
-        dh = torch.empty((plan.n_src, R * uc), dtype=torch.float32, device=x.device)
-        if ctx.accum == "sum":   # dH[(n,r)] = sum_p t_w * dpre[t_idx[p], :]
-            ops.gather_sum(dh, dpre, plan.t_idx, plan.t_indptr, plan.t_w, plan.n_src * R, uc, dst_group=R,
-                           dst_ld=R * uc)
-        else:                    # dH[(n,r)] = sum_p t_w * dpre[t_idx[p], r*uc:(r+1)*uc]
-            ops.gather_sum(dh, dpre, plan.t_q, plan.t_indptr, plan.t_w, plan.n_src * R, uc, dst_group=R,
-                           dst_ld=R * uc, src_group=R, src_ld=R * uc)
-        dx = ops.gemm(dh, wcat) if ctx.needs_input_grad[0] else None
-        dw = ops.gemm(dh, x, trans_a=True) if ctx.needs_input_grad[1] else None
-        db = ops.colsum(dh) if ctx.needs_input_grad[2] else None
-        return dx, dw, db, None, None, None, None
-
-
-class _AggregateFirst(torch.autograd.Function):
-    """out = act( [A_0 X | ... | A_{R-1} X | rowsum] Wext^T )  with Zext (n_dst, R*D + pad) materialised on the
-    DESTINATION side; Wext (U, R*D + pad) carries the level weights and, in the rowsum columns, the biases."""
-
-    @staticmethod
-    def forward(ctx, x, wext, plan, act, slope):
-        x, wext = L.f32c(x), L.f32c(wext)
-        R, D = plan.R, x.shape[1]
-        ld = wext.shape[1]
-        zext = torch.empty((plan.n_dst, ld), dtype=torch.float32, device=x.device)
-        ops.gather_sum(zext, x, plan.c_idx, plan.c_indptr, plan.c_w, plan.n_dst * R, D, dst_group=R, dst_ld=ld)
-        zext[:, R * D:R * D + R] = plan.rowsum
-        if ld > R * D + R:
-            zext[:, R * D + R:] = 0
-        out = ops.gemm(zext, wext, trans_b=True, act=act, slope=slope)
-        ctx.plan, ctx.act, ctx.slope, ctx.D = plan, act, slope, D
-        ctx.save_for_backward(zext, wext, out)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        zext, wext, out = ctx.saved_tensors
-        plan, R, D = ctx.plan, ctx.plan.R, ctx.D
-        dpre = ops.act_bwd(L.f32c(dout), out, ctx.act, ctx.slope)
-        dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dz = ops.gemm(dpre, wext)                                                # (n_dst, ld)
-            dx = torch.empty((plan.n_src, D), dtype=torch.float32, device=dz.device)
-            ops.gather_sum(dx, dz, plan.t_q, plan.s_indptr, plan.t_w, plan.n_src, D, src_group=R,
-                           src_ld=dz.shape[1])
-        if ctx.needs_input_grad[1]:
-            dw = ops.gemm(dpre, zext, trans_a=True)
-        return dx, dw, None, None, None
-
-
-def pack_wext(weights, biases, accum, D):
-    """(U, R*D + pad) matrix for the aggregate-first contraction, built with differentiable torch plumbing from
-    the per-level parameters: 'sum' -> [W_0 | ... | W_{R-1} | b_0 ... b_{R-1} | 0]; 'stack' -> block diagonal."""
-    R = len(weights)
-    pad = (-(R * D + R)) % 4
-    dev = weights[0].device
-    if accum == "sum":
-        cols = list(weights) + [torch.stack(list(biases), dim=1)]
-        if pad:
-            cols.append(torch.zeros((weights[0].shape[0], pad), dtype=torch.float32, device=dev))
-        return torch.cat(cols, dim=1)
-    blocks = [torch.block_diag(*weights), torch.block_diag(*[b.view(-1, 1) for b in biases])]
-    if pad:
-        blocks.append(torch.zeros((blocks[0].shape[0], pad), dtype=torch.float32, device=dev))
-    return torch.cat(blocks, dim=1)
+        x, out = ctx.saved_tensors[:2]
+        weights = list(ctx.saved_tensors[2:])
+        R = ctx.plan.R
+        need_dw = any(ctx.needs_input_grad[6:6 + R])
+        need_db = any(ctx.needs_input_grad[6 + R:6 + 2 * R])
+        dx, dws, dbs = ops.multilink_agg_bwd(L.f32c(dout), out, ctx.saved_z, x, weights, ctx.plan, ctx.accum, ctx.act,
+                                             ctx.slope, ctx.order, ctx.needs_input_grad[0], need_dw, need_db)
+        ctx.saved_z = None
+        return (dx, None, None, None, None, None) + tuple(dws or [None] * R) + tuple(dbs or [None] * R)
 
 
 def multilink_aggregate(x, weights, biases, plan, accum="stack", act=None, slope=0.1, order="auto"):
     """act( accum_r  A_r (x W_r^T + b_r) )  for the R levels of `plan`; weights[r] (U', D), biases[r] (U')."""
-    if order == "auto":
-        order = "transform_first" if plan.n_src <= plan.n_dst else "aggregate_first"
     if accum not in ("sum", "stack"):
         raise NotImplementedError(accum)
+    if order not in ("auto", "transform_first", "aggregate_first"):
+        raise L.StarGCNError("order must be 'auto', 'transform_first' or 'aggregate_first'")
     if len(weights) != plan.R or len(biases) != plan.R:
         raise L.StarGCNError("need one weight/bias per link level (%d)" % plan.R)
-    if order == "transform_first":
-        return _TransformFirst.apply(x, torch.cat(list(weights), dim=0), torch.cat(list(biases), dim=0), plan, accum,
-                                     act, slope)
-    if order == "aggregate_first":
-        return _AggregateFirst.apply(x, pack_wext(weights, biases, accum, x.shape[1]), plan, act, slope)
-    raise L.StarGCNError("order must be 'auto', 'transform_first' or 'aggregate_first'")
+    order = ops.multilink_resolve_order(plan, order)
+    return _MultiLinkAgg.apply(x, plan, accum, act, slope, order, *weights, *biases)
 
 
 class _TakeRows(torch.autograd.Function):

@@ -212,3 +212,62 @@ def masked_embed(table, ids, noise=None):
     L.check(L.lib().sg_masked_embed_hip(L.ptr(out), L.ptr(table), L.ptr(ids), L.ptr(noise), n, table.shape[0],
                                         table.shape[1], L.stream_ptr()), "sg_masked_embed_hip")
     return out
+
+
+_ORDER = {"auto": 0, "transform_first": 1, "aggregate_first": 2}
+_ACCUM = {"sum": 0, "stack": 1}
+
+
+def _ptr_array(tensors):
+    import ctypes
+    arr = (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+    return arr
+
+
+def multilink_resolve_order(plan, order):
+    rc = L.lib().sg_multilink_agg_resolve_order(_byref(plan.c_struct(False)), _ORDER[order])
+    L.check(min(rc, 0), "sg_multilink_agg_resolve_order")
+    return ("auto", "transform_first", "aggregate_first")[rc]
+
+
+def _byref(struct):
+    import ctypes
+    return ctypes.cast(ctypes.pointer(struct), ctypes.c_void_p)
+
+
+def multilink_agg_fwd(x, weights, biases, plan, accum, act, slope, order):
+    """Fused aggregator forward (sg_multilink_agg_fwd_hip).  Returns (out, saved) -- `saved` is the opaque buffer
+    the backward needs (None for transform-first)."""
+    L.require_gpu(x, *weights)
+    lib = L.lib()
+    D, upl = x.shape[1], weights[0].shape[0]
+    o, a = _ORDER[order], _ACCUM[accum]
+    st = plan.c_struct(order != "transform_first")
+    outw = upl * (plan.R if accum == "stack" else 1)
+    out = torch.empty((plan.n_dst, outw), dtype=torch.float32, device=x.device)
+    nsaved = lib.sg_multilink_agg_saved_bytes(_byref(st), D, upl, o, a)
+    saved = torch.empty(nsaved // 4, dtype=torch.float32, device=x.device) if nsaved else None
+    ws, wsn = L.workspace(lib.sg_multilink_agg_workspace_bytes(_byref(st), D, upl, o, a, 0), x.device)
+    wp, bp = _ptr_array(weights), _ptr_array(biases)
+    L.check(lib.sg_multilink_agg_fwd_hip(L.ptr(out), L.ptr(saved), L.ptr(x), wp, bp, _byref(st), D, upl, o, a,
+                                         _act_id(act), float(slope), L.ptr(ws), wsn, L.stream_ptr()),
+            "sg_multilink_agg_fwd_hip")
+    return out, saved
+
+
+def multilink_agg_bwd(dout, out, saved, x, weights, plan, accum, act, slope, order, need_dx, need_dw, need_db):
+    """Fused aggregator backward (sg_multilink_agg_bwd_hip) -> (dx | None, [dW_r] | None, [db_r] | None)."""
+    L.require_gpu(dout, x, *weights)
+    lib = L.lib()
+    D, upl = x.shape[1], weights[0].shape[0]
+    o, a = _ORDER[order], _ACCUM[accum]
+    st = plan.c_struct(order != "transform_first")
+    dx = torch.empty((plan.n_src, D), dtype=torch.float32, device=x.device) if need_dx else None
+    dws = [torch.empty_like(w) for w in weights] if need_dw else None
+    dbs = [torch.empty(upl, dtype=torch.float32, device=x.device) for _ in weights] if need_db else None
+    ws, wsn = L.workspace(lib.sg_multilink_agg_workspace_bytes(_byref(st), D, upl, o, a, 1), x.device)
+    L.check(lib.sg_multilink_agg_bwd_hip(L.ptr(dx), _ptr_array(dws) if dws else None, _ptr_array(dbs) if dbs else None,
+                                         L.ptr(dout), L.ptr(out), L.ptr(saved), L.ptr(x), _ptr_array(weights),
+                                         _byref(st), D, upl, o, a, _act_id(act), float(slope), L.ptr(ws), wsn,
+                                         L.stream_ptr()), "sg_multilink_agg_bwd_hip")
+    return dx, dws, dbs

@@ -112,6 +112,18 @@ class MultiLinkPlan(object):
         self.d_indptr = up(np.ascontiguousarray(c_indptr[::R]))
         self.s_indptr = up(np.ascontiguousarray(t_indptr[::R]))
         self._rowsum = None
+        self._struct = None
+
+    def c_struct(self, need_rowsum):
+        """ctypes `sg_multilink_plan` view of the resident arrays (kept alive by this object)."""
+        if self._struct is None or (need_rowsum and not self._struct.rowsum):
+            st = L.MultiLinkPlanStruct()
+            for name in ("c_indptr", "c_idx", "c_q", "c_w", "t_indptr", "t_idx", "t_q", "t_w", "d_indptr", "s_indptr"):
+                setattr(st, name, getattr(self, name).data_ptr())
+            st.rowsum = self.rowsum.data_ptr() if need_rowsum else None
+            st.n_dst, st.n_src, st.nnz, st.num_links = self.n_dst, self.n_src, self.nnz, self.R
+            self._struct = st
+        return self._struct
 
     @property
     def rowsum(self):

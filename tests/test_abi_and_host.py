@@ -21,7 +21,7 @@ def declared_symbols():
 
 def test_library_exports_every_declared_symbol():
     names = declared_symbols()
-    assert len(names) >= 25
+    assert len(names) >= 35
     handle = ctypes.CDLL(L.SO_PATH)
     for n in names:
         assert hasattr(handle, n), "libstargcn_hip.so does not export %s" % n
@@ -137,6 +137,37 @@ def test_multilink_fuse_structure():
     np.testing.assert_allclose(A, B, rtol=0, atol=1e-6)
     assert np.array_equal(plan.d_indptr.numpy(), c_indptr[::R])
     assert np.array_equal(plan.s_indptr.numpy(), t_indptr[::R])
+
+
+def test_fused_aggregator_entry_sizes_orders_and_errors():
+    """sg_multilink_agg_* (the fused entry of SURVEY 8b): order resolution, buffer sizing and argument errors are
+    host-side decisions -- checked here without launching anything."""
+    lib = L.lib()
+    st = L.MultiLinkPlanStruct()
+    st.n_dst, st.n_src, st.nnz, st.num_links = 1000, 300, 20000, 5
+    ref = ctypes.cast(ctypes.pointer(st), ctypes.c_void_p)
+    assert lib.sg_multilink_agg_resolve_order(ref, 0) == 1          # n_src <= n_dst -> transform first
+    st.n_dst, st.n_src = 300, 1000
+    assert lib.sg_multilink_agg_resolve_order(ref, 0) == 2          # expansion on the smaller (destination) side
+    assert lib.sg_multilink_agg_resolve_order(ref, 1) == 1
+    D, U = 64, 50
+    ld = 5 * D + 5 + 3                                              # R*D + R rowsum columns, padded to a multiple of 4
+    assert lib.sg_multilink_agg_saved_bytes(ref, D, U, 2, 0) == 300 * ld * 4
+    assert lib.sg_multilink_agg_saved_bytes(ref, D, U, 1, 0) == 0
+    for order in (1, 2):
+        for accum in (0, 1):
+            f = lib.sg_multilink_agg_workspace_bytes(ref, D, U, order, accum, 0)
+            b = lib.sg_multilink_agg_workspace_bytes(ref, D, U, order, accum, 1)
+            assert f > 0 and b > f
+    # transform-first forward must at least hold Wcat, bcat and H = (n_src, R*U)
+    assert lib.sg_multilink_agg_workspace_bytes(ref, D, U, 1, 0, 0) >= (5 * U * D + 5 * U + 1000 * 5 * U) * 4
+    buf = np.zeros(16, np.float32)
+    ptrs = (ctypes.c_void_p * 5)(*[buf.ctypes.data] * 5)
+    rc = lib.sg_multilink_agg_fwd_hip(_vp(buf), None, _vp(buf), ptrs, ptrs, ref, D, U, 1, 0, 0, 0.1, _vp(buf), 64, None)
+    assert rc == -5 and b"workspace too small" in lib.sg_last_error()
+    st.num_links = 33
+    assert lib.sg_multilink_agg_fwd_hip(_vp(buf), None, _vp(buf), ptrs, ptrs, ref, D, U, 1, 0, 0, 0.1, None, 0, None) == -1
+    assert lib.sg_multilink_agg_workspace_bytes(None, D, U, 1, 0, 0) == 0 and b"plan is null" in lib.sg_last_error()
 
 
 def test_ops_fail_loudly_without_gpu():

@@ -149,6 +149,45 @@ def test_multilink_aggregate_matches_reference_order(n_dst, n_src, nnz, R, D, U,
         rel_close(bd[r].grad, br[r].grad, 2e-5, "db%d" % r)
 
 
+@pytest.mark.parametrize("nnz", [700, 0])
+@pytest.mark.parametrize("order", ["auto", "transform_first", "aggregate_first"])
+def test_fused_aggregator_raw_c_abi(order, nnz):
+    """sg_multilink_agg_{fwd,bwd}_hip called the way a non-torch host would (ctypes, caller-owned buffers, selective
+    gradients), incl. a graph with zero edges (reference pads every level with one weight-0 edge, graph.py:221-222)."""
+    from star_gcn_amd import ops
+    from star_gcn_amd.plan import MultiLinkPlan
+    n_dst, n_src, R, D, U = 37, 53, 4, 24, 20
+    rng = np.random.default_rng(5 + nnz)
+    eps, ips, sps = make_multilink(rng, n_dst, n_src, nnz, R)
+    g = torch.Generator().manual_seed(nnz + 1)
+    x = torch.randn(n_src, D, generator=g)
+    ws = [torch.randn(U, D, generator=g) * 0.2 for _ in range(R)]
+    bs = [torch.randn(U, generator=g) for _ in range(R)]
+    gy = torch.randn(n_dst, U, generator=g)
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    br = [b.double().requires_grad_(True) for b in bs]
+    ref = OM.multilink_aggregator(xr, wr, br, eps, ips, sps, accum="sum", act="tanh")
+    ref.backward(gy.double())
+    plan = MultiLinkPlan(eps, ips, sps, n_src, "cuda")
+    resolved = ops.multilink_resolve_order(plan, order)
+    assert resolved == ("transform_first" if order == "transform_first" else "aggregate_first")   # n_src > n_dst
+    xd, wd, bd = x.cuda(), [w.cuda() for w in ws], [b.cuda() for b in bs]
+    out, saved = ops.multilink_agg_fwd(xd, wd, bd, plan, "sum", "tanh", 0.1, resolved)
+    assert (saved is None) == (resolved == "transform_first")
+    rel_close(out, ref, 1e-5, "out")
+    dx, dws, dbs = ops.multilink_agg_bwd(gy.cuda(), out, saved, xd, wd, plan, "sum", "tanh", 0.1, resolved, True, True, True)
+    rel_close(dx, xr.grad, 1e-5, "dx")
+    for r in range(R):
+        rel_close(dws[r], wr[r].grad, 2e-5, "dW%d" % r)
+        rel_close(dbs[r], br[r].grad, 2e-5, "db%d" % r)
+    # selective gradients: only dx, only parameters
+    dx2, dws2, dbs2 = ops.multilink_agg_bwd(gy.cuda(), out, saved, xd, wd, plan, "sum", "tanh", 0.1, resolved, True, False, False)
+    assert dws2 is None and dbs2 is None and torch.equal(dx2, dx)
+    dx3, dws3, _ = ops.multilink_agg_bwd(gy.cuda(), out, saved, xd, wd, plan, "sum", "tanh", 0.1, resolved, False, True, True)
+    assert dx3 is None and all(torch.equal(a, b) for a, b in zip(dws3, dws))
+
+
 def test_take_rows_and_masked_embed():
     from star_gcn_amd import functional as F
     from star_gcn_amd import ops
