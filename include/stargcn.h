@@ -208,6 +208,13 @@ int sg_unique_inverse_cpu(int32_t* uniq, int32_t* inverse, int32_t* counts, int6
 int sg_remove_edges_cpu(int32_t* out_end_points, float* out_values, int32_t* out_ind_ptr, int64_t* new_nnz,
                         const int32_t* end_points, const float* values, const int32_t* ind_ptr, int64_t row_num,
                         const int32_t* rm_rows, const int32_t* rm_cols, int64_t rm_num);
+/* random_sample_fix_neighbor  graph_sampler.cpp:742-779: per selected row all edges (<= neighbor_num of them, or
+ * neighbor_num < 0) or neighbor_num positions drawn without replacement; row i's draw depends only on (seed, i)
+ * and positions come back in increasing order.  sampled == NULL: only dst_ind_ptr (sel_num+1) is filled. */
+int sg_sample_fix_neighbor_cpu(int32_t* sampled, int32_t* dst_ind_ptr, const int32_t* src_ind_ptr,
+                               const int32_t* sel_indices, int64_t sel_num, int64_t neighbor_num, uint64_t seed);
+/* gen_row_indices_by_indptr  py_ext.cpp:612-627 / graph.py:83-99: COO row index of every edge */
+int sg_gen_row_indices_cpu(int32_t* row_indices, const int32_t* ind_ptr, int64_t row_num, int64_t nnz);
 
 /* ------------------------------------------------------------------------------------------------
  * (8) the fused multi-link aggregator: reference MultiLinkGCNAggregator.hybrid_forward

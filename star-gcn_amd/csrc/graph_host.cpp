@@ -217,3 +217,68 @@ SG_API int sg_remove_edges_cpu(int32_t* out_end_points, float* out_values, int32
   *new_nnz = w;
   return SG_OK;
 }
+
+// random_sample_fix_neighbor of the reference (graph_sampler.cpp:742-779): for every selected row keep all of its
+// edges when it has <= neighbor_num of them (or neighbor_num < 0), otherwise draw neighbor_num edge positions
+// uniformly WITHOUT replacement.  Differences by design: the draw of row i depends only on (seed, i) -- the
+// reference indexes its RNG by OpenMP thread id, so its output changes with the thread count -- and the positions
+// of a row are returned in increasing order (CSR column order is preserved for the level split that follows).
+// Call with sampled == NULL to obtain dst_ind_ptr (sel_num+1) first; sampled holds dst_ind_ptr[sel_num] entries.
+static inline uint64_t splitmix64(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+SG_API int sg_sample_fix_neighbor_cpu(int32_t* sampled, int32_t* dst_ind_ptr, const int32_t* src_ind_ptr,
+                                      const int32_t* sel_indices, int64_t sel_num, int64_t neighbor_num,
+                                      uint64_t seed) {
+  if (sel_num < 0) return fail(SG_ERR_INVALID, "negative dimension");
+  if (!dst_ind_ptr || !src_ind_ptr || (sel_num > 0 && !sel_indices)) return fail(SG_ERR_INVALID, "null argument");
+  int64_t total = 0;
+  dst_ind_ptr[0] = 0;
+  for (int64_t i = 0; i < sel_num; ++i) {
+    const int64_t len = src_ind_ptr[sel_indices[i] + 1] - src_ind_ptr[sel_indices[i]];
+    total += (neighbor_num < 0) ? len : std::min<int64_t>(neighbor_num, len);
+    if (total > INT32_MAX) return fail(SG_ERR_VALUE, "sampled edge count exceeds int32");
+    dst_ind_ptr[i + 1] = static_cast<int32_t>(total);
+  }
+  if (!sampled) return SG_OK;
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t i = 0; i < sel_num; ++i) {
+    const int32_t b = src_ind_ptr[sel_indices[i]], e = src_ind_ptr[sel_indices[i] + 1];
+    const int32_t k = dst_ind_ptr[i + 1] - dst_ind_ptr[i], len = e - b;
+    int32_t* out = sampled + dst_ind_ptr[i];
+    if (k == len) {
+      for (int32_t j = 0; j < len; ++j) out[j] = b + j;
+      continue;
+    }
+    uint64_t st = seed ^ (0xD1B54A32D192ED03ull * static_cast<uint64_t>(i + 1));
+    // Floyd's algorithm: k distinct values of [0, len) in O(k^2) worst case on tiny k, O(k log k) via the sorted insert
+    int32_t n = 0;
+    for (int32_t j = len - k; j < len; ++j) {
+      const int32_t t = static_cast<int32_t>(splitmix64(st) % static_cast<uint64_t>(j + 1));
+      int32_t* pos = std::lower_bound(out, out + n, b + t);
+      int32_t v = b + t;
+      if (pos != out + n && *pos == v) {   // already chosen -> take j itself (larger than everything chosen so far)
+        v = b + j;
+        pos = out + n;
+      }
+      std::copy_backward(pos, out + n, out + n + 1);
+      *pos = v;
+      ++n;
+    }
+  }
+  return SG_OK;
+}
+
+// gen_row_indices_by_indptr of the reference (graph_sampler.h / py_ext.cpp:612-627): COO row index of every edge
+SG_API int sg_gen_row_indices_cpu(int32_t* row_indices, const int32_t* ind_ptr, int64_t row_num, int64_t nnz) {
+  if (row_num < 0 || nnz < 0) return fail(SG_ERR_INVALID, "negative dimension");
+  if (row_num > 0 && ind_ptr[row_num] != nnz) return fail(SG_ERR_VALUE, "ind_ptr[-1] = %d but nnz = %lld", ind_ptr[row_num],
+                                                         static_cast<long long>(nnz));
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < row_num; ++i)
+    for (int32_t j = ind_ptr[i]; j < ind_ptr[i + 1]; ++j) row_indices[j] = static_cast<int32_t>(i);
+  return SG_OK;
+}

@@ -25,6 +25,19 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+_SEED = [0x5EED]
+
+
+def set_seed(seed):
+    """reference graph.py:70-81: seed of the native neighbour sampler (every draw advances it)."""
+    _SEED[0] = int(seed) & 0xFFFFFFFFFFFFFFFF
+
+
+def _next_seed():
+    _SEED[0] = (_SEED[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+    return _SEED[0]
+
+
 def unordered_unique(data, return_counts=False, return_inverse=False):
     """Unique values in FIRST-OCCURRENCE order (what the reference's hash-based unique yields for n <= 10000,
     graph_sampler.h:465-534; above that its order depends on the OpenMP schedule)."""
@@ -152,7 +165,9 @@ class CSRMat(object):
 
     @property
     def edge_row_indices(self):
-        return np.repeat(np.arange(self.shape[0], dtype=np.int32), np.diff(self.ind_ptr))
+        out = np.empty(self.nnz, np.int32)
+        L.check(L.lib().sg_gen_row_indices_cpu(_vp(out), _vp(self.ind_ptr), self.shape[0], self.nnz), "sg_gen_row_indices_cpu")
+        return out
 
     @property
     def node_pair_ids(self):
@@ -214,11 +229,17 @@ class CSRMat(object):
         beg, end = self.ind_ptr[src].astype(np.int64), self.ind_ptr[src + 1].astype(np.int64)
         lens = end - beg
         if num_neighbors is not None and num_neighbors >= 0:
-            rng = np.random.default_rng() if rng is None else rng
-            take = np.minimum(lens, num_neighbors)
-            sampled = np.concatenate([np.sort(b + rng.choice(l, t, replace=False)) if t else np.zeros(0, np.int64)
-                                      for b, l, t in zip(beg, lens, take)] or [np.zeros(0, np.int64)])
-            lens = take
+            # native sampler (sg_sample_fix_neighbor_cpu == reference random_sample_fix_neighbor)
+            seed = int(rng.integers(0, 2 ** 63)) if rng is not None else _next_seed()
+            src32 = _i32(src)
+            dst_ptr = np.empty(src32.size + 1, np.int32)
+            L.check(L.lib().sg_sample_fix_neighbor_cpu(None, _vp(dst_ptr), _vp(self.ind_ptr), _vp(src32), src32.size,
+                                                       int(num_neighbors), seed), "sg_sample_fix_neighbor_cpu")
+            sampled = np.empty(max(int(dst_ptr[-1]), 1), np.int32)
+            L.check(L.lib().sg_sample_fix_neighbor_cpu(_vp(sampled), _vp(dst_ptr), _vp(self.ind_ptr), _vp(src32),
+                                                       src32.size, int(num_neighbors), seed), "sg_sample_fix_neighbor_cpu")
+            sampled = sampled[:int(dst_ptr[-1])]
+            lens = np.diff(dst_ptr).astype(np.int64)
         else:
             dst_ptr = np.concatenate([[0], np.cumsum(lens)])
             sampled = np.repeat(beg - dst_ptr[:-1], lens) + np.arange(int(dst_ptr[-1]))

@@ -89,6 +89,54 @@ def test_sample_neighbors_full_and_subset():
         assert np.all(np.isin(got, m.end_points[m.ind_ptr[s]:m.ind_ptr[s + 1]]))
 
 
+def test_native_fix_neighbor_sampler_properties():
+    """sg_sample_fix_neighbor_cpu (reference random_sample_fix_neighbor, graph_sampler.cpp:742-779): sizes
+    min(k, degree), no repeats, increasing positions inside the row, deterministic in (seed, row) and independent of
+    the other rows, uniform over the row's edges."""
+    import ctypes
+    import star_gcn_amd._lib as L
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rng = np.random.default_rng(1)
+    lens = rng.integers(0, 40, 300)
+    lens[7] = 1000
+    ind_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    sel = rng.permutation(300).astype(np.int32)[:200]
+    sel[3] = 7
+
+    def draw(sel, k, seed):
+        ptr = np.empty(sel.size + 1, np.int32)
+        L.check(L.lib().sg_sample_fix_neighbor_cpu(None, vp(ptr), vp(ind_ptr), vp(sel), sel.size, k, seed))
+        out = np.empty(max(int(ptr[-1]), 1), np.int32)
+        L.check(L.lib().sg_sample_fix_neighbor_cpu(vp(out), vp(ptr), vp(ind_ptr), vp(sel), sel.size, k, seed))
+        return out[:ptr[-1]], ptr
+
+    out, ptr = draw(sel, 10, 42)
+    for i, r in enumerate(sel):
+        got = out[ptr[i]:ptr[i + 1]]
+        assert got.size == min(10, lens[r])
+        assert np.all(np.diff(got) > 0)
+        assert got.size == 0 or (got[0] >= ind_ptr[r] and got[-1] < ind_ptr[r + 1])
+    out2, _ = draw(sel, 10, 42)
+    assert np.array_equal(out, out2)
+    out3, _ = draw(sel, 10, 43)
+    assert not np.array_equal(out, out3)
+    full, fptr = draw(sel, -1, 0)
+    assert fptr[-1] == lens[sel].sum()
+    assert np.array_equal(full[fptr[3]:fptr[4]], np.arange(ind_ptr[7], ind_ptr[8]))
+    # uniformity on the 1000-edge row: every edge is kept with probability k/len (chi-square-ish bound)
+    one = np.array([7], np.int32)
+    hits = np.zeros(1000)
+    for seed in range(2000):
+        o, _ = draw(one, 100, seed)
+        hits[o - ind_ptr[7]] += 1
+    assert abs(hits.mean() - 200) < 1e-9 and hits.std() < 3 * np.sqrt(200 * 0.9) and hits.min() > 130 and hits.max() < 270
+    # COO row indices
+    rows = np.empty(int(ind_ptr[-1]), np.int32)
+    L.check(L.lib().sg_gen_row_indices_cpu(vp(rows), vp(ind_ptr), 300, int(ind_ptr[-1])))
+    assert np.array_equal(rows, np.repeat(np.arange(300), lens))
+    assert L.lib().sg_gen_row_indices_cpu(vp(rows), vp(ind_ptr), 300, 5) == -4
+
+
 def test_remove_edges_both_directions():
     graph, eu, ei, vals = small_graph(seed=5)
     drop = np.stack([eu[::7], ei[::7]])
