@@ -80,21 +80,39 @@ def merge_nodes(node_ids):
 
 
 def merge_node_ids_dict(data):
-    """data: sequence of {key: ids}; returns ({key: unique ids}, [ {key: index of every id in the unique list} ])."""
+    """reference graph.py:166-219.  data: sequence of dicts holding either {key: ids (n,)} or
+    {(src_key, dst_key): ids (1 + K, n)} (row 0 = src ids, rows 1.. = dst ids).  Returns ({key: unique ids},
+    [same-shaped dicts with every id replaced by its index in the unique list of its node type])."""
     per_key = dict()
     for d in data:
         for key, ids in d.items():
-            per_key.setdefault(key, []).append(_i32(ids))
+            ids = _i32(ids)
+            if isinstance(key, tuple):
+                assert ids.ndim == 2
+                per_key.setdefault(key[0], []).append(ids[0, :])
+                per_key.setdefault(key[1], []).append(ids[1:, :].reshape(-1))
+            else:
+                per_key.setdefault(key, []).append(ids)
     uniq, inds = dict(), dict()
     for key, lst in per_key.items():
         uniq[key], inds[key] = merge_nodes(lst)
     counter = {key: 0 for key in per_key}
+
+    def pop(key):
+        counter[key] += 1
+        return inds[key][counter[key] - 1]
+
     out = []
     for d in data:
         nd = dict()
-        for key in d:
-            nd[key] = inds[key][counter[key]]
-            counter[key] += 1
+        for key, ids in d.items():
+            if isinstance(key, tuple):
+                shape = np.asarray(ids).shape
+                src = pop(key[0]).reshape((1, shape[1]))
+                dst = pop(key[1]).reshape((shape[0] - 1, shape[1]))
+                nd[key] = np.concatenate([src, dst], axis=0)
+            else:
+                nd[key] = pop(key)
         out.append(nd)
     return uniq, out
 

@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/graph_glue_golden.npz: outputs of the REFERENCE's own Python graph layer
+(mxgraph/graph.py CSRMat / HeterGraph / merge_nodes / merge_node_ids_dict / empty_as_zero and
+mxgraph/iterators.py DataIterator, mxgraph/layers/layers.py StackedHeterGCNLayers.gen_plan) on seeded inputs.  Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_graph_golden.py
+
+How the reference code is executed
+----------------------------------
+`graph.py` imports `mxnet` (absent) and the compiled extension `mxgraph._graph_sampler` (needs google/sparsehash,
+absent -> unbuildable here) at its top.  This script parses the two reference files with `ast` where they lie,
+drops exactly those two import statements (and iterators.py's `from mxgraph.graph import ...`), and executes the
+remaining, unmodified reference definitions.  The 8 C++ primitives the Python glue calls through `_graph_sampler`
+are supplied by the `Primitives` class below: `get_support` and `multi_link_split` by the oracle's C restatement
+(oracle/seg_oracle.c), the others by numpy one-liners restated from the cited C++ lines.  So what these vectors
+PIN is the reference's Python glue -- id<->index mapping, CSR transposition, both-direction edge removal, per-level
+neighbour lists (`sample_neighbors`), node merging / re-indexing, and the samplers' RNG call sequence -- i.e. the
+integer plan arrays that enter the hot path.  The primitives themselves stay "parity unpinned" (DESIGN.md section 5).
+No reference text is copied into this repository: the committed artefact is data.
+"""
+import ast
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import seg as O  # noqa: E402
+
+REF_GRAPH = "/root/reference/mxgraph/graph.py"
+REF_ITER = "/root/reference/mxgraph/iterators.py"
+REF_LAYERS = "/root/reference/mxgraph/layers/layers.py"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_glue_golden.npz")
+
+
+class Primitives(object):
+    """Stand-in for `mxgraph._graph_sampler` (py_ext.cpp:612-627)."""
+
+    @staticmethod
+    def _first_occurrence(data):
+        data = np.asarray(data)
+        uniq, first, inv, cnt = np.unique(data, return_index=True, return_inverse=True, return_counts=True)
+        order = np.argsort(first, kind="stable")
+        rank = np.empty_like(order)
+        rank[order] = np.arange(order.size)
+        return uniq[order].astype(np.int32), rank[inv].astype(np.int32), cnt[order].astype(np.int32)
+
+    def unique_cnt(self, data):                       # graph_sampler.h:441-463
+        u, _, c = self._first_occurrence(data)
+        return u, c
+
+    def unique_inverse(self, data):                   # graph_sampler.h:465-534
+        u, i, _ = self._first_occurrence(data)
+        return u, i
+
+    @staticmethod
+    def gen_row_indices_by_indptr(ind_ptr, nnz):      # graph.py:83-99 docstring
+        return np.repeat(np.arange(ind_ptr.size - 1, dtype=np.int32), np.diff(ind_ptr)).astype(np.int32)
+
+    @staticmethod
+    def get_support(row_degrees, col_degrees, ind_ptr, end_points, symm):   # graph_sampler.cpp:393-420
+        return O.get_support(row_degrees, col_degrees, end_points, ind_ptr, symm=bool(symm))
+
+    @staticmethod
+    def random_sample_fix_neighbor(ind_ptr, sel_indices, neighbor_num):     # graph_sampler.cpp:742-779
+        lens = ind_ptr[sel_indices + 1] - ind_ptr[sel_indices]
+        if neighbor_num >= 0 and np.any(lens > neighbor_num):
+            raise NotImplementedError("the random branch is thread-dependent in the reference; not used for goldens")
+        dst = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        pos = np.concatenate([np.arange(ind_ptr[s], ind_ptr[s + 1]) for s in sel_indices] + [np.zeros(0, np.int64)])
+        return pos.astype(np.int32), dst
+
+    @staticmethod
+    def remove_edges_by_indices(end_points, values, ind_ptr, rows, cols):   # graph_sampler.cpp:154-201
+        drop = set(zip(rows.tolist(), cols.tolist()))
+        ep, va, ip = [], [], [0]
+        for i in range(ind_ptr.size - 1):
+            for j in range(ind_ptr[i], ind_ptr[i + 1]):
+                if (i, int(end_points[j])) not in drop:
+                    ep.append(end_points[j])
+                    va.append(values[j])
+            ip.append(len(ep))
+        return np.array(ep, np.int32), np.array(va, np.float32), np.array(ip, np.int32)
+
+    @staticmethod
+    def multi_link_split(edge_values, ind_ptr, multi_link):                 # graph_sampler.cpp:277-376
+        pos, ips = O.multi_link_split(np.ascontiguousarray(edge_values, np.float32),
+                                      np.ascontiguousarray(ind_ptr, np.int32),
+                                      np.ascontiguousarray(multi_link, np.float32))
+        return list(pos), list(ips)
+
+    @staticmethod
+    def take_1d_omp(data, sel):
+        return np.take(data, sel)
+
+
+def load_reference():
+    def keep(node):
+        if isinstance(node, ast.Import):
+            return not any(a.name in ("mxnet", "mxgraph._graph_sampler") for a in node.names)
+        if isinstance(node, ast.ImportFrom):
+            return node.module != "mxgraph.graph"
+        return True
+
+    ns = {"_graph_sampler": Primitives(), "mx": None, "__name__": "reference_graph"}
+    with open(REF_GRAPH) as f:
+        tree = ast.parse(f.read(), REF_GRAPH)
+    exec(compile(ast.Module(body=[n for n in tree.body if keep(n)], type_ignores=[]), REF_GRAPH, "exec"), ns)
+    it = {"HeterGraph": ns["HeterGraph"], "CSRMat": ns["CSRMat"], "__name__": "reference_iterators"}
+    with open(REF_ITER) as f:
+        tree = ast.parse(f.read(), REF_ITER)
+    exec(compile(ast.Module(body=[n for n in tree.body if keep(n)], type_ignores=[]), REF_ITER, "exec"), it)
+    return ns, it
+
+
+def load_reference_gen_plan(graph_ns):
+    """`StackedHeterGCNLayers.gen_plan` (layers.py:260-337) lives in a Gluon subclass (mxnet absent): take the
+    method's FunctionDef out of the class body and execute it, unmodified, as a plain function of a stub `self`.
+    Its debugging `print(...); ch = input()` (layers.py:319-320) is silenced by shadowing the two builtins."""
+    with open(REF_LAYERS) as f:
+        tree = ast.parse(f.read(), REF_LAYERS)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "StackedHeterGCNLayers"][0]
+    fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "gen_plan"][0]
+    ns = {"np": np, "unordered_unique": graph_ns["unordered_unique"], "merge_nodes": graph_ns["merge_nodes"],
+          "print": lambda *a, **k: None, "input": lambda *a: ""}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), REF_LAYERS, "exec"), ns)
+    return ns["gen_plan"]
+
+
+class _StubStack(object):
+    """What gen_plan touches of `self`: len(self) and self[depth].aggregators[(src, dst)].use_multi_link."""
+
+    class _Agg(object):
+        use_multi_link = True
+
+    class _Layer(object):
+        def __init__(self, keys):
+            self.aggregators = {k: _StubStack._Agg() for k in keys}
+
+    def __init__(self, depth, keys):
+        self._layers = [self._Layer(keys) for _ in range(depth)]
+
+    def __len__(self):
+        return len(self._layers)
+
+    def __getitem__(self, i):
+        return self._layers[i]
+
+
+def make_inputs(seed, n_user, n_item, nnz, levels):
+    """Seeded duplicate-free bipartite rating graph in CSR order (node ids = 0..n-1, as the reference's samplers index
+    their noise arrays with them, iterators.py:338-346)."""
+    rng = np.random.default_rng(seed)
+    cells = rng.choice(n_user * n_item, nnz, replace=False)
+    cells.sort()                                    # CSR order: rows, then columns (scipy tocsr order)
+    ru, ci = (cells // n_item).astype(np.int32), (cells % n_item).astype(np.int32)
+    vals = np.asarray(levels, np.float32)[rng.integers(0, len(levels), nnz)]
+    ind_ptr = np.concatenate([[0], np.cumsum(np.bincount(ru, minlength=n_user))]).astype(np.int32)
+    return ru, ci, vals, ind_ptr
+
+
+def main():
+    ref, ref_it = load_reference()
+    out = {}
+
+    # ---- node merging (graph.py:142-219) -------------------------------------------------------------------------
+    rng = np.random.default_rng(7)
+    a, b, c = (rng.integers(0, 40, n).astype(np.int32) for n in (25, 1, 60))
+    uniq, idx = ref["merge_nodes"]([a, b, c])
+    out.update(mn_a=a, mn_b=b, mn_c=c, mn_uniq=uniq, mn_idx0=idx[0], mn_idx1=idx[1], mn_idx2=idx[2])
+    uniq1, idx1 = ref["merge_nodes"](c)
+    out.update(mn1_uniq=uniq1, mn1_idx=idx1)
+    pair = rng.integers(0, 30, (3, 12)).astype(np.int32)        # (1 + K, n): src row, K dst rows
+    d0, d1 = {"user": a, ("user", "movie"): pair}, {"movie": c[:20]}
+    ud, nl = ref["merge_node_ids_dict"]([d0, d1])
+    out.update(md_pair=pair, md_u_user=ud["user"], md_u_movie=ud["movie"], md_0_user=nl[0]["user"],
+               md_0_pair=nl[0][("user", "movie")], md_1_movie=nl[1]["movie"])
+    ez = ref["empty_as_zero"]([np.zeros(0, np.float32), np.array([2.5, 1.0])], np.float32)
+    out.update(ez0=ez[0], ez1=ez[1])
+
+    # ---- CSRMat / HeterGraph glue on a rating graph ---------------------------------------------------------------
+    levels = [0.5, 1.0, 2.0, 3.5, 5.0]
+    n_user, n_item, nnz = 30, 22, 260
+    ru, ci, vals, ind_ptr = make_inputs(11, n_user, n_item, nnz, levels)
+    user_ids = np.arange(n_user, dtype=np.int32)       # HeterGraph needs ids usable as feature row indices
+    item_ids = np.arange(n_item, dtype=np.int32)
+    out.update(g_ru=ru, g_ci=ci, g_vals=vals, g_ind_ptr=ind_ptr, g_levels=np.asarray(levels, np.float32))
+    CSRMat, HeterGraph = ref["CSRMat"], ref["HeterGraph"]
+    mat = CSRMat(ci, ind_ptr, user_ids, item_ids, values=vals, multi_link=levels)
+    graph = HeterGraph({"user": np.zeros((n_user, 1), np.float32), "movie": np.zeros((n_item, 1), np.float32)},
+                       {"user": user_ids, "movie": item_ids}, {("user", "movie"): mat})
+
+    def dump_csr(prefix, m):
+        out.update({prefix + "ep": m.end_points, prefix + "ip": m.ind_ptr, prefix + "val": m.values,
+                    prefix + "rdeg": m.row_degrees.astype(np.int32), prefix + "cdeg": m.col_degrees.astype(np.int32),
+                    prefix + "sup_symm": m.get_support(True), prefix + "sup_row": m.get_support(False)})
+
+    dump_csr("um_", graph["user", "movie"])
+    dump_csr("mu_", graph["movie", "user"])            # = mat.T via scipy (graph.py:586-593)
+
+    def dump_neighbors(prefix, m, src_ids, symm):
+        eps, vs, ips, sps = m.sample_neighbors(src_ids=src_ids, symm=symm, use_multi_link=True, num_neighbors=-1)
+        for l in range(len(levels)):
+            out.update({"%sep%d" % (prefix, l): eps[l], "%sval%d" % (prefix, l): vs[l], "%sip%d" % (prefix, l): ips[l],
+                        "%ssup%d" % (prefix, l): sps[l]})
+        ep, v, ip, sp = m.sample_neighbors(src_ids=src_ids, symm=symm, use_multi_link=False)
+        out.update({prefix + "flat_ep": ep, prefix + "flat_val": v, prefix + "flat_ip": ip, prefix + "flat_sup": sp})
+
+    src = np.array([4, 0, 17, 4, 29], np.int32)
+    out["nb_src"] = src
+    dump_neighbors("nb_all_um_", graph["user", "movie"], None, True)
+    dump_neighbors("nb_all_mu_", graph["movie", "user"], None, True)
+    dump_neighbors("nb_sub_um_", graph["user", "movie"], src, True)
+    dump_neighbors("nb_sub_um_row_", graph["user", "movie"], src, False)
+
+    # batch edge removal in both directions (graph.py:952-974) and value fetch (:920-934)
+    sel = rng.choice(nnz, 40, replace=False)
+    pairs = np.stack([user_ids[ru[sel]], item_ids[ci[sel]]]).astype(np.int32)
+    out["rm_pairs"] = pairs
+    out["fetch_vals"] = graph.fetch_edges_by_id("user", "movie", pairs)
+    g2 = graph.remove_edges_by_id("user", "movie", pairs)
+    dump_csr("rm_um_", g2["user", "movie"])
+    dump_csr("rm_mu_", g2["movie", "user"])
+    dump_neighbors("rm_nb_um_", g2["user", "movie"], None, True)
+    out["um_pair_ids"] = graph["user", "movie"].node_pair_ids
+
+    # ---- gen_plan: the 2-layer top-down plan with re-indexing (layers.py:260-337) ----------------------------------
+    gen_plan = load_reference_gen_plan(ref)
+    keys = [("user", "movie"), ("movie", "user")]
+    sel = {"user": np.array([3, 9, 3, 28, 0, 9], np.int32), "movie": np.array([5, 5, 1, 20], np.int32)}
+    out.update(gp_sel_user=sel["user"], gp_sel_movie=sel["movie"])
+    req, plan = gen_plan(_StubStack(2, keys), g2, sel, {k: -1 for k in keys}, True)
+    for key in ("user", "movie"):
+        out["gp_req_" + key] = req[key]
+    for depth in range(2):
+        prev_ids, agg_args = plan[depth]
+        for key in ("user", "movie"):
+            out["gp%d_prev_%s" % (depth, key)] = prev_ids[key]
+            base_inds, sel_idx, info = agg_args[key]
+            out["gp%d_base_%s" % (depth, key)] = base_inds
+            if sel_idx is not None:
+                out["gp%d_selidx_%s" % (depth, key)] = sel_idx
+            for dst_key, (eps, vals_l, ips, sps) in info.items():
+                for l in range(len(levels)):
+                    out["gp%d_%s_%s_ep%d" % (depth, key, dst_key, l)] = eps[l]
+                    out["gp%d_%s_%s_ip%d" % (depth, key, dst_key, l)] = ips[l]
+                    out["gp%d_%s_%s_sup%d" % (depth, key, dst_key, l)] = sps[l]
+
+    # ---- DataIterator: splits + the samplers' RNG call sequence (iterators.py:120-236, 264-370) -------------------
+    test_pairs, valid_pairs = pairs[:, :15], pairs[:, 15:]
+    it = ref_it["DataIterator"](graph, "user", "movie", test_node_pairs=test_pairs, valid_node_pairs=valid_pairs,
+                                embed_P_mask=0.3, embed_p_zero=0.5, embed_p_self=0.5, seed=123)
+    out.update(it_train_pairs=it._train_node_pairs, it_train_ratings=it._train_ratings,
+               it_valid_ratings=it._valid_ratings, it_test_ratings=it._test_ratings,
+               it_eval_noise_user=it.evaluate_embed_noise_dict["user"],
+               it_eval_noise_movie=it.evaluate_embed_noise_dict["movie"])
+    rs = it.rating_sampler(batch_size=32, segment="train")
+    for k in range(3):
+        p, r = next(rs)
+        out.update({"it_rs%d_pairs" % k: p, "it_rs%d_ratings" % k: r})
+    ns = it.recon_nodes_sampler(batch_size=4)
+    for k in range(3):
+        noise, batch, allr = next(ns)
+        for key in ("user", "movie"):
+            out.update({"it_ns%d_noise_%s" % (k, key): noise[key], "it_ns%d_batch_%s" % (k, key): batch[key],
+                        "it_ns%d_all_%s" % (k, key): allr[key]})
+    vs = list(it.rating_sampler(batch_size=10, segment="valid"))
+    out["it_valid_batches"] = np.array([p.shape[1] for p, _ in vs], np.int32)
+
+    np.savez_compressed(OUT, **{k: np.asarray(v) for k, v in out.items()})
+    print("wrote %s: %d arrays, %d bytes" % (OUT, len(out), os.path.getsize(OUT)))
+
+
+if __name__ == "__main__":
+    main()

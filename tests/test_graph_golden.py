@@ -1,0 +1,162 @@
+"""Host-side plan construction vs golden vectors produced by the REFERENCE's own Python graph layer
+(tests/golden/make_graph_golden.py executes reference mxgraph/graph.py + iterators.py from where they lie): id<->index
+mapping, CSR transpose, both-direction edge removal, per-level neighbour lists, node merging / re-indexing and the
+samplers' RNG call sequence.  Integer arrays bit-exact; float32 support within one ulp-class (the reference builds its
+core with -ffast-math)."""
+import os
+
+import numpy as np
+import pytest
+
+from star_gcn_amd.mxgraph import graph as G
+from star_gcn_amd.mxgraph.iterators import DataIterator
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graph_glue_golden.npz"))
+U, I = "user", "movie"
+
+
+def eq(name, got):
+    want = GOLD[name]
+    got = np.asarray(got)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    if want.dtype.kind == "f":
+        np.testing.assert_allclose(got, want, rtol=3e-7, atol=0, err_msg=name)
+    else:
+        assert np.array_equal(got, want), name
+
+
+def build():
+    n_user, n_item = GOLD["g_ind_ptr"].size - 1, int(GOLD["um_cdeg"].size)
+    mat = G.CSRMat(GOLD["g_ci"], GOLD["g_ind_ptr"], np.arange(n_user, dtype=np.int32), np.arange(n_item, dtype=np.int32),
+                   GOLD["g_vals"], GOLD["g_levels"])
+    return G.HeterGraph({U: np.arange(n_user, dtype=np.int32), I: np.arange(n_item, dtype=np.int32)}, {(U, I): mat})
+
+
+def check_csr(prefix, m):
+    eq(prefix + "ep", m.end_points)
+    eq(prefix + "ip", m.ind_ptr)
+    eq(prefix + "val", m.values)
+    eq(prefix + "rdeg", m.row_degrees)
+    eq(prefix + "cdeg", m.col_degrees)
+    eq(prefix + "sup_symm", m.get_support(True))
+    eq(prefix + "sup_row", m.get_support(False))
+
+
+def check_neighbors(prefix, m, src, symm):
+    eps, vs, ips, sps = m.sample_neighbors(src_ids=src, symm=symm, use_multi_link=True, num_neighbors=-1)
+    for l in range(GOLD["g_levels"].size):
+        eq("%sep%d" % (prefix, l), eps[l])
+        eq("%sval%d" % (prefix, l), vs[l])
+        eq("%sip%d" % (prefix, l), ips[l])
+        eq("%ssup%d" % (prefix, l), sps[l])
+    ep, v, ip, sp = m.sample_neighbors(src_ids=src, symm=symm, use_multi_link=False)
+    eq(prefix + "flat_ep", ep)
+    eq(prefix + "flat_val", v)
+    eq(prefix + "flat_ip", ip)
+    eq(prefix + "flat_sup", sp)
+
+
+def test_merge_nodes_and_dicts_match_reference():
+    a, b, c = GOLD["mn_a"], GOLD["mn_b"], GOLD["mn_c"]
+    uniq, idx = G.merge_nodes([a, b, c])
+    eq("mn_uniq", uniq)
+    for k in range(3):
+        eq("mn_idx%d" % k, idx[k])
+    uniq1, idx1 = G.merge_nodes(c)
+    eq("mn1_uniq", uniq1)
+    eq("mn1_idx", idx1)
+    ud, nl = G.merge_node_ids_dict([{U: a, (U, I): GOLD["md_pair"]}, {I: c[:20]}])
+    eq("md_u_user", ud[U])
+    eq("md_u_movie", ud[I])
+    eq("md_0_user", nl[0][U])
+    eq("md_0_pair", nl[0][(U, I)])
+    eq("md_1_movie", nl[1][I])
+    ez = G.empty_as_zero([np.zeros(0, np.float32), np.array([2.5, 1.0])], np.float32)
+    eq("ez0", ez[0])
+    eq("ez1", ez[1])
+
+
+def test_csr_transpose_support_and_neighbor_lists_match_reference():
+    g = build()
+    check_csr("um_", g[U, I])
+    check_csr("mu_", g[I, U])
+    eq("um_pair_ids", g[U, I].node_pair_ids)
+    src = GOLD["nb_src"]
+    check_neighbors("nb_all_um_", g[U, I], None, True)
+    check_neighbors("nb_all_mu_", g[I, U], None, True)
+    check_neighbors("nb_sub_um_", g[U, I], src, True)
+    check_neighbors("nb_sub_um_row_", g[U, I], src, False)
+
+
+def test_edge_removal_and_fetch_match_reference():
+    g = build()
+    pairs = GOLD["rm_pairs"]
+    eq("fetch_vals", g.fetch_edges_by_id(U, I, pairs))
+    g2 = g.remove_edges_by_id(U, I, pairs)
+    check_csr("rm_um_", g2[U, I])
+    check_csr("rm_mu_", g2[I, U])
+    check_neighbors("rm_nb_um_", g2[U, I], None, True)
+
+
+def test_data_iterator_splits_and_rng_sequence_match_reference():
+    g = build()
+    pairs = GOLD["rm_pairs"]
+    it = DataIterator(g, U, I, test_node_pairs=pairs[:, :15], valid_node_pairs=pairs[:, 15:], embed_P_mask=0.3,
+                      embed_p_zero=0.5, embed_p_self=0.5, seed=123)
+    eq("it_train_pairs", it._train_node_pairs)
+    eq("it_train_ratings", it._train_ratings)
+    eq("it_valid_ratings", it._valid_ratings)
+    eq("it_test_ratings", it._test_ratings)
+    eq("it_eval_noise_user", it.evaluate_embed_noise_dict[U])
+    eq("it_eval_noise_movie", it.evaluate_embed_noise_dict[I])
+    rs = it.rating_sampler(batch_size=32, segment="train")
+    for k in range(3):
+        p, r = next(rs)
+        eq("it_rs%d_pairs" % k, p)
+        eq("it_rs%d_ratings" % k, r)
+    ns = it.recon_nodes_sampler(batch_size=4)
+    for k in range(3):
+        noise, batch, allr = next(ns)
+        for key in (U, I):
+            eq("it_ns%d_noise_%s" % (k, key), noise[key])
+            eq("it_ns%d_batch_%s" % (k, key), batch[key])
+            eq("it_ns%d_all_%s" % (k, key), allr[key])
+    sizes = [p.shape[1] for p, _ in it.rating_sampler(batch_size=10, segment="valid")]
+    eq("it_valid_batches", np.array(sizes, np.int32))
+
+
+def test_gen_plan_matches_reference_gen_plan():
+    """The 2-layer top-down plan (unique of the selected ids, per-level neighbour lists, merge + re-indexing against the
+    previous level's unique node list) vs the reference's own `StackedHeterGCNLayers.gen_plan` (layers.py:260-337,
+    executed by make_graph_golden.py) on the graph with the batch edges removed.  The fused MultiLinkPlan is unpacked
+    back into the reference's per-level lists for the comparison."""
+    from star_gcn_amd.mxgraph.layers import HeterGCNLayer, StackedHeterGCNLayers
+    g = build().remove_edges_by_id(U, I, GOLD["rm_pairs"])
+    enc = StackedHeterGCNLayers()
+    for _ in range(2):
+        enc.add(HeterGCNLayer(g.meta_graph, g.get_multi_link_structure(), 10, 8, agg_accum="sum"))
+    sel = {U: GOLD["gp_sel_user"], I: GOLD["gp_sel_movie"]}
+    req, plan = enc.gen_plan(g, sel, {(U, I): -1, (I, U): -1}, True, device="cpu")
+    R = GOLD["g_levels"].size
+    for key in (U, I):
+        eq("gp_req_" + key, req[key])
+    for depth in range(2):
+        prev_ids, agg_args = plan[depth]
+        for key in (U, I):
+            eq("gp%d_prev_%s" % (depth, key), prev_ids[key])
+            base_take, sel_take, plans = agg_args[key]
+            eq("gp%d_base_%s" % (depth, key), base_take.ids.numpy())
+            if depth == 1:
+                eq("gp%d_selidx_%s" % (depth, key), sel_take.ids.numpy())
+            else:
+                assert sel_take is None
+            for dst_key, mp in plans.items():
+                c_indptr, c_idx, c_w = mp.c_indptr.numpy(), mp.c_idx.numpy(), mp.c_w.numpy()
+                for l in range(R):
+                    starts, ends = c_indptr[l:-1:R], c_indptr[l + 1::R]
+                    lens = ends - starts
+                    ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+                    pos = np.concatenate([np.arange(a, b) for a, b in zip(starts, ends)] + [np.zeros(0, np.int64)]).astype(np.int64)
+                    eq("gp%d_%s_%s_ip%d" % (depth, key, dst_key, l), ip)
+                    eq("gp%d_%s_%s_ep%d" % (depth, key, dst_key, l), c_idx[pos])
+                    eq("gp%d_%s_%s_sup%d" % (depth, key, dst_key, l), c_w[pos])
