@@ -5,7 +5,10 @@ per-batch removal of the batch's rating edges from the aggregation graph (both d
 graph.py:952-974), 2-block network with decoder, the two losses, Adam + global-norm clipping, RMSE on held-out
 ratings.  Data: a MovieLens-shaped synthetic graph (no dataset files in this environment).
 
-  python examples/train_star_gcn.py --shape ml-100k --iters 200
+  python examples/train_star_gcn.py --shape ml-100k --iters 200 [--resident]
+
+--resident keeps the plan of the whole training graph in HBM and removes each batch's edges ON THE DEVICE
+(star_gcn_amd/resident.py, sg_mask_edges_hip) instead of rebuilding CSRs + plan on the host every iteration.
 """
 import argparse
 import os
@@ -43,6 +46,8 @@ def main():
     ap.add_argument("--embed", type=int, default=32)
     ap.add_argument("--lr", type=float, default=0.002)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--resident", action="store_true")
+    ap.add_argument("--eval-every", type=int, default=20)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(args.seed)
@@ -63,13 +68,24 @@ def main():
     rating_it = it.rating_sampler(args.batch, "train")
     recon_it = it.recon_nodes_sampler(1000000)
     opt = None
+    resident = None
+    if args.resident:
+        from star_gcn_amd.resident import ResidentPlan
+        resident = ResidentPlan(net, it.train_graph, device=dev)
     t0 = time.time()
+    t_train = 0.0
     for step in range(1, args.iters + 1):
+        torch.cuda.synchronize()
+        t_it = time.perf_counter()
         pairs, ratings = next(rating_it)
         noise, recon_ids, _ = next(recon_it)
-        g = it.train_graph.remove_edges_by_id(U, I, pairs)            # never aggregate over the edges being predicted
-        preds, recons, gt = net(g, rating_node_pairs=pairs, embed_noise_dict=noise, recon_node_ids_dict=recon_ids,
-                                device=dev)
+        if resident is not None:    # never aggregate over the edges being predicted: masked on the device
+            preds, recons, gt = net.run(resident.set_batch(rating_node_pairs=pairs, embed_noise_dict=noise,
+                                                           recon_node_ids_dict=recon_ids))
+        else:                       # reference-style: new CSRs, new plan, new uploads every iteration
+            g = it.train_graph.remove_edges_by_id(U, I, pairs)
+            preds, recons, gt = net(g, rating_node_pairs=pairs, embed_noise_dict=noise, recon_node_ids_dict=recon_ids,
+                                    device=dev)
         y = torch.from_numpy(((ratings - mean) / std).astype(np.float32)).to(dev)
         loss = M.star_gcn_loss(preds, recons, gt, y, recon_lambda=0.1)
         if opt is None:   # parameters are created lazily on the first forward
@@ -78,11 +94,16 @@ def main():
         loss.backward()
         torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
         opt.step()
-        if step % 20 == 0 or step == 1:
+        torch.cuda.synchronize()
+        if step > 3:
+            t_train += time.perf_counter() - t_it
+        if step % args.eval_every == 0 or step == 1:
             net.eval()
             rmse = evaluate(net, it, it.val_graph, "valid", mean, std, dev, lo, hi)
             net.train()
             print("iter %4d  loss %.4f  valid RMSE %.4f  (%.1f s)" % (step, float(loss.detach()), rmse, time.time() - t0))
+    print("training iterations: %.2f ms/iter (%s planning, batch %d, after 3 warm-up iterations)" %
+          (1e3 * t_train / max(args.iters - 3, 1), "resident/device" if resident is not None else "host re-", args.batch))
     net.eval()
     print("test RMSE %.4f" % evaluate(net, it, it.test_graph, "test", mean, std, dev, lo, hi))
 

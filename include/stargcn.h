@@ -270,6 +270,25 @@ int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* const* db
                              int accum, int act, float slope, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (9) per-batch edge removal on the device.  Reference: HeterGraph.remove_edges_by_id in both
+ *     directions (graph.py:952-974 -> graph_sampler.cpp:154-201), then fresh degrees + support (graph.py:401-429), a
+ *     new plan (layers.py:260-337) and new uploads (layers.py:366-377) on EVERY training iteration.
+ *     Here the full-graph plan stays resident and only its weights are rewritten: for every edge e of the graph
+ *         w(e) = removed(e) ? 0 : support(d_row'(e), d_col'(e))        d' = degrees after the removal
+ *     is stored at w_out[o][pos[o][e]] for each of the n_out weight arrays (c_w / t_w of the resident plans; pos[o] maps
+ *     the edge id to its slot in that array).  support = sqrt(1/d_row/d_col) | 1/d_row for transposed[o] = 0 and sqrt(1/d_col/d_row) | 1/d_col for
+ *     transposed[o] = 1 (symm | not): the expression sg_get_support_cpu evaluates for that matrix, bit-identical.  Edge ids: position in
+ *     the (edge_row, edge_col) COO; ids outside [0, nnz) are ignored, duplicates count once.  n_rm = 0 restores the
+ *     full graph.  w_out / pos / transposed are HOST arrays (of device pointers / ints).
+ * ---------------------------------------------------------------------------------------------- */
+#define SG_MAX_MASK_OUT 16
+size_t sg_mask_edges_workspace_bytes(int64_t n_rows, int64_t n_cols, int64_t nnz);
+int sg_mask_edges_hip(float* const* w_out, const int32_t* const* pos, const int32_t* transposed, int32_t n_out,
+                      const int32_t* edge_row, const int32_t* edge_col, const int32_t* row_degrees,
+                      const int32_t* col_degrees, const int32_t* rm_edges, int64_t n_rm, int64_t n_rows,
+                      int64_t n_cols, int64_t nnz, int symm, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

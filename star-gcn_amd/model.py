@@ -150,15 +150,17 @@ class Net(nn.Module):
 
     # ---- host-side planning (reference STAR-GCN.py:373-397) -------------------------------------------
     def make_plan(self, graph, rating_node_pairs=None, embed_noise_dict=None, recon_node_ids_dict=None,
-                  graph_sampler_args=None, symm=None, device="cuda"):
+                  graph_sampler_args=None, symm=None, device="cuda", full_node_ids=None):
+        """full_node_ids {key: ids}: node types whose EVERY node is computed, in this order, at every block and depth
+        (replicated types of a node-partitioned run; all types for a resident full-graph plan, star_gcn_amd.resident)."""
         symm = self._norm_symm if symm is None else symm
-        if rating_node_pairs is None and recon_node_ids_dict is None:
+        if rating_node_pairs is None and recon_node_ids_dict is None and full_node_ids is None:
             raise NotImplementedError
         nb = self._nblocks
         plan = dict(enc=[None] * nb, idx=[None] * nb, device=torch.device(device))
         req = dict()
-        full = None
-        if self.pair_partition is not None:   # replicated node types: every node, same order, on every rank
+        full = full_node_ids
+        if full is None and self.pair_partition is not None:   # replicated node types: every node, same order, on every rank
             full = {k: graph.node_ids_dict[k] for k in graph.meta_graph if k in self.pair_partition.replicated_keys}
         for b in range(nb - 1, -1, -1):
             parts, names = [], []

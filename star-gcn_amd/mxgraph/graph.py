@@ -202,6 +202,16 @@ class CSRMat(object):
             raise ValueError("fetch_edges_by_id: some node pairs are not edges of this matrix")
         return self.values[pos]
 
+    def edge_positions(self, node_pair_ids):
+        """Position in CSR order (= edge id) of every (row id, col id) pair; -1 where the pair is not an edge."""
+        r = self.row_id_to_ind(node_pair_ids[0]).astype(np.int64)
+        c = self.col_id_to_ind(node_pair_ids[1]).astype(np.int64)
+        key = self.edge_row_indices.astype(np.int64) * self.shape[1] + self.end_points
+        want = r * self.shape[1] + c
+        pos = np.minimum(np.searchsorted(key, want), max(key.size - 1, 0))
+        hit = (key[pos] == want) if key.size else np.zeros(want.shape, bool)
+        return np.where(hit, pos, -1).astype(np.int32)
+
     def row_id_to_ind(self, ids):
         return self._row_map[ids]
 

@@ -132,3 +132,6 @@ class LayerDictionary(nn.Module):
 
     def items(self):
         return ((k, self._layers[i]) for k, i in self._key2idx.items())
+
+    def values(self):
+        return (self._layers[i] for i in self._key2idx.values())

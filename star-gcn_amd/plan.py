@@ -125,6 +125,13 @@ class MultiLinkPlan(object):
             self._struct = st
         return self._struct
 
+    def refresh_rowsum(self):
+        """Recompute `rowsum` IN PLACE after the weights were rewritten (resident edge masking); the tensor -- and
+        the pointer inside the cached C struct -- stays the same."""
+        if self._rowsum is not None and self.nnz > 0:
+            from . import ops
+            ops.seg_sum(self.c_w.view(1, -1), self.c_indptr, out=self._rowsum.view(1, -1))
+
     @property
     def rowsum(self):
         """(n_dst, R): sum of the support over each (node, level) segment -- the factor that scales the level bias

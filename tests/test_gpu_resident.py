@@ -1,0 +1,131 @@
+"""Device-side per-batch edge removal on a resident full-graph plan (star_gcn_amd/resident.py,
+sg_mask_edges_hip) vs the reference-style host path: remove_edges_by_id in both directions -> fresh degrees / support
+-> gen_plan -> upload (reference graph.py:952-974, layers.py:260-337)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+U, I = "user", "movie"
+
+
+def dense_levels(mp):
+    """(n_dst*R, n_src) float64 matrix of a MultiLinkPlan's forward CSR and of its transpose."""
+    R = mp.R
+    c_indptr, c_idx, c_w = mp.c_indptr.cpu().numpy(), mp.c_idx.cpu().numpy(), mp.c_w.cpu().numpy()
+    t_indptr, t_idx, t_w = mp.t_indptr.cpu().numpy(), mp.t_idx.cpu().numpy(), mp.t_w.cpu().numpy()
+    A = np.zeros((mp.n_dst * R, mp.n_src), np.float32)
+    rows = np.repeat(np.arange(mp.n_dst * R), np.diff(c_indptr))
+    A[rows, c_idx[:rows.size]] = c_w[:rows.size]
+    B = np.zeros_like(A)
+    seg = np.repeat(np.arange(mp.n_src * R), np.diff(t_indptr))
+    B[t_idx[:seg.size] * R + seg % R, seg // R] = t_w[:seg.size]
+    return A, B
+
+
+def make(symm=True, accum="sum", nblocks=2):
+    import star_gcn_amd.model as M
+    import star_gcn_amd.synthetic as S
+    graph, eu, ei, vals = S.make_graph("custom", seed=31, n_user=80, n_item=50, n_edges=1100, n_levels=5)
+    torch.manual_seed(5)
+    net = M.Net(graph, U, I, embed_units=24, agg_units=(40,), out_units=(30,), nblocks=nblocks, use_dae=True,
+                agg_accum=accum, norm_symm=symm).cuda()
+    return net, graph, eu, ei, vals
+
+
+@pytest.mark.parametrize("symm", [True, False])
+def test_masked_weights_equal_host_edge_removal_bit_exactly(symm):
+    from star_gcn_amd.resident import ResidentPlan
+    net, graph, eu, ei, vals = make(symm=symm)
+    res = ResidentPlan(net, graph, symm=symm)
+    before = [(w.clone()) for w in res._w_arrays]
+    rng = np.random.default_rng(0)
+    sel = rng.choice(eu.size, 200, replace=False)
+    # one user loses ALL its ratings (degree 0 -> support 0), ids repeat, and -1 / out-of-range ids are ignored
+    all_of_user = np.nonzero(eu == eu[sel[0]])[0]
+    pairs = np.stack([np.concatenate([eu[sel], eu[all_of_user]]), np.concatenate([ei[sel], ei[all_of_user]])])
+    ids = graph[U, I].edge_positions(pairs)
+    assert np.all(ids >= 0)
+    res.mask_edges(np.concatenate([ids, ids[:7], [-1, 10 ** 6]]))
+    # host path: new graph, new plan
+    g2 = graph.remove_edges_by_id(U, I, pairs)
+    full = {k: g2.node_ids_dict[k] for k in g2.meta_graph}
+    host = net.make_plan(g2, symm=symm, device="cuda", full_node_ids=full)
+    for b in range(2):
+        for depth in range(len(host["enc"][b])):
+            for key in (U, I):
+                for src, hp in host["enc"][b][depth][1][key][2].items():
+                    rp = res.plan["enc"][b][depth][1][key][2][src]
+                    Ah, Bh = dense_levels(hp)
+                    Ar, Br = dense_levels(rp)
+                    assert np.array_equal(Ah, Ar) and np.array_equal(Bh, Br), (b, depth, key)
+                    assert np.array_equal(Ah, Bh)
+                    assert torch.equal(rp.rowsum, hp.rowsum) or torch.allclose(rp.rowsum, hp.rowsum, rtol=1e-6, atol=0)
+    # restoring the full graph reproduces the original weights bit for bit
+    res.mask_edges(np.zeros(0, np.int32))
+    for w0, w in zip(before, res._w_arrays):
+        assert torch.equal(w0, w)
+
+
+@pytest.mark.parametrize("accum,order", [("sum", "auto"), ("stack", "aggregate_first")])
+def test_training_step_on_resident_plan_matches_replanned_step(accum, order):
+    import star_gcn_amd.model as M
+    from star_gcn_amd.resident import ResidentPlan
+    net, graph, eu, ei, vals = make(accum=accum)
+    for enc in net.encoders:
+        for layer in enc._blocks:
+            for agg in layer.aggregators.values():
+                agg._order = order
+    rng = np.random.default_rng(2)
+    noise, recon = {}, {}
+    for key, n in ((U, 80), (I, 50)):
+        perm = rng.permutation(n).astype(np.int32)
+        k = int(np.ceil(0.2 * n))
+        recon[key] = perm[:k]
+        nz = np.arange(n, dtype=np.int32)
+        nz[perm[:k // 2]] = -1
+        noise[key] = nz
+    sel = rng.choice(eu.size, 256, replace=False)
+    pairs = np.stack([eu[sel], ei[sel]])
+    y = torch.from_numpy(((vals[sel] - vals.mean()) / vals.std()).astype(np.float32)).cuda()
+
+    def grads():
+        return {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    # reference-style iteration: remove the batch's edges on the host, re-plan, upload
+    net.zero_grad(set_to_none=True)
+    g2 = graph.remove_edges_by_id(U, I, pairs)
+    preds, recons, gt = net(g2, rating_node_pairs=pairs, embed_noise_dict=noise, recon_node_ids_dict=recon, device="cuda")
+    loss = M.star_gcn_loss(preds, recons, gt, y, recon_lambda=0.1)
+    loss.backward()
+    want = grads()
+    # resident iteration: weights masked on the device, heads re-indexed
+    net.zero_grad(set_to_none=True)
+    res = ResidentPlan(net, graph)
+    plan = res.set_batch(rating_node_pairs=pairs, embed_noise_dict=noise, recon_node_ids_dict=recon)
+    preds2, recons2, gt2 = net.run(plan)
+    loss2 = M.star_gcn_loss(preds2, recons2, gt2, y, recon_lambda=0.1)
+    loss2.backward()
+    got = grads()
+
+    def close(a, b, what, tol=2e-6):
+        a, b = a.detach(), b.detach()
+        scale = max(float(b.abs().max()), 1e-3)
+        assert float((a - b).abs().max()) <= tol * scale, (what, float((a - b).abs().max()), scale)
+
+    for b in range(2):
+        close(preds2[b], preds[b], "pred %d" % b)
+        for key in (U, I):
+            close(recons2[b][key], recons[b][key], "recon %d %s" % (b, key))
+            close(gt2[key], gt[key], "gt " + key, tol=0.0 + 1e-12)
+    close(loss2, loss, "loss")
+    assert set(got) == set(want)
+    for n in want:
+        close(got[n], want[n], "grad " + n, tol=1e-5)
+    # a second batch on the same resident plan (different removal set) still matches a fresh host plan
+    sel = rng.choice(eu.size, 100, replace=False)
+    pairs = np.stack([eu[sel], ei[sel]])
+    with torch.no_grad():
+        p_host, _, _ = net(graph.remove_edges_by_id(U, I, pairs), rating_node_pairs=pairs, device="cuda")
+        p_res, _, _ = net.run(res.set_batch(rating_node_pairs=pairs, edge_ids=graph[U, I].edge_positions(pairs)))
+    close(p_res[1], p_host[1], "second batch")
