@@ -65,7 +65,7 @@ def main():
     lo, hi = float(it.possible_rating_values.min()), float(it.possible_rating_values.max())
     net = M.Net(graph, U, I, embed_units=args.embed, agg_units=(250,), out_units=(75,), nblocks=2, use_dae=True,
                 dropout=0.5, agg_accum="sum").to(dev)
-    rating_it = it.rating_sampler(args.batch, "train")
+    rating_it = it.rating_sampler(args.batch, "train", return_index=args.resident)
     recon_it = it.recon_nodes_sampler(1000000)
     opt = None
     resident = None
@@ -77,11 +77,12 @@ def main():
     for step in range(1, args.iters + 1):
         torch.cuda.synchronize()
         t_it = time.perf_counter()
-        pairs, ratings = next(rating_it)
+        batch = next(rating_it)
+        pairs, ratings = batch[0], batch[1]
         noise, recon_ids, _ = next(recon_it)
         if resident is not None:    # never aggregate over the edges being predicted: masked on the device
-            preds, recons, gt = net.run(resident.set_batch(rating_node_pairs=pairs, embed_noise_dict=noise,
-                                                           recon_node_ids_dict=recon_ids))
+            preds, recons, gt = net.run(resident.set_batch(rating_node_pairs=pairs, edge_ids=batch[2],
+                                                           embed_noise_dict=noise, recon_node_ids_dict=recon_ids))
         else:                       # reference-style: new CSRs, new plan, new uploads every iteration
             g = it.train_graph.remove_edges_by_id(U, I, pairs)
             preds, recons, gt = net(g, rating_node_pairs=pairs, embed_noise_dict=noise, recon_node_ids_dict=recon_ids,

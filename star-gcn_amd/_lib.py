@@ -70,6 +70,9 @@ _SIGS = {
     "sg_remove_edges_cpu": (_INT, [_P] * 7 + [_I64, _P, _P, _I64]),
     "sg_sample_fix_neighbor_cpu": (_INT, [_P] * 4 + [_I64, _I64, _c.c_uint64]),
     "sg_gen_row_indices_cpu": (_INT, [_P, _P, _I64, _I64]),
+    "sg_edge_positions_cpu": (_INT, [_P] * 3 + [_I64, _P, _P, _I64]),
+    "sg_pair_plan_cpu": (_INT, [_P] * 10 + [_I64] * 3),
+    "sg_take_plan_cpu": (_INT, [_P] * 6 + [_I64] * 2),
     "sg_mask_edges_workspace_bytes": (_SZ, [_I64] * 3),
     "sg_mask_edges_hip": (_INT, [_P, _P, _P, _c.c_int32] + [_P] * 5 + [_I64] * 4 + [_INT, _P, _SZ, _P]),
     "sg_multilink_agg_resolve_order": (_INT, [_P, _INT]),

@@ -23,26 +23,43 @@ from .mxgraph.layers import (Dense, HeterGCNLayer, InnerProductLayer, LayerDicti
 from .plan import TakePlan, TransposePlan
 
 
+class _PairTranspose(object):
+    """t_indptr / t_pos / t_seg of a PairPlan, in the shape ops.seg_weighted_pool_bwd_data expects."""
+    __slots__ = ("t_indptr", "t_pos", "t_seg", "seg_num", "nnz", "total_ind_num", "covered")
+
+
 class PairPlan(object):
     """(user, item) row-index pairs grouped by user into a CSR so the per-pair inner product of the rating head is
-    ONE `seg_take_k_corr` launch (and its gradients two gather launches) instead of two (#pairs, width) takes."""
+    ONE `seg_take_k_corr` launch (and its gradients two gather launches) instead of two (#pairs, width) takes.
+    Built by native code (sg_pair_plan_cpu: two counting sorts), uploaded with one copy."""
 
     def __init__(self, user_idx, item_idx, n_user, n_item, device):
-        user_idx, item_idx = np.asarray(user_idx, np.int64), np.asarray(item_idx, np.int64)
-        order = np.argsort(user_idx, kind="stable")
-        self.identity = bool(np.all(order == np.arange(order.size)))
-        indptr = np.zeros(n_user + 1, np.int64)
-        np.cumsum(np.bincount(user_idx, minlength=n_user), out=indptr[1:])
-        self.n_user, self.n_item, self.n_pairs = int(n_user), int(n_item), int(order.size)
-        items = np.ascontiguousarray(item_idx[order], dtype=np.int32)
-        indptr = indptr.astype(np.int32)
-        self.indptr = torch.from_numpy(indptr).to(device)
-        self.items = torch.from_numpy(items if items.size else np.zeros(1, np.int32)).to(device)
-        inv = np.empty_like(order)
-        inv[order] = np.arange(order.size)
-        self.inv_order = None if self.identity else torch.from_numpy(inv).to(device)
-        self.order = None if self.identity else torch.from_numpy(order).to(device)
-        self.tplan = TransposePlan(items, indptr, n_item, device)
+        import ctypes
+        u = np.ascontiguousarray(user_idx, dtype=np.int32).reshape(-1)
+        i = np.ascontiguousarray(item_idx, dtype=np.int32).reshape(-1)
+        n = u.size
+        self.n_user, self.n_item, self.n_pairs = int(n_user), int(n_item), int(n)
+        m = max(n, 1)
+        order, inv, items, t_pos, t_seg = (np.zeros(m, np.int32) for _ in range(5))
+        indptr, t_indptr = np.empty(self.n_user + 1, np.int32), np.empty(self.n_item + 1, np.int32)
+        ident = ctypes.c_int32(0)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        L.check(L.lib().sg_pair_plan_cpu(vp(order), vp(inv), vp(indptr), vp(items), vp(t_indptr), vp(t_pos), vp(t_seg),
+                                         ctypes.byref(ident), vp(u), vp(i), n, self.n_user, self.n_item),
+                "sg_pair_plan_cpu")
+        self.identity = bool(ident.value)
+        from .plan import upload_packed
+        extra = [] if self.identity else [inv, order]
+        views = upload_packed([indptr, items, t_indptr, t_pos, t_seg] + extra, device)
+        d_indptr, d_items, d_tip, d_tpos, d_tseg = views[:5]
+        d_inv, d_order = (views[5], views[6]) if extra else (None, None)
+        self.indptr, self.items = d_indptr, d_items
+        self.inv_order = None if self.identity else d_inv
+        self.order = None if self.identity else d_order
+        tp = _PairTranspose()
+        tp.t_indptr, tp.t_pos, tp.t_seg = d_tip, d_tpos, d_tseg
+        tp.seg_num, tp.nnz, tp.total_ind_num, tp.covered = self.n_user, m, self.n_item, n
+        self.tplan = tp
 
 
 class _PairDot(torch.autograd.Function):

@@ -204,13 +204,11 @@ class CSRMat(object):
 
     def edge_positions(self, node_pair_ids):
         """Position in CSR order (= edge id) of every (row id, col id) pair; -1 where the pair is not an edge."""
-        r = self.row_id_to_ind(node_pair_ids[0]).astype(np.int64)
-        c = self.col_id_to_ind(node_pair_ids[1]).astype(np.int64)
-        key = self.edge_row_indices.astype(np.int64) * self.shape[1] + self.end_points
-        want = r * self.shape[1] + c
-        pos = np.minimum(np.searchsorted(key, want), max(key.size - 1, 0))
-        hit = (key[pos] == want) if key.size else np.zeros(want.shape, bool)
-        return np.where(hit, pos, -1).astype(np.int32)
+        r, c = _i32(self.row_id_to_ind(node_pair_ids[0])), _i32(self.col_id_to_ind(node_pair_ids[1]))
+        pos = np.empty(r.size, np.int32)
+        L.check(L.lib().sg_edge_positions_cpu(_vp(pos), _vp(self.end_points), _vp(self.ind_ptr), self.shape[0], _vp(r),
+                                              _vp(c), r.size), "sg_edge_positions_cpu")
+        return pos
 
     def row_id_to_ind(self, ids):
         return self._row_map[ids]

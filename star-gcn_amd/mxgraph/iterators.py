@@ -41,9 +41,11 @@ class DataIterator(object):
     val_graph = property(lambda self: self._val_graph)
     train_graph = property(lambda self: self._train_graph)
 
-    def rating_sampler(self, batch_size, segment='train', sequential=None):
+    def rating_sampler(self, batch_size, segment='train', sequential=None, return_index=False):
         """Yields (node_pairs (2, B), ratings (B,)).  Train: random batches without replacement within a batch,
-        forever; valid/test: sequential sweep once (reference :264-307)."""
+        forever; valid/test: sequential sweep once (reference :264-307).  return_index=True (train, random) also
+        yields the positions of the batch inside the train pairs = the edge ids (CSR positions) of
+        train_graph[user, item], which the resident plan masks on the device."""
         if segment == 'train':
             sequential = False if sequential is None else sequential
             pairs, ratings = self._train_node_pairs, self._train_ratings
@@ -63,10 +65,10 @@ class DataIterator(object):
             return
         while True:
             if batch_size == n:
-                yield pairs, ratings
+                yield (pairs, ratings, np.arange(n, dtype=np.int32)) if return_index else (pairs, ratings)
             else:
                 sel = self._rng.choice(n, batch_size, replace=False)
-                yield pairs[:, sel], ratings[sel]
+                yield (pairs[:, sel], ratings[sel], sel.astype(np.int32)) if return_index else (pairs[:, sel], ratings[sel])
 
     def recon_nodes_sampler(self, batch_size):
         """Yields (embed_noise_dict, batch_recon_node_ids_dict, all_recon_node_ids_dict) forever (reference :309-370):

@@ -145,30 +145,43 @@ class MultiLinkPlan(object):
         return self._rowsum
 
 
+def upload_packed(arrays, device):
+    """ONE host->device copy for several int32 arrays (each padded to a 16-byte multiple); returns device views.
+    A per-batch plan used to cost one ~0.2 ms pageable copy per array."""
+    sizes = [int(a.size) for a in arrays]
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 3) & ~3
+    buf = np.zeros(max(total, 1), np.int32)
+    for a, o, n in zip(arrays, offs, sizes):
+        buf[o:o + n] = a.reshape(-1)
+    dev = torch.from_numpy(buf).to(device)
+    return [dev[o:o + n] for o, n in zip(offs, sizes)]
+
+
 class TakePlan(object):
-    """Row gather `out[i] = table[ids[i]]` (ids == -1 -> zero row) with an atomic-free gradient: the transposed
-    plan groups the positions i by id, so d table[n] = sum of dout rows in segment n (gather kernel again)."""
+    """Row gather `out[i] = table[ids[i]]` (ids == -1 -> zero row) with an atomic-free gradient: when every row is
+    taken at most once (permutations, subsets) the gradient is a row copy through the inverse index `inv_ids`
+    (-1 = row not taken -> zero); otherwise the transposed plan groups the positions i by id, so
+    d table[n] = sum of dout rows in segment n (gather kernel again).  Built by native code (sg_take_plan_cpu),
+    uploaded with one copy."""
 
     def __init__(self, ids, n_rows, device):
-        ids = _np_i32(ids)
+        ids = _np_i32(ids).reshape(-1)
         n = ids.shape[0]
         self.n, self.n_rows = n, int(n_rows)
+        t_indptr = np.empty(self.n_rows + 1, np.int32)
+        t_pos = np.empty(max(n, 1), np.int32)
+        inv = np.empty(max(self.n_rows, 1), np.int32)
+        flags, covered = ctypes.c_int32(0), ctypes.c_int64(0)
+        L.check(L.lib().sg_take_plan_cpu(_vp(t_indptr), _vp(t_pos), _vp(inv), ctypes.byref(flags), ctypes.byref(covered),
+                                         _vp(ids), n, self.n_rows), "sg_take_plan_cpu")
         # identity takes (full-graph plans: unique ids are already 0..n-1 in order) cost nothing
-        self.identity = bool(n == self.n_rows and np.array_equal(ids, np.arange(n, dtype=np.int32)))
-        valid = ids >= 0
-        order = np.nonzero(valid)[0].astype(np.int32)
-        order = order[np.argsort(ids[order], kind="stable")]
-        counts = np.bincount(ids[valid], minlength=self.n_rows).astype(np.int64)
-        indptr = np.zeros(self.n_rows + 1, np.int32)
-        np.cumsum(counts, out=indptr[1:])
-        self.ids = torch.from_numpy(ids).to(device)
-        self.t_indptr = torch.from_numpy(indptr).to(device)
-        self.t_pos = torch.from_numpy(np.ascontiguousarray(order if order.size else np.zeros(1, np.int32))).to(device)
-        self.covered = int(order.size)
-        # every row taken at most once (permutations, subsets): the gradient is a row copy through the inverse
-        # index (-1 = row not taken -> zero), one fully parallel coalesced pass instead of 1-edge segments
-        self.inv_ids = None
-        if counts.size == 0 or counts.max() <= 1:
-            inv = -np.ones(self.n_rows, np.int32)
-            inv[ids[valid]] = np.nonzero(valid)[0].astype(np.int32)
-            self.inv_ids = torch.from_numpy(inv).to(device)
+        self.identity = bool(flags.value & 1)
+        self.covered = int(covered.value)
+        self.inv_ids = self.t_indptr = self.t_pos = None
+        if flags.value & 2:
+            self.ids, self.inv_ids = upload_packed([ids, inv[:self.n_rows]], device)
+        else:
+            self.ids, self.t_indptr, self.t_pos = upload_packed([ids, t_indptr, t_pos], device)

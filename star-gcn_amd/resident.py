@@ -117,17 +117,21 @@ class ResidentPlan(object):
         elif self.masked:
             self.mask_edges(np.zeros(0, np.int32))
         n_out = {self.U: self.n_user, self.I: self.n_item}
+        pair = recon_take = None       # every block reads the same rows: one plan, shared
+        if rating_node_pairs is not None:
+            pairs = np.asarray(rating_node_pairs)
+            pair = PairPlan(self._id_maps[self.U](pairs[0]), self._id_maps[self.I](pairs[1]), self.n_user, self.n_item, dev)
+        if recon_node_ids_dict is not None:
+            recon_take = {k: TakePlan(self._id_maps[k](np.asarray(v)), n_out[k], dev)
+                          for k, v in recon_node_ids_dict.items()}
         for b in range(net._nblocks):
             idx = plan["idx"][b]
             for k in ("pair", "recon_take", "rating", "recon"):
                 idx.pop(k, None)
-            if rating_node_pairs is not None:
-                pairs = np.asarray(rating_node_pairs)
-                idx["pair"] = PairPlan(self._id_maps[self.U](pairs[0]), self._id_maps[self.I](pairs[1]), self.n_user,
-                                       self.n_item, dev)
-            if recon_node_ids_dict is not None:
-                idx["recon_take"] = {k: TakePlan(self._id_maps[k](np.asarray(v)), n_out[k], dev)
-                                     for k, v in recon_node_ids_dict.items()}
+            if pair is not None:
+                idx["pair"] = pair
+            if recon_take is not None:
+                idx["recon_take"] = recon_take
         plan["input"] = net._embed_plan({k: self.graph.node_ids_dict[k] for k in self._all_ids}, embed_noise_dict,
                                         embed_noise_dict is not None, dev)
         plan["gt"] = (net._embed_plan(recon_node_ids_dict, None, False, dev) if recon_node_ids_dict is not None else None)

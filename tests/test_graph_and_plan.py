@@ -243,3 +243,49 @@ def test_plan_order_is_independent_of_hash_randomisation():
         env = dict(os.environ, PYTHONHASHSEED=seed, PYTHONPATH=ROOT)
         outs.add(subprocess.check_output([sys.executable, "-c", code], env=env, cwd=ROOT).decode())
     assert len(outs) == 1, outs
+
+
+def test_native_batch_plan_builders_match_numpy():
+    """sg_edge_positions_cpu / sg_pair_plan_cpu / sg_take_plan_cpu (host side of the per-batch plans) vs their numpy
+    definitions: stable grouping, stable transpose, inverse index, flags."""
+    import torch
+    from star_gcn_amd.model import PairPlan
+    from star_gcn_amd.plan import TakePlan
+    graph, eu, ei, vals = small_graph(seed=9)
+    m = graph["user", "movie"]
+    rng = np.random.default_rng(3)
+    sel = rng.choice(eu.size, 60, replace=False)
+    pairs = np.stack([np.concatenate([eu[sel], [0, 3]]), np.concatenate([ei[sel], [10 ** 3 % m.shape[1], 1]])])
+    pos = m.edge_positions(pairs)
+    key = m.edge_row_indices.astype(np.int64) * m.shape[1] + m.end_points
+    for k in range(pairs.shape[1]):
+        hit = np.nonzero(key == pairs[0, k].astype(np.int64) * m.shape[1] + pairs[1, k])[0]
+        assert pos[k] == (hit[0] if hit.size else -1)
+    # pair plan
+    u, i = rng.integers(0, 17, 200), rng.integers(0, 11, 200)
+    pp = PairPlan(u, i, 17, 11, "cpu")
+    order = np.argsort(u, kind="stable")
+    assert np.array_equal(pp.order.numpy(), order) and np.array_equal(pp.items.numpy(), i[order])
+    assert np.array_equal(pp.inv_order.numpy()[order], np.arange(200))
+    assert np.array_equal(np.diff(pp.indptr.numpy()), np.bincount(u, minlength=17))
+    t_order = np.argsort(i[order], kind="stable")
+    assert np.array_equal(pp.tplan.t_pos.numpy(), t_order)
+    assert np.array_equal(pp.tplan.t_seg.numpy(), u[order][t_order])
+    assert np.array_equal(np.diff(pp.tplan.t_indptr.numpy()), np.bincount(i, minlength=11))
+    srt = PairPlan(np.sort(u), i, 17, 11, "cpu")
+    assert srt.identity and srt.order is None and not pp.identity
+    empty = PairPlan(np.zeros(0, np.int32), np.zeros(0, np.int32), 4, 3, "cpu")
+    assert empty.n_pairs == 0 and empty.indptr.numpy().tolist() == [0] * 5
+    # take plan
+    ids = np.array([4, -1, 2, 4, 0, 7, 2, 4], np.int32)
+    tp = TakePlan(ids, 9, "cpu")
+    assert not tp.identity and tp.inv_ids is None and tp.covered == 7
+    assert np.array_equal(np.diff(tp.t_indptr.numpy()), np.bincount(ids[ids >= 0], minlength=9))
+    valid = np.nonzero(ids >= 0)[0]
+    assert np.array_equal(tp.t_pos.numpy()[:7], valid[np.argsort(ids[valid], kind="stable")])
+    perm = TakePlan(np.array([3, 0, -1, 2], np.int32), 5, "cpu")
+    assert perm.inv_ids.numpy().tolist() == [1, 3, 3 - 0, 0, -1][:0] + [1, -1, 3, 0, -1] and perm.t_pos is None
+    assert TakePlan(np.arange(6, dtype=np.int32), 6, "cpu").identity
+    assert not TakePlan(np.arange(6, dtype=np.int32), 7, "cpu").identity
+    with pytest.raises(Exception):
+        TakePlan(np.array([9], np.int32), 9, "cpu")
