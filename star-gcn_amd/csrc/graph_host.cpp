@@ -10,6 +10,12 @@
 #include <string>
 #include <vector>
 
+// Host helpers run once per training iteration on arrays of 1e4..1e7 entries.  Waking the OpenMP pool of a 256-thread
+// host costs ~10 ms (measured: sg_get_support_cpu on 72 k edges took 14 ms with the default team, <0.1 ms serial),
+// so small inputs stay serial and large ones use a bounded team.
+#define SG_HOST_THREADS 16
+#define SG_OMP_MIN_WORK (1 << 20)
+
 #include "common.hpp"
 
 namespace sg {
@@ -68,7 +74,7 @@ SG_API int sg_build_transpose_cpu(int32_t* t_indptr, int32_t* t_pos, int32_t* t_
 SG_API int sg_get_support_cpu(float* support, const int32_t* row_degrees, const int32_t* col_degrees,
                               const int32_t* end_points, const int32_t* ind_ptr, int64_t row_num, int symm) {
   if (row_num < 0) return fail(SG_ERR_INVALID, "negative row_num");
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(SG_HOST_THREADS) if (ind_ptr[row_num] > SG_OMP_MIN_WORK)
   for (int64_t i = 0; i < row_num; ++i) {
     const int32_t dr = row_degrees[i];
     for (int64_t j = ind_ptr[i]; j < ind_ptr[i + 1]; ++j) {
@@ -244,7 +250,7 @@ SG_API int sg_sample_fix_neighbor_cpu(int32_t* sampled, int32_t* dst_ind_ptr, co
     dst_ind_ptr[i + 1] = static_cast<int32_t>(total);
   }
   if (!sampled) return SG_OK;
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for schedule(dynamic, 256) num_threads(SG_HOST_THREADS) if (total > SG_OMP_MIN_WORK)
   for (int64_t i = 0; i < sel_num; ++i) {
     const int32_t b = src_ind_ptr[sel_indices[i]], e = src_ind_ptr[sel_indices[i] + 1];
     const int32_t k = dst_ind_ptr[i + 1] - dst_ind_ptr[i], len = e - b;
@@ -277,7 +283,7 @@ SG_API int sg_gen_row_indices_cpu(int32_t* row_indices, const int32_t* ind_ptr, 
   if (row_num < 0 || nnz < 0) return fail(SG_ERR_INVALID, "negative dimension");
   if (row_num > 0 && ind_ptr[row_num] != nnz) return fail(SG_ERR_VALUE, "ind_ptr[-1] = %d but nnz = %lld", ind_ptr[row_num],
                                                          static_cast<long long>(nnz));
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(SG_HOST_THREADS) if (nnz > SG_OMP_MIN_WORK)
   for (int64_t i = 0; i < row_num; ++i)
     for (int32_t j = ind_ptr[i]; j < ind_ptr[i + 1]; ++j) row_indices[j] = static_cast<int32_t>(i);
   return SG_OK;
@@ -290,7 +296,7 @@ SG_API int sg_gen_row_indices_cpu(int32_t* row_indices, const int32_t* ind_ptr, 
 SG_API int sg_edge_positions_cpu(int32_t* pos, const int32_t* end_points, const int32_t* ind_ptr, int64_t row_num,
                                  const int32_t* rows, const int32_t* cols, int64_t n) {
   if (row_num < 0 || n < 0) return fail(SG_ERR_INVALID, "negative dimension");
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(SG_HOST_THREADS) if (n > SG_OMP_MIN_WORK)
   for (int64_t k = 0; k < n; ++k) {
     const int32_t r = rows[k];
     if (r < 0 || r >= row_num) { pos[k] = -1; continue; }

@@ -106,11 +106,11 @@ class MultiLinkPlan(object):
             ctypes.cast(arr(*[a.ctypes.data for a in sps]), ctypes.c_void_p), R, n_dst, n_src),
             "sg_multilink_fuse_cpu")
         self.R, self.n_dst, self.n_src, self.nnz, self.device = R, n_dst, n_src, nnz, torch.device(device)
-        up = lambda a: torch.from_numpy(a).to(device)
-        self.c_indptr, self.c_idx, self.c_q, self.c_w = up(c_indptr), up(c_idx), up(c_q), up(c_w)
-        self.t_indptr, self.t_idx, self.t_q, self.t_w = up(t_indptr), up(t_idx), up(t_q), up(t_w)
-        self.d_indptr = up(np.ascontiguousarray(c_indptr[::R]))
-        self.s_indptr = up(np.ascontiguousarray(t_indptr[::R]))
+        # one host->device copy for the ten arrays (the two fp32 weight arrays travel as their bit patterns)
+        (self.c_indptr, self.c_idx, self.c_q, cw, self.t_indptr, self.t_idx, self.t_q, tw, self.d_indptr,
+         self.s_indptr) = upload_packed([c_indptr, c_idx, c_q, c_w.view(np.int32), t_indptr, t_idx, t_q, t_w.view(np.int32),
+                                         np.ascontiguousarray(c_indptr[::R]), np.ascontiguousarray(t_indptr[::R])], device)
+        self.c_w, self.t_w = cw.view(torch.float32), tw.view(torch.float32)
         self._rowsum = None
         self._struct = None
 
