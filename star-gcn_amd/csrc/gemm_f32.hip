@@ -352,13 +352,15 @@ __global__ void act_bwd_kernel(float* __restrict__ dpre, const float* __restrict
   }
 }
 
-constexpr int kColRows = 64;   // rows per workgroup in pass 1 of colsum
+// rows per workgroup in pass 1 of colsum: 64 keeps >= 160 workgroups in flight for the 10 k-row matrices of the step,
+// 256 keeps the number of partial rows (pass 2 reads them all) small for the 70 k-row ones
+static inline int colsum_rows(long long M) { return M > 32768 ? 256 : 64; }
 // pass 1: partial[chunk][col] = sum over the chunk's rows.  256 threads = 4 waves; a wave reads whole row
 // segments of 64*VEC consecutive floats (1 KiB with float4) so each load instruction is one coalesced burst;
 // the 4 waves take rows r, r+4, ... and are combined through LDS.
 template <int VEC>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(float* __restrict__ partial, const float* __restrict__ X,
-                                                             long long ldx, long long M, int N) {
+                                                             long long ldx, long long M, int N, int kColRows) {
   __shared__ float red[4][64 * VEC];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.y * 64 * VEC + lane * VEC;
@@ -388,13 +390,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(float* __restrict__
     }
   }
 }
-__global__ void colsum_final_kernel(float* __restrict__ dst, const float* __restrict__ partial, int chunks, int N,
-                                    int add) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N) return;
+// pass 2: 1024 threads = 64 columns x 16 row groups; group g sums partial rows g, g+16, ... (one coalesced 256-byte
+// row segment per wave and iteration), the 16 group sums are combined through LDS in a fixed order (deterministic).
+// The first version walked all `chunks` partial rows serially with one thread per column: 118 us average, 0.94 ms
+// per step at ML-10M (rocprofv3, profiles/r1_bench_ml10m_kernel_stats_v4.csv).
+__global__ __launch_bounds__(1024) void colsum_final_kernel(float* __restrict__ dst, const float* __restrict__ partial,
+                                                            int chunks, int N, int add) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
   float acc = 0.f;
-  for (int c = 0; c < chunks; ++c) acc += partial[static_cast<long long>(c) * N + col];
-  dst[col] = add ? dst[col] + acc : acc;
+  if (col < N)
+    for (int c = g; c < chunks; c += 16) acc += partial[static_cast<long long>(c) * N + col];
+  red[g][lane] = acc;
+  __syncthreads();
+  if (g == 0 && col < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][lane];
+    dst[col] = add ? dst[col] + s : s;
+  }
 }
 
 }  // namespace sg
@@ -480,6 +495,7 @@ SG_API int sg_act_bwd_hip(float* dpre, const float* dout, const float* out, int6
 
 SG_API size_t sg_colsum_workspace_bytes(int64_t M, int64_t N) {
   if (M <= 0 || N <= 0) return 0;
+  const int64_t kColRows = colsum_rows(M);
   return static_cast<size_t>((M + kColRows - 1) / kColRows) * N * sizeof(float);
 }
 
@@ -489,6 +505,7 @@ SG_API int sg_colsum_hip(float* dst, const float* X, int64_t ldx, int64_t M, int
   if (req == SG_REQ_NULL || N <= 0) return SG_OK;
   if (M < 0 || ldx < N || N >= (1ll << 31)) return fail(SG_ERR_INVALID, "bad colsum shape");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int kColRows = colsum_rows(M);
   const int64_t chunks = (M + kColRows - 1) / kColRows;
   if (chunks >= (1ll << 31) || (N + 63) / 64 > 65535) return fail(SG_ERR_INVALID, "colsum: shape too large");
   if (chunks > 0) {
@@ -497,13 +514,13 @@ SG_API int sg_colsum_hip(float* dst, const float* X, int64_t ldx, int64_t M, int
     if (N % 4 == 0 && ldx % 4 == 0 && aligned(X, 16))
       hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>((N + 255) / 256)),
                          dim3(256), 0, st, static_cast<float*>(workspace), X, static_cast<long long>(ldx),
-                         static_cast<long long>(M), static_cast<int>(N));
+                         static_cast<long long>(M), static_cast<int>(N), kColRows);
     else
       hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>((N + 63) / 64)),
                          dim3(256), 0, st, static_cast<float*>(workspace), X, static_cast<long long>(ldx),
-                         static_cast<long long>(M), static_cast<int>(N));
+                         static_cast<long long>(M), static_cast<int>(N), kColRows);
   }
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, st, dst,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>((N + 63) / 64)), dim3(1024), 0, st, dst,
                      static_cast<const float*>(workspace), static_cast<int>(chunks), static_cast<int>(N),
                      req == SG_REQ_ADD);
   return check_launch("colsum");
