@@ -113,7 +113,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.GATHER_TIMELINE = []
+    ops.gather_profile(True)      # HIP events around every gather launch, on the launch stream, inside the library
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -122,14 +122,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timeline, ops.GATHER_TIMELINE = ops.GATHER_TIMELINE, None
+    ops.gather_profile(False)
+    timeline = ops.gather_profile_read()
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     # ---- roofline of the dominant kernel (aggregation launches: width D over all local edges) ----------
-    agg = [(a.elapsed_time(b) * 1e-3, nnz, C) for a, b, nnz, C, _ in timeline if C == D and nnz == max(E_local, 1)]
+    agg = [(t, nnz, C) for t, nnz, C in timeline if C == D and nnz == max(E_local, 1) and t > 0]
     roof = None
     if agg:
         avg = sum(t for t, _, _ in agg) / len(agg)

@@ -302,6 +302,15 @@ int sg_mask_edges_hip(float* const* w_out, const int32_t* const* pos, const int3
                       const int32_t* col_degrees, const int32_t* rm_edges, int64_t n_rm, int64_t n_rows,
                       int64_t n_cols, int64_t nnz, int symm, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (10) measurement aid for bench.py's `roofline`: while enabled, every seg_gather launch (direct, or issued inside
+ *      sg_multilink_agg_*_hip) is bracketed with HIP events on the stream it is launched on.  enable(1) clears old
+ *      records and returns the previous state; read() synchronises the recorded events, returns up to `capacity`
+ *      (elapsed ms, edges visited, feature width) triples in launch order and clears the records.
+ * ---------------------------------------------------------------------------------------------- */
+int sg_gather_profile_enable(int on);
+int64_t sg_gather_profile_read(float* ms, int64_t* nnz, int64_t* feat_dim, int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

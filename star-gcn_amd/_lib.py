@@ -75,6 +75,8 @@ _SIGS = {
     "sg_take_plan_cpu": (_INT, [_P] * 6 + [_I64] * 2),
     "sg_mask_edges_workspace_bytes": (_SZ, [_I64] * 3),
     "sg_mask_edges_hip": (_INT, [_P, _P, _P, _c.c_int32] + [_P] * 5 + [_I64] * 4 + [_INT, _P, _SZ, _P]),
+    "sg_gather_profile_enable": (_INT, [_INT]),
+    "sg_gather_profile_read": (_I64, [_P, _P, _P, _I64]),
     "sg_multilink_agg_resolve_order": (_INT, [_P, _INT]),
     "sg_multilink_agg_saved_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT]),
     "sg_multilink_agg_workspace_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT, _INT]),

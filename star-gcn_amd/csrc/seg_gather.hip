@@ -21,6 +21,9 @@
 //     kernel adds the partials of each such segment in chunk order.
 #include "common.hpp"
 
+#include <mutex>
+#include <vector>
+
 namespace sg {
 
 constexpr int kChunk = 256;  // edges per wavefront
@@ -334,6 +337,33 @@ static void launch_variants(const GatherArgs& a, dim3 grid, hipStream_t st, bool
 }
 
 // Generic launcher shared by every public entry point built on the gather kernel.
+// ---- measurement aid (bench.py `roofline`): when enabled, every gather launch -- called directly or from inside the
+// fused aggregator entry -- is bracketed with HIP events ON ITS OWN STREAM.  Off by default; the compute entry
+// points stay stateless otherwise.
+struct ProfRecord {
+  hipEvent_t a, b;
+  int64_t nnz, C;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRecord> g_prof;
+
+static ProfRecord* prof_begin(hipStream_t st, int64_t nnz, int64_t C) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_on) return nullptr;
+  ProfRecord r{};
+  r.nnz = nnz; r.C = C;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return nullptr;
+  (void)hipEventRecord(r.a, st);
+  g_prof.push_back(r);
+  return &g_prof.back();   // valid until the next push: prof_end follows immediately on the same thread
+}
+static void prof_end(ProfRecord* r, hipStream_t st) {
+  if (!r) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  (void)hipEventRecord(g_prof.back().b, st);
+}
+
 int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs, const float* src, int64_t src_group,
                   int64_t src_ld, int64_t src_bs, const float* w, int64_t w_bs, const int32_t* wpos,
                   const int32_t* idx, const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t nnz, int64_t C,
@@ -390,9 +420,11 @@ int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs,
   const bool grouped = (src_group > 1);
   dim3 grid(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch));
   if (batch > 65535) return fail(SG_ERR_INVALID, "batch > 65535 not supported");
+  ProfRecord* rec = prof_begin(st, nnz * batch, C);
   if (vec == 4) launch_variants<4>(a, grid, st, grouped, uni);
   else if (vec == 2) launch_variants<2>(a, grid, st, grouped, uni);
   else launch_variants<1>(a, grid, st, grouped, uni);
+  prof_end(rec, st);
   return check_launch("seg_gather");
 }
 
@@ -443,4 +475,35 @@ SG_API int sg_seg_weighted_pool_bwd_data_hip(float* ddata, const float* weights,
   return sg::launch_gather(ddata, 1, feat_dim, total_ind_num * feat_dim, ograd, 1, feat_dim, seg_num * feat_dim,
                            weights, nnz, t_pos, t_seg, t_indptr, batch, total_ind_num, nnz, feat_dim, req, 0, SG_ACT_NONE,
                            0.f, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+SG_API int sg_gather_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(sg::g_prof_mu);
+  const int was = sg::g_prof_on ? 1 : 0;
+  if (on && !was) {
+    for (auto& r : sg::g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    sg::g_prof.clear();
+  }
+  sg::g_prof_on = on != 0;
+  return was;
+}
+
+SG_API int64_t sg_gather_profile_read(float* ms, int64_t* nnz, int64_t* feat_dim, int64_t capacity) {
+  std::lock_guard<std::mutex> lk(sg::g_prof_mu);
+  int64_t n = 0;
+  for (auto& r : sg::g_prof) {
+    if (n < capacity) {
+      float t = 0.f;
+      (void)hipEventSynchronize(r.b);
+      if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) t = -1.f;
+      if (ms) ms[n] = t;
+      if (nnz) nnz[n] = r.nnz;
+      if (feat_dim) feat_dim[n] = r.C;
+      ++n;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  sg::g_prof.clear();
+  return n;
 }

@@ -9,7 +9,19 @@ from . import _lib as L
 from ._lib import ACT, REQ_ADD, REQ_NULL, REQ_WRITE  # noqa: F401  (re-exported)
 
 
-GATHER_TIMELINE = None   # set to a list by bench.py to collect (start_event, end_event, nnz, C, segs) per launch
+def gather_profile(enable):
+    """bench.py: switch the library's HIP-event bracketing of gather launches on/off (sg_gather_profile_enable)."""
+    return L.lib().sg_gather_profile_enable(int(bool(enable)))
+
+
+def gather_profile_read(capacity=1 << 16):
+    """-> list of (seconds, edges visited, feature width) per gather launch since the profile was enabled."""
+    import ctypes
+    ms = (ctypes.c_float * capacity)()
+    nnz = (ctypes.c_int64 * capacity)()
+    fd = (ctypes.c_int64 * capacity)()
+    n = L.lib().sg_gather_profile_read(ms, nnz, fd, capacity)
+    return [(ms[i] * 1e-3, int(nnz[i]), int(fd[i])) for i in range(n)]
 
 
 def _act_id(act):
@@ -30,16 +42,9 @@ def gather_sum(dst, src, indices, indptr, weights, seg_num, feat_dim, dst_group=
     lib = L.lib()
     wsb = lib.sg_seg_weighted_pool_workspace_bytes(1, seg_num, nnz, feat_dim)
     ws, wsn = L.workspace(wsb, dst.device)
-    ev = None
-    if GATHER_TIMELINE is not None:   # bench.py: HIP events on the launch stream around the dominant kernel
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
     L.check(lib.sg_seg_gather_sum_hip(L.ptr(dst), dst_group, dst_ld, L.ptr(src), src_group, src_ld, L.ptr(weights),
                                       L.ptr(indices), L.ptr(indptr), seg_num, nnz, feat_dim, req, _act_id(act),
                                       float(slope), L.ptr(ws), wsn, L.stream_ptr()), "sg_seg_gather_sum_hip")
-    if ev is not None:
-        ev[1].record()
-        GATHER_TIMELINE.append((ev[0], ev[1], int(nnz), int(feat_dim), int(seg_num)))
     return dst
 
 
