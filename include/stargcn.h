@@ -81,6 +81,14 @@ int sg_seg_gather_sum_hip(float* dst, int64_t dst_group, int64_t dst_ld, const f
                           int64_t src_ld, const float* weights, const int32_t* indices, const int32_t* indptr,
                           int64_t seg_num, int64_t nnz, int64_t feat_dim, int req, int act, float slope,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* Same, with the byte size of the source matrix as a scheduling hint (0 = unknown): when the source fits the 256 MB
+ * Infinity Cache but not one XCD's 4 MB L2, the launch is column-sliced across the XCDs (each XCD only touches one
+ * 256-byte slice of every source row), which raises the L2 hit rate.  Deterministic either way; a sliced launch
+ * sums each row's edges as 4 interleaved partial sums combined by a fixed shuffle tree (same fp32 error class). */
+int sg_seg_gather_sum_hinted_hip(float* dst, int64_t dst_group, int64_t dst_ld, const float* src, int64_t src_group,
+                                 int64_t src_ld, const float* weights, const int32_t* indices, const int32_t* indptr,
+                                 int64_t seg_num, int64_t nnz, int64_t feat_dim, int req, int act, float slope,
+                                 void* workspace, size_t workspace_bytes, void* stream, int64_t src_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * (2) gradient of (1) w.r.t. data == reference `_contrib__backward_seg_take_k_corr_embed2(weights,

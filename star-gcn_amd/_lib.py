@@ -43,6 +43,8 @@ _SIGS = {
     "sg_seg_weighted_pool_hip": (_INT, [_P] * 5 + [_I64] * 5 + [_INT, _P, _SZ, _P]),
     "sg_seg_gather_sum_hip": (_INT, [_P, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _F32,
                                      _P, _SZ, _P]),
+    "sg_seg_gather_sum_hinted_hip": (_INT, [_P, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _INT, _INT,
+                                            _F32, _P, _SZ, _P, _I64]),
     "sg_seg_weighted_pool_bwd_data_workspace_bytes": (_SZ, [_I64] * 4),
     "sg_seg_weighted_pool_bwd_data_hip": (_INT, [_P] * 6 + [_I64] * 5 + [_INT, _P, _SZ, _P]),
     "sg_build_transpose_cpu": (_INT, [_P] * 5 + [_I64] * 3),

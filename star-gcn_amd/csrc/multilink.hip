@@ -251,10 +251,12 @@ SG_API int sg_multilink_agg_fwd_hip(float* out, void* saved, const float* x, con
       SG_TRY(sg_gemm_f32_hip(h, d.RU, x, d.D, 0, wcat, d.D, 1, d.n_src, d.RU, d.D, bcat, SG_ACT_NONE, 0.f, 0, scratch,
                              L.scratch_bytes, stream));
     if (!d.stack)
-      return sg_seg_gather_sum_hip(out, 1, d.U, h, d.R, d.RU, plan->c_w, plan->c_q, plan->d_indptr, d.n_dst, d.nnz, d.U,
-                                   SG_REQ_WRITE, act, slope, scratch, L.scratch_bytes, stream);
-    return sg_seg_gather_sum_hip(out, d.R, d.RU, h, d.R, d.RU, plan->c_w, plan->c_q, plan->c_indptr, d.n_dst * d.R,
-                                 d.nnz, d.U, SG_REQ_WRITE, act, slope, scratch, L.scratch_bytes, stream);
+      return sg_seg_gather_sum_hinted_hip(out, 1, d.U, h, d.R, d.RU, plan->c_w, plan->c_q, plan->d_indptr, d.n_dst, d.nnz,
+                                          d.U, SG_REQ_WRITE, act, slope, scratch, L.scratch_bytes, stream,
+                                          d.n_src * d.RU * 4);
+    return sg_seg_gather_sum_hinted_hip(out, d.R, d.RU, h, d.R, d.RU, plan->c_w, plan->c_q, plan->c_indptr, d.n_dst * d.R,
+                                        d.nnz, d.U, SG_REQ_WRITE, act, slope, scratch, L.scratch_bytes, stream,
+                                        d.n_src * d.RU * 4);
   }
 
   if (!saved) return fail(SG_ERR_INVALID, "aggregate-first needs the `saved` buffer (sg_multilink_agg_saved_bytes)");
@@ -264,8 +266,9 @@ SG_API int sg_multilink_agg_fwd_hip(float* out, void* saved, const float* x, con
   hipLaunchKernelGGL(pack_ext_kernel, dim3(blocks_for(d.outw * d.ld)), dim3(256), 0, st, wext, w, b, d.R,
                      static_cast<int>(d.U), static_cast<int>(d.D), static_cast<int>(d.ld), d.stack);
   SG_TRY(check_launch("pack_ext_kernel"));
-  SG_TRY(sg_seg_gather_sum_hip(zext, d.R, d.ld, x, 1, d.D, plan->c_w, plan->c_idx, plan->c_indptr, d.n_dst * d.R, d.nnz,
-                               d.D, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream));
+  SG_TRY(sg_seg_gather_sum_hinted_hip(zext, d.R, d.ld, x, 1, d.D, plan->c_w, plan->c_idx, plan->c_indptr, d.n_dst * d.R,
+                                      d.nnz, d.D, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream,
+                                      d.n_src * d.D * 4));
   hipLaunchKernelGGL(fill_rowsum_kernel, dim3(blocks_for(d.n_dst * (d.ld - d.R * d.D))), dim3(256), 0, st, zext,
                      plan->rowsum, static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.D), static_cast<int>(d.ld));
   SG_TRY(check_launch("fill_rowsum_kernel"));
@@ -318,11 +321,13 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
     }
     // dH[(n, r), :] = sum over the transposed plan of t_w * dpre[dest (, level r block)]
     if (!d.stack)
-      SG_TRY(sg_seg_gather_sum_hip(dh, d.R, d.RU, dpre, 1, d.U, plan->t_w, plan->t_idx, plan->t_indptr, d.n_src * d.R,
-                                   d.nnz, d.U, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream));
+      SG_TRY(sg_seg_gather_sum_hinted_hip(dh, d.R, d.RU, dpre, 1, d.U, plan->t_w, plan->t_idx, plan->t_indptr,
+                                          d.n_src * d.R, d.nnz, d.U, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch,
+                                          L.scratch_bytes, stream, d.n_dst * d.outw * 4));
     else
-      SG_TRY(sg_seg_gather_sum_hip(dh, d.R, d.RU, dpre, d.R, d.RU, plan->t_w, plan->t_q, plan->t_indptr, d.n_src * d.R,
-                                   d.nnz, d.U, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream));
+      SG_TRY(sg_seg_gather_sum_hinted_hip(dh, d.R, d.RU, dpre, d.R, d.RU, plan->t_w, plan->t_q, plan->t_indptr,
+                                          d.n_src * d.R, d.nnz, d.U, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch,
+                                          L.scratch_bytes, stream, d.n_dst * d.outw * 4));
     if (dx) {
       hipLaunchKernelGGL(pack_cat_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, wcat,
                          static_cast<float*>(nullptr), w, nob, d.R, static_cast<int>(d.U), static_cast<int>(d.D));
@@ -359,8 +364,9 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
     if (d.n_dst > 0)
       SG_TRY(sg_gemm_f32_hip(dz, d.ld, dpre, d.outw, 0, wext, d.ld, 0, d.n_dst, d.ld, d.outw, nullptr, SG_ACT_NONE, 0.f,
                              0, scratch, L.scratch_bytes, stream));
-    SG_TRY(sg_seg_gather_sum_hip(dx, 1, d.D, dz, d.R, d.ld, plan->t_w, plan->t_q, plan->s_indptr, d.n_src, d.nnz, d.D,
-                                 SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream));
+    SG_TRY(sg_seg_gather_sum_hinted_hip(dx, 1, d.D, dz, d.R, d.ld, plan->t_w, plan->t_q, plan->s_indptr, d.n_src, d.nnz,
+                                        d.D, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream,
+                                        d.n_dst * d.ld * 4));
   }
   if ((want_w || want_b) && d.n_dst == 0) return zero_param_grads(dw, db, d, st);
   if (want_w || want_b) {

@@ -26,6 +26,9 @@
 
 namespace sg {
 
+#ifndef SG_GATHER_DEFAULT_SLICES
+#define SG_GATHER_DEFAULT_SLICES 4
+#endif
 constexpr int kChunk = 256;  // edges per wavefront
 constexpr int kPtrTile = 64; // CSR row pointers staged in LDS per refill
 
@@ -44,6 +47,7 @@ struct GatherArgs {
   uint32_t src_magic;    // q / src_group == (uint64(q) * src_magic) >> (31 + src_shift)   for q < 2^31
   int32_t src_shift;
   int32_t seg_num, C, n_chunks, lpr;
+  int32_t n_slices, Cs;  // column slicing across XCDs: slice i covers channels [i*Cs, (i+1)*Cs); 1 / C = off
   int32_t req, mean;
   int32_t act;
   float slope;
@@ -169,14 +173,24 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
   __shared__ int32_t s_ptr[kPtrTile + 1];
 
   const int lane = threadIdx.x;
-  const int k = blockIdx.x;
+  // Column slicing (n_slices in {2,4,8}): workgroup x runs on XCD x % 8 (round-robin dispatch), and XCD i only ever
+  // touches the 4*Cs-byte column slice (i % n_slices) of every source row, so its private 4 MB L2 faces a working set
+  // n_slices times smaller than the source matrix.  The 8 / n_slices XCDs that share a slice split the chunks.
+  int k = blockIdx.x, slice = 0;
+  if (a.n_slices > 1) {
+    const int xcd = blockIdx.x & 7;
+    slice = xcd % a.n_slices;
+    k = (blockIdx.x >> 3) * (8 / a.n_slices) + xcd / a.n_slices;
+    if (k >= a.n_chunks) return;
+  }
+  const int c_lo = slice * a.Cs, c_hi = min(a.C, c_lo + a.Cs);
   const int b = blockIdx.y;
   const int32_t* __restrict__ indptr = a.indptr;
   const int E = indptr[a.seg_num];  // covered edges; positions >= E are padding
   const long long cb64 = static_cast<long long>(k) * kChunk;
   int32_t* tailseg = a.ws_tailseg + static_cast<long long>(b) * a.n_chunks + k;
   if (cb64 >= E && !(E == 0 && k == 0)) {
-    if (lane == 0) *tailseg = -1;
+    if (lane == 0 && slice == 0) *tailseg = -1;
     return;
   }
   const int cb = static_cast<int>(cb64);
@@ -208,9 +222,9 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
   const int p_lo = indptr[s_lo];  // s_lo <= seg_num
   if (cb < ce && p_lo > cb) {
     const int hb = min(ce, p_lo);
-    for (int ct = 0; ct < a.C; ct += ctile) {
+    for (int ct = c_lo; ct < c_hi; ct += ctile) {
       const int c = ct + slot * VEC;
-      const bool chan_ok = c < a.C;
+      const bool chan_ok = c < c_hi;
       float acc[VEC];
       accumulate_piece<VEC, GROUPED, UNI>(a, src, s_idx, s_w, 0, hb - cb, c, chan_ok, grp, epg, acc);
       if (grp == 0 && chan_ok) st_vec<VEC>(a.ws_head + wsrow + c, acc);
@@ -241,9 +255,9 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
         out = a.ws_tail + wsrow;
       }
       const float scale = (a.mean && pe > pb) ? 1.f / static_cast<float>(pe - pb) : 1.f;
-      for (int ct = 0; ct < a.C; ct += ctile) {
+      for (int ct = c_lo; ct < c_hi; ct += ctile) {
         const int c = ct + slot * VEC;
-        const bool chan_ok = c < a.C;
+        const bool chan_ok = c < c_hi;
         float acc[VEC];
         accumulate_piece<VEC, GROUPED, UNI>(a, src, s_idx, s_w, pb - cb, eb - cb, c, chan_ok, grp, epg, acc);
         if (grp == 0 && chan_ok) {
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
       if (!whole) { tail_s = s; done = true; break; }
     }
   }
-  if (lane == 0) *tailseg = tail_s;
+  if (lane == 0 && slice == 0) *tailseg = tail_s;
 }
 
 // Adds, in chunk order, the partial rows of every segment that straddles chunk boundaries.
@@ -325,7 +339,12 @@ size_t gather_workspace_bytes(int64_t batch, int64_t nnz, int64_t C) {
 }
 
 template <int VEC>
-static void launch_variants(const GatherArgs& a, dim3 grid, hipStream_t st, bool grouped, bool uni) {
+static void launch_variants(const GatherArgs& a, dim3 fix_grid, hipStream_t st, bool grouped, bool uni) {
+  dim3 grid = fix_grid;   // sliced: 8 workgroups (one per XCD) per group of 8 / n_slices chunks
+  if (a.n_slices > 1) {
+    const unsigned per = 8u / static_cast<unsigned>(a.n_slices);
+    grid.x = (static_cast<unsigned>(a.n_chunks) + per - 1) / per * 8u;
+  }
   if (grouped) {
     if (uni) hipLaunchKernelGGL((seg_gather_kernel<VEC, true, true>), grid, dim3(kWave), 0, st, a);
     else hipLaunchKernelGGL((seg_gather_kernel<VEC, true, false>), grid, dim3(kWave), 0, st, a);
@@ -333,7 +352,7 @@ static void launch_variants(const GatherArgs& a, dim3 grid, hipStream_t st, bool
     if (uni) hipLaunchKernelGGL((seg_gather_kernel<VEC, false, true>), grid, dim3(kWave), 0, st, a);
     else hipLaunchKernelGGL((seg_gather_kernel<VEC, false, false>), grid, dim3(kWave), 0, st, a);
   }
-  hipLaunchKernelGGL((seg_gather_fixup_kernel<VEC>), grid, dim3(kWave), 0, st, a);
+  hipLaunchKernelGGL((seg_gather_fixup_kernel<VEC>), fix_grid, dim3(kWave), 0, st, a);
 }
 
 // Generic launcher shared by every public entry point built on the gather kernel.
@@ -367,7 +386,8 @@ static void prof_end(ProfRecord* r, hipStream_t st) {
 int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs, const float* src, int64_t src_group,
                   int64_t src_ld, int64_t src_bs, const float* w, int64_t w_bs, const int32_t* wpos,
                   const int32_t* idx, const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t nnz, int64_t C,
-                  int req, int mean, int act, float slope, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                  int req, int mean, int act, float slope, void* workspace, size_t workspace_bytes, hipStream_t st,
+                  int64_t src_bytes) {
   if (!valid_req(req)) return fail(SG_ERR_INVALID, "req must be 0 (null), 1 (write) or 3 (add), got %d", req);
   if (req == SG_REQ_NULL) return SG_OK;
   if (batch < 0 || seg_num < 0 || nnz < 0 || C < 0) return fail(SG_ERR_INVALID, "negative dimension");
@@ -413,8 +433,25 @@ int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs,
            aligned(dst, 4 * v) && aligned(src, 4 * v);
   };
   if (ok(4)) vec = 4; else if (ok(2)) vec = 2;
+  // Column slicing across XCDs (see the kernel).  Measured (bench.py, MovieLens-10M shape, 68-105 MB sources that sit
+  // in the 256 MB Infinity Cache): 1.278 ms -> 1.187 ms (2 slices) -> 1.113 ms (4) -> 1.25 (8) per 10 M-edge launch;
+  // with sources far beyond the Infinity Cache (hbm-stress, 0.5-8 GB) the 1 KiB row bursts are worth more than the
+  // L2 hits: 10.2 ms -> 11.0 (2) -> 12.7 (4).  So: slice only when the caller tells us the source footprint
+  // (src_bytes, 0 = unknown) and it fits the Infinity Cache next to the output, but not a single L2.
+  int slices = 1;
+  auto valid = [&](int v) { return (v == 1 || v == 2 || v == 4 || v == 8) && C % (v * vec) == 0; };
+  if (vec == 4 && C >= 256 && nnz >= (1 << 20) && src_bytes >= (8ll << 20) && src_bytes <= (160ll << 20)) {
+    slices = SG_GATHER_DEFAULT_SLICES;
+    if (const char* e = getenv("SG_GATHER_SLICES")) slices = atoi(e);   // tuning aid: applies to eligible launches only
+    if (!valid(slices)) slices = 1;
+  }
+  if (const char* e = getenv("SG_GATHER_SLICES_FORCE")) {                // tests: slice every launch it divides
+    if (valid(atoi(e))) slices = atoi(e);
+  }
+  a.n_slices = slices;
+  a.Cs = static_cast<int32_t>(C / slices);
   int lpr = 1;
-  while (lpr < kWave && static_cast<int64_t>(lpr) * vec < C) lpr <<= 1;
+  while (lpr < kWave && static_cast<int64_t>(lpr) * vec < a.Cs) lpr <<= 1;
   a.lpr = lpr;
   const bool uni = (lpr == kWave);
   const bool grouped = (src_group > 1);
@@ -445,16 +482,26 @@ SG_API int sg_seg_weighted_pool_hip(float* dst, const float* data, const float* 
   if (weights == nullptr && nnz > 0 && req != SG_REQ_NULL) return sg::fail(SG_ERR_INVALID, "weights is null");
   return sg::launch_gather(dst, 1, feat_dim, seg_num * feat_dim, data, 1, feat_dim, total_ind_num * feat_dim, weights,
                            nnz, nullptr, indices, indptr, batch, seg_num, nnz, feat_dim, req, 0, SG_ACT_NONE, 0.f,
-                           workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                           workspace, workspace_bytes, static_cast<hipStream_t>(stream),
+                           batch * total_ind_num * feat_dim * static_cast<int64_t>(sizeof(float)));
+}
+
+SG_API int sg_seg_gather_sum_hinted_hip(float* dst, int64_t dst_group, int64_t dst_ld, const float* src,
+                                        int64_t src_group, int64_t src_ld, const float* weights, const int32_t* indices,
+                                        const int32_t* indptr, int64_t seg_num, int64_t nnz, int64_t feat_dim, int req,
+                                        int act, float slope, void* workspace, size_t workspace_bytes, void* stream,
+                                        int64_t src_bytes) {
+  return sg::launch_gather(dst, dst_group, dst_ld, 0, src, src_group, src_ld, 0, weights, 0, nullptr, indices, indptr,
+                           1, seg_num, nnz, feat_dim, req, 0, act, slope, workspace, workspace_bytes,
+                           static_cast<hipStream_t>(stream), src_bytes);
 }
 
 SG_API int sg_seg_gather_sum_hip(float* dst, int64_t dst_group, int64_t dst_ld, const float* src, int64_t src_group,
                                  int64_t src_ld, const float* weights, const int32_t* indices, const int32_t* indptr,
                                  int64_t seg_num, int64_t nnz, int64_t feat_dim, int req, int act, float slope,
                                  void* workspace, size_t workspace_bytes, void* stream) {
-  return sg::launch_gather(dst, dst_group, dst_ld, 0, src, src_group, src_ld, 0, weights, 0, nullptr, indices, indptr,
-                           1, seg_num, nnz, feat_dim, req, 0, act, slope, workspace, workspace_bytes,
-                           static_cast<hipStream_t>(stream));
+  return sg_seg_gather_sum_hinted_hip(dst, dst_group, dst_ld, src, src_group, src_ld, weights, indices, indptr, seg_num,
+                                      nnz, feat_dim, req, act, slope, workspace, workspace_bytes, stream, 0);
 }
 
 SG_API size_t sg_seg_weighted_pool_bwd_data_workspace_bytes(int64_t batch, int64_t total_ind_num, int64_t nnz,
@@ -474,7 +521,8 @@ SG_API int sg_seg_weighted_pool_bwd_data_hip(float* ddata, const float* weights,
   // gather over the transposed plan: segment n collects ograd rows t_seg[p] with weight weights[t_pos[p]]
   return sg::launch_gather(ddata, 1, feat_dim, total_ind_num * feat_dim, ograd, 1, feat_dim, seg_num * feat_dim,
                            weights, nnz, t_pos, t_seg, t_indptr, batch, total_ind_num, nnz, feat_dim, req, 0, SG_ACT_NONE,
-                           0.f, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                           0.f, workspace, workspace_bytes, static_cast<hipStream_t>(stream),
+                           batch * seg_num * feat_dim * static_cast<int64_t>(sizeof(float)));
 }
 
 SG_API int sg_gather_profile_enable(int on) {

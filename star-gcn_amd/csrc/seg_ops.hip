@@ -12,7 +12,8 @@ namespace sg {
 int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs, const float* src, int64_t src_group,
                   int64_t src_ld, int64_t src_bs, const float* w, int64_t w_bs, const int32_t* wpos,
                   const int32_t* idx, const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t nnz, int64_t C,
-                  int req, int mean, int act, float slope, void* workspace, size_t workspace_bytes, hipStream_t st);
+                  int req, int mean, int act, float slope, void* workspace, size_t workspace_bytes, hipStream_t st,
+                  int64_t src_bytes);
 size_t gather_workspace_bytes(int64_t batch, int64_t nnz, int64_t C);
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -368,7 +369,7 @@ SG_API int sg_seg_pool_hip(float* dst, int32_t* pool_indices, const float* data,
   }
   return launch_gather(dst, 1, feat_dim, seg_num * feat_dim, data, 1, feat_dim, total_ind_num * feat_dim, nullptr, 0,
                        nullptr, indices, indptr, batch, seg_num, nnz, feat_dim, req, pool_type == SG_POOL_AVG, SG_ACT_NONE, 0.f,
-                       workspace, workspace_bytes, st);
+                       workspace, workspace_bytes, st, batch * total_ind_num * feat_dim * static_cast<int64_t>(sizeof(float)));
 }
 
 SG_API size_t sg_seg_pool_bwd_workspace_bytes(int64_t batch, int64_t total_ind_num, int64_t nnz, int64_t feat_dim) {
@@ -407,5 +408,5 @@ SG_API int sg_seg_pool_bwd_hip(float* ddata, const float* ograd, const int32_t* 
   // same weights for every batch element (w_bs = 0)
   return launch_gather(ddata, 1, feat_dim, total_ind_num * feat_dim, ograd, 1, feat_dim, seg_num * feat_dim, w, 0,
                        nullptr, t_seg, t_indptr, batch, total_ind_num, nnz, feat_dim, req, 0, SG_ACT_NONE, 0.f, workspace, gbytes,
-                       st);
+                       st, batch * seg_num * feat_dim * static_cast<int64_t>(sizeof(float)));
 }

@@ -42,9 +42,10 @@ def gather_sum(dst, src, indices, indptr, weights, seg_num, feat_dim, dst_group=
     lib = L.lib()
     wsb = lib.sg_seg_weighted_pool_workspace_bytes(1, seg_num, nnz, feat_dim)
     ws, wsn = L.workspace(wsb, dst.device)
-    L.check(lib.sg_seg_gather_sum_hip(L.ptr(dst), dst_group, dst_ld, L.ptr(src), src_group, src_ld, L.ptr(weights),
-                                      L.ptr(indices), L.ptr(indptr), seg_num, nnz, feat_dim, req, _act_id(act),
-                                      float(slope), L.ptr(ws), wsn, L.stream_ptr()), "sg_seg_gather_sum_hip")
+    L.check(lib.sg_seg_gather_sum_hinted_hip(L.ptr(dst), dst_group, dst_ld, L.ptr(src), src_group, src_ld,
+                                             L.ptr(weights), L.ptr(indices), L.ptr(indptr), seg_num, nnz, feat_dim, req,
+                                             _act_id(act), float(slope), L.ptr(ws), wsn, L.stream_ptr(),
+                                             src.numel() * 4), "sg_seg_gather_sum_hinted_hip")
     return dst
 
 

@@ -102,3 +102,41 @@ def test_errors_are_python_exceptions():
         ops.gemm(torch.zeros(3, 4, device="cuda"), torch.zeros(5, 6, device="cuda"))
     with pytest.raises(L.StarGCNError, match="CUDA/HIP tensor"):
         ops.seg_sum(torch.zeros(1, 3), indptr)
+
+
+@pytest.mark.parametrize("slices", ["2", "4", "8"])
+def test_column_sliced_gather_matches_unsliced(slices, monkeypatch):
+    """XCD column slicing of the gather (SG_GATHER_SLICES_FORCE): every addressing mode, write / add, fused activation,
+    empty segments, a hub segment spanning many chunks -- against the unsliced launch (same values up to the different
+    but fixed summation order) and the float64 definition."""
+    from star_gcn_amd import ops
+    rng = np.random.default_rng(int(slices))
+    g = torch.Generator().manual_seed(int(slices))
+    n_seg, n_src, nnz, R = 300, 90, 20000, 3
+    lens = rng.multinomial(nnz - 6000, rng.dirichlet(np.ones(n_seg) * 0.3))
+    lens[17] += 6000                                            # hub segment: > 23 chunks
+    lens[5] = 0
+    nnz = int(lens.sum())
+    indptr = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).cuda()
+    w = torch.randn(nnz, generator=g).cuda()
+    for C in (256, 320):
+        for grouped in (False, True):
+            idx = torch.from_numpy(rng.integers(0, n_src * (R if grouped else 1), nnz).astype(np.int32)).cuda()
+            src = torch.randn(n_src, R * C if grouped else C, generator=g).cuda()
+            kw = dict(src_group=R, src_ld=R * C) if grouped else {}
+            rows = src.view(-1, C) if grouped else src
+            ref = torch.zeros(n_seg, C, dtype=torch.float64)
+            seg = np.repeat(np.arange(n_seg), lens)
+            ref.index_add_(0, torch.from_numpy(seg), (w.double().cpu()[:, None] * rows.double().cpu()[idx.cpu().long()]))
+            for req, act in ((ops.REQ_WRITE, None), (ops.REQ_ADD, None), (ops.REQ_WRITE, "leaky")):
+                base = torch.randn(n_seg, C, generator=g).cuda()
+                monkeypatch.delenv("SG_GATHER_SLICES_FORCE", raising=False)
+                plain = ops.gather_sum(base.clone(), src, idx, indptr, w, n_seg, C, req=req, act=act, **kw)
+                monkeypatch.setenv("SG_GATHER_SLICES_FORCE", slices)
+                sliced = ops.gather_sum(base.clone(), src, idx, indptr, w, n_seg, C, req=req, act=act, **kw)
+                want = ref + (base.double().cpu() if req == ops.REQ_ADD else 0)
+                if act:
+                    want = torch.where(want > 0, want, 0.1 * want)
+                scale = float(want.abs().max())
+                assert float((sliced.double().cpu() - want).abs().max()) <= 2e-6 * scale
+                assert float((sliced - plain).abs().max()) <= 2e-6 * scale
