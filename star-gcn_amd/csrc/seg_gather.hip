@@ -114,10 +114,17 @@ __device__ __forceinline__ long long src_row_off(const GatherArgs& a, int q) {
   return static_cast<long long>(hi) * a.src_ld + static_cast<long long>(lo) * a.C;
 }
 
+// wave-uniform 64-bit value -> SGPR pair (scalar address arithmetic for the row burst)
+__device__ __forceinline__ long long uniform_ll(long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(static_cast<unsigned long long>(v) >> 32));
+  return static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 // Accumulate edges [ea, eb) (chunk-relative LDS positions) for the channel tile starting at ct; the
 // result (summed over edge groups) is returned in acc on every lane.
 template <int VEC, bool GROUPED, bool UNI>
-__device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const float* __restrict__ src, const int32_t* s_idx,
+__device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const float* __restrict__ src, const long long* s_off,
                                                  const float* s_w, int ea, int eb, int c, bool chan_ok, int grp,
                                                  int epg, float (&acc)[VEC]) {
 #pragma unroll
@@ -129,13 +136,13 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
     float wv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      int q = s_idx[e + u * epg];
+      long long off = s_off[e + u * epg];
       wv[u] = s_w[e + u * epg];
       if (UNI) {
-        q = __builtin_amdgcn_readfirstlane(q);
+        off = uniform_ll(off);
         wv[u] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wv[u])));
       }
-      if (chan_ok) ld_vec<VEC>(x[u], src + src_row_off<GROUPED>(a, q) + c);
+      if (chan_ok) ld_vec<VEC>(x[u], src + off + c);
     }
     if (chan_ok) {
 #pragma unroll
@@ -145,15 +152,15 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
     }
   }
   for (; e < eb; e += epg) {
-    int q = s_idx[e];
+    long long off = s_off[e];
     float wv = s_w[e];
     if (UNI) {
-      q = __builtin_amdgcn_readfirstlane(q);
+      off = uniform_ll(off);
       wv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wv)));
     }
     if (chan_ok) {
       float x[VEC];
-      ld_vec<VEC>(x, src + src_row_off<GROUPED>(a, q) + c);
+      ld_vec<VEC>(x, src + off + c);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[v] = fmaf(wv, x[v], acc[v]);
     }
@@ -168,7 +175,7 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
 
 template <int VEC, bool GROUPED, bool UNI>
 __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
-  __shared__ int32_t s_idx[kChunk];
+  __shared__ long long s_off[kChunk];   // element offset of each edge's source row (index -> row address done once)
   __shared__ float s_w[kChunk];
   __shared__ int32_t s_ptr[kPtrTile + 1];
 
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
   // ---- stage this chunk's edges in LDS (coalesced) -------------------------------------------------
   for (int q = lane; q < ce - cb; q += kWave) {
     const int j = cb + q;
-    s_idx[q] = a.idx[j];
+    s_off[q] = src_row_off<GROUPED>(a, a.idx[j]);
     float wv = 1.f;
     if (a.w) wv = a.w[static_cast<long long>(b) * a.w_bs + (a.wpos ? a.wpos[j] : j)];
     s_w[q] = wv;
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
       const int c = ct + slot * VEC;
       const bool chan_ok = c < c_hi;
       float acc[VEC];
-      accumulate_piece<VEC, GROUPED, UNI>(a, src, s_idx, s_w, 0, hb - cb, c, chan_ok, grp, epg, acc);
+      accumulate_piece<VEC, GROUPED, UNI>(a, src, s_off, s_w, 0, hb - cb, c, chan_ok, grp, epg, acc);
       if (grp == 0 && chan_ok) st_vec<VEC>(a.ws_head + wsrow + c, acc);
     }
   }
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
         const int c = ct + slot * VEC;
         const bool chan_ok = c < c_hi;
         float acc[VEC];
-        accumulate_piece<VEC, GROUPED, UNI>(a, src, s_idx, s_w, pb - cb, eb - cb, c, chan_ok, grp, epg, acc);
+        accumulate_piece<VEC, GROUPED, UNI>(a, src, s_off, s_w, pb - cb, eb - cb, c, chan_ok, grp, epg, acc);
         if (grp == 0 && chan_ok) {
           if (whole) {
             if (a.mean) {
