@@ -48,14 +48,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # SG_BENCH_FORCE_DIST=1: take the partitioned (N > 1) code path -- RCCL init, barriers, all-reduces, partition
+    # crossings -- even with a single rank; development check of that path on a 1-GPU box.
+    dist_on = world > 1 or os.environ.get("SG_BENCH_FORCE_DIST") == "1"
     # SG_BENCH_BACKEND=gloo lets several ranks share ONE GPU (development check of the N > 1 code path on a 1-GPU
     # box); the real multi-GPU run uses nccl == RCCL with one rank per GPU.
     backend = os.environ.get("SG_BENCH_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -75,7 +81,7 @@ def main():
     csr = graph[U, I]
     n_user, n_item, E_total, R = csr.shape[0], csr.shape[1], csr.nnz, int(csr.multi_link.size)
     mean, std = float(vals.mean()), float(vals.std())
-    if world > 1:
+    if dist_on:
         lo, hi = SD.balanced_row_blocks(csr.ind_ptr, world)[rank]
         sub = S.user_block(graph, U, I, lo, hi)
         lgraph = HeterGraph({U: np.arange(hi - lo, dtype=np.int32), I: np.arange(n_item, dtype=np.int32)}, {(U, I): sub})
@@ -88,7 +94,7 @@ def main():
     D = args.dim
     net = M.Net(lgraph, U, I, embed_units=D, agg_units=(D, D), out_units=(D, D), nblocks=1, use_dae=False,
                 activation="leaky", dropout=0.0, agg_accum="sum", agg_order=args.order).to(dev)
-    if world > 1:
+    if dist_on:
         part = SD.NodePartition([U], [I])
         for enc in net.encoders:
             for layer in enc._blocks:
@@ -103,14 +109,14 @@ def main():
         preds, _, _ = net.run(plan)
         loss = (0.5 * (preds[0].view(-1) - y) ** 2).sum() / E_total
         loss.backward()
-        if world > 1:
+        if dist_on:
             SD.allreduce_grads(net.local_region_parameters())
         return loss
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     ops.gather_profile(True)      # HIP events around every gather launch, on the launch stream, inside the library
@@ -118,13 +124,13 @@ def main():
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.gather_profile(False)
     timeline = ops.gather_profile_read()
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -174,7 +180,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(graph, U, I, D, args)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

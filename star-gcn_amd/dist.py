@@ -23,6 +23,14 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _active():
+    """Collectives are issued when there is more than one rank -- or, for a development check of the RCCL code path
+    on a single GPU, when SG_BENCH_FORCE_DIST=1 initialised a one-rank group."""
+    import os
+    return (dist.is_available() and dist.is_initialized() and
+            (dist.get_world_size() > 1 or os.environ.get("SG_BENCH_FORCE_DIST") == "1"))
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -61,16 +69,16 @@ class _ReduceFromLocal(torch.autograd.Function):
 
 
 def copy_to_local(x):
-    return x if world() == 1 else _CopyToLocal.apply(x)
+    return _CopyToLocal.apply(x) if _active() else x
 
 
 def reduce_from_local(x):
-    return x if world() == 1 else _ReduceFromLocal.apply(x)
+    return _ReduceFromLocal.apply(x) if _active() else x
 
 
 def allreduce_grads(params):
     """Sum the gradients of local-region parameters over ranks through ONE flat buffer."""
-    if world() == 1:
+    if not _active():
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
