@@ -101,7 +101,9 @@ def main():
                 layer.partition = part
         net.pair_partition = part
     t_plan = time.perf_counter()
-    plan = net.make_plan(lgraph, rating_node_pairs=pairs, device=dev)
+    # every node of the (local) graph is computed, in natural order: index takes between levels are identities
+    plan = net.make_plan(lgraph, rating_node_pairs=pairs, device=dev,
+                         full_node_ids={k: lgraph.node_ids_dict[k] for k in (U, I)})
     t_plan = time.perf_counter() - t_plan
 
     def step():
