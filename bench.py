@@ -71,6 +71,7 @@ def main():
 
     import star_gcn_amd.dist as SD
     import star_gcn_amd.model as M
+    import star_gcn_amd.functional as SF
     import star_gcn_amd.ops as ops
     import star_gcn_amd.synthetic as S
     from star_gcn_amd.mxgraph.graph import HeterGraph
@@ -109,7 +110,7 @@ def main():
     def step():
         net.zero_grad(set_to_none=True)
         preds, _, _ = net.run(plan)
-        loss = (0.5 * (preds[0].view(-1) - y) ** 2).sum() / E_total
+        loss = SF.l2_loss(preds[0].view(-1), y, 1.0 / E_total)
         loss.backward()
         if dist_on:
             SD.allreduce_grads(net.local_region_parameters())

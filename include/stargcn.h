@@ -185,6 +185,12 @@ int sg_masked_embed_hip(float* out, const float* table, const int32_t* ids, cons
 int sg_resolve_ids_hip(int32_t* resolved, const int32_t* ids, const int32_t* noise, int64_t n_ids,
                        void* stream);
 
+/* rating loss of the reference (gluon L2Loss, STAR-GCN.py:550,612): *loss = scale * sum_i 0.5 (pred_i - target_i)^2 and,
+ * in the same pass, grad_i = scale * (pred_i - target_i) (grad may be NULL).  Two-pass fixed-order reduction. */
+size_t sg_l2_loss_workspace_bytes(int64_t n);
+int sg_l2_loss_hip(float* loss, float* grad, const float* pred, const float* target, int64_t n, float scale,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * (7) host graph helpers (reference GraphSampler/graph_sampler.cpp; `_cpu` = host pointers)
  * ---------------------------------------------------------------------------------------------- */

@@ -77,6 +77,8 @@ _SIGS = {
     "sg_take_plan_cpu": (_INT, [_P] * 6 + [_I64] * 2),
     "sg_mask_edges_workspace_bytes": (_SZ, [_I64] * 3),
     "sg_mask_edges_hip": (_INT, [_P, _P, _P, _c.c_int32] + [_P] * 5 + [_I64] * 4 + [_INT, _P, _SZ, _P]),
+    "sg_l2_loss_workspace_bytes": (_SZ, [_I64]),
+    "sg_l2_loss_hip": (_INT, [_P] * 4 + [_I64, _F32, _P, _SZ, _P]),
     "sg_gather_profile_enable": (_INT, [_INT]),
     "sg_gather_profile_read": (_I64, [_P, _P, _P, _I64]),
     "sg_multilink_agg_resolve_order": (_INT, [_P, _INT]),

@@ -113,3 +113,23 @@ def take_rows(table, take_plan):
     if take_plan.identity:
         return table
     return _TakeRows.apply(table, take_plan)
+
+
+class _L2Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, scale):
+        loss, grad = ops.l2_loss_fwd(pred, target, scale)
+        ctx.shape = pred.shape
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g).view(ctx.shape), None, None
+
+
+def l2_loss(pred, target, scale):
+    """scale * sum 0.5 (pred - target)^2 -- gluon L2Loss of the reference (STAR-GCN.py:550,612) with the reduction;
+    value and gradient come from one native pass (sg_l2_loss_hip).  `target` gets no gradient."""
+    return _L2Loss.apply(pred, target, scale)

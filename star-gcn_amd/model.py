@@ -252,7 +252,7 @@ def star_gcn_loss(pred_ratings, pred_embeddings, gt_embeddings, gt_ratings_std, 
     + recon_lambda * sum over blocks and keys of mean_nodes( sum_c (gt - pred)^2 ); the target is NOT detached."""
     loss = 0.0
     for pr in pred_ratings:
-        loss = loss + (0.5 * (pr.view(-1) - gt_ratings_std.view(-1)) ** 2).mean()
+        loss = loss + SF.l2_loss(pr.view(-1), gt_ratings_std.view(-1), 1.0 / max(pr.numel(), 1))
     for block in pred_embeddings:
         for key, pred in block.items():
             loss = loss + recon_lambda * ((gt_embeddings[key] - pred) ** 2).sum(dim=1).mean()

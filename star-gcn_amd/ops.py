@@ -277,3 +277,19 @@ def multilink_agg_bwd(dout, out, saved, x, weights, plan, accum, act, slope, ord
                                          _byref(st), D, upl, o, a, _act_id(act), float(slope), L.ptr(ws), wsn,
                                          L.stream_ptr()), "sg_multilink_agg_bwd_hip")
     return dx, dws, dbs
+
+
+def l2_loss_fwd(pred, target, scale):
+    """(loss scalar tensor, grad) with loss = scale * sum 0.5 (pred - target)^2, grad = scale * (pred - target)."""
+    L.require_gpu(pred, target)
+    pred, target = L.f32c(pred).reshape(-1), L.f32c(target).reshape(-1)
+    n = pred.numel()
+    if target.numel() != n:
+        raise L.StarGCNError("l2_loss: %d predictions vs %d targets" % (n, target.numel()))
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred)
+    lib = L.lib()
+    ws, wsn = L.workspace(lib.sg_l2_loss_workspace_bytes(n), pred.device)
+    L.check(lib.sg_l2_loss_hip(L.ptr(loss), L.ptr(grad), L.ptr(pred), L.ptr(target), n, float(scale), L.ptr(ws), wsn,
+                               L.stream_ptr()), "sg_l2_loss_hip")
+    return loss, grad

@@ -270,3 +270,20 @@ def test_fused_aggregator_properties_at_ml10m_size():
     rowsum = plan.rowsum                                                            # (n_dst, R) sum of supports per level
     expect = rowsum @ torch.stack(bs)                                               # plumbing-level check, fp32
     assert float((only_bias - expect).abs().max()) <= 1e-5 * float(expect.abs().max())
+
+
+@pytest.mark.parametrize("n", [1, 255, 100003, 3000000])
+def test_l2_loss_value_and_gradient(n):
+    """sg_l2_loss_hip: scale * sum 0.5 (x - y)^2 and its gradient in one pass (gluon L2Loss + mean of the reference)."""
+    from star_gcn_amd import functional as F
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g)
+    y = torch.randn(n, generator=g)
+    xd = x.cuda().requires_grad_(True)
+    loss = F.l2_loss(xd, y.cuda(), 1.0 / n)
+    (3.0 * loss).backward()
+    ref = (0.5 * (x.double() - y.double()) ** 2).mean()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * float(ref) + 1e-12
+    rel_close(xd.grad, 3.0 * (x.double() - y.double()) / n, 1e-6, "grad")
+    again = F.l2_loss(x.cuda(), y.cuda(), 1.0 / n)
+    assert float(again) == float(loss)          # fixed-order reduction: bit-reproducible
