@@ -29,7 +29,10 @@ namespace sg {
 #ifndef SG_GATHER_DEFAULT_SLICES
 #define SG_GATHER_DEFAULT_SLICES 4
 #endif
-constexpr int kChunk = 256;  // edges per wavefront
+#ifndef SG_GATHER_CHUNK
+#define SG_GATHER_CHUNK 256
+#endif
+constexpr int kChunk = SG_GATHER_CHUNK;  // edges per wavefront
 constexpr int kPtrTile = 64; // CSR row pointers staged in LDS per refill
 
 struct GatherArgs {
