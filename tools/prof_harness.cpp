@@ -143,6 +143,50 @@ int main(int argc, char** argv) {
     }
     printf("overlap: gather + gemm serial %.3f ms, on two streams %.3f ms\n", serial / reps, par / reps);
   }
+  // ---- same pair on CU-MASKED streams: the gather gets `gcu` CUs (spread evenly over the 8 XCDs), the GEMM the rest ----
+  for (int gemm_per_xcd : {4, 6, 8, 12, 16}) {
+    // physical layout assumption: CU index c -> XCD c % 8 (round-robin across XCDs in the mask bit order)
+    const int total_cu = 256;
+    std::vector<uint32_t> mg(total_cu / 32, 0u), mm(total_cu / 32, 0u);
+    for (int c = 0; c < total_cu; ++c) {
+      const bool to_gemm = (c / 8) < gemm_per_xcd;        // the first gemm_per_xcd CUs of every XCD
+      (to_gemm ? mm : mg)[c / 32] |= 1u << (c % 32);
+    }
+    hipStream_t sa, sb;
+    if (hipExtStreamCreateWithCUMask(&sa, mg.size(), mg.data()) != hipSuccess ||
+        hipExtStreamCreateWithCUMask(&sb, mm.size(), mm.data()) != hipSuccess) {
+      printf("CU-masked streams unavailable\n");
+      break;
+    }
+    void* ws2;
+    CK(hipMalloc(&ws2, wsb + 16));
+    hipEvent_t f0, f1, g1;
+    CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1)); CK(hipEventCreate(&g1));
+    float par = 0, galone = 0, malone = 0;
+    for (int it = 0; it < reps + 1; ++it) {
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(f0, sa));
+      SG(sg_seg_gather_sum_hip(d_out, 1, D, d_h, R, (int64_t)R * D, d_w, d_q, d_dip, n_dst, nnz, D, SG_REQ_WRITE,
+                               SG_ACT_LEAKY, 0.1f, ws2, wsb + 16, sa));
+      CK(hipEventRecord(f1, sa)); CK(hipEventSynchronize(f1)); CK(hipEventElapsedTime(&ms, f0, f1)); if (it) galone += ms;
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(f0, sb));
+      SG(sg_gemm_f32_hip(d_pre, D, d_zext, ld, 0, d_wext, ld, 1, n_dst, D, ld, nullptr, SG_ACT_LEAKY, 0.1f, 0, nullptr, 0, sb));
+      CK(hipEventRecord(f1, sb)); CK(hipEventSynchronize(f1)); CK(hipEventElapsedTime(&ms, f0, f1)); if (it) malone += ms;
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(f0, sa));
+      CK(hipStreamWaitEvent(sb, f0, 0));
+      SG(sg_seg_gather_sum_hip(d_out, 1, D, d_h, R, (int64_t)R * D, d_w, d_q, d_dip, n_dst, nnz, D, SG_REQ_WRITE,
+                               SG_ACT_LEAKY, 0.1f, ws2, wsb + 16, sa));
+      SG(sg_gemm_f32_hip(d_pre, D, d_zext, ld, 0, d_wext, ld, 1, n_dst, D, ld, nullptr, SG_ACT_LEAKY, 0.1f, 0, nullptr, 0, sb));
+      CK(hipEventRecord(g1, sb));
+      CK(hipStreamWaitEvent(sa, g1, 0));
+      CK(hipEventRecord(f1, sa)); CK(hipEventSynchronize(f1)); CK(hipEventElapsedTime(&ms, f0, f1)); if (it) par += ms;
+    }
+    printf("cu-mask: gemm %3d CUs / gather %3d CUs: gather alone %.3f ms, gemm alone %.3f ms, concurrent %.3f ms\n",
+           gemm_per_xcd * 8, total_cu - gemm_per_xcd * 8, galone / reps, malone / reps, par / reps);
+    CK(hipStreamDestroy(sa)); CK(hipStreamDestroy(sb));
+  }
   const double bytes = (8.0 + 4.0 * D) * nnz;
   printf("n_dst %lld n_src %lld nnz %lld R %d D %d reps %d\n", (long long)n_dst, (long long)n_src, (long long)nnz, R, D, reps);
   printf("gather transform-first : %.3f ms  %.1f GB/s algorithmic\n", ms_tf / reps, bytes / (ms_tf / reps) / 1e6);
