@@ -23,12 +23,13 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+_FORCE_ONE_RANK = __import__("os").environ.get("SG_BENCH_FORCE_DIST") == "1"   # read once: this sits on the hot path
+
+
 def _active():
     """Collectives are issued when there is more than one rank -- or, for a development check of the RCCL code path
     on a single GPU, when SG_BENCH_FORCE_DIST=1 initialised a one-rank group."""
-    import os
-    return (dist.is_available() and dist.is_initialized() and
-            (dist.get_world_size() > 1 or os.environ.get("SG_BENCH_FORCE_DIST") == "1"))
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_ONE_RANK)
 
 
 def rank():
