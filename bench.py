@@ -162,6 +162,9 @@ def main():
                          "gathered matrices (%d-%d MB) exceed the 256 MB Infinity Cache: HBM-bound") %
                         (max(n_user, n_item) * D * 4 // 2 ** 20, min(n_user, n_item) * R * D * 4 // 2 ** 20)}
 
+    loss_total = loss.detach().clone()
+    if dist_on:      # every rank holds its users' share of the loss; report the whole (outside the timed region)
+        loss_total = SD.all_reduce_sum(loss_total.view(1))[0]
     ms = elapsed / args.steps * 1e3
     value = E_total / (elapsed / args.steps)
     out = {
@@ -175,7 +178,7 @@ def main():
                                                                                           E_total, R, D),
                    "partition": "single GPU" if world == 1 else "1-D user-block node partition, items replicated, "
                                 "RCCL all-reduce of item-side partials", "order": args.order,
-                   "plan_build_s": round(t_plan, 2), "loss": float(loss.detach())},
+                   "plan_build_s": round(t_plan, 2), "loss": float(loss_total)},
         "roofline": roof,
         "step_roofline_frac": value * 8 * (8 + 4 * D) / (world * HBM_PEAK),
     }
