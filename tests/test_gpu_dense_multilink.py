@@ -287,3 +287,48 @@ def test_l2_loss_value_and_gradient(n):
     rel_close(xd.grad, 3.0 * (x.double() - y.double()) / n, 1e-6, "grad")
     again = F.l2_loss(x.cuda(), y.cuda(), 1.0 / n)
     assert float(again) == float(loss)          # fixed-order reduction: bit-reproducible
+
+
+@pytest.mark.skipif(__import__("os").environ.get("SG_TEST_STRESS") != "1",
+                    reason="opt-in (SG_TEST_STRESS=1): ~2 min, 60 M edges, 16 levels, multi-GB matrices")
+def test_fused_aggregator_properties_at_hbm_stress_size():
+    """The HBM-bound stress shape (600 k users x 500 k items, 60 M ratings, 16 levels, dim 256; every gathered matrix
+    0.5 - 8 GB, element offsets beyond 2^31): association orders agree, adjoint identity through autograd, and a
+    float64 spot check of individual output rows against the definition."""
+    import star_gcn_amd.synthetic as S
+    from star_gcn_amd import functional as F
+    from star_gcn_amd.plan import MultiLinkPlan
+    graph, eu, ei, vals = S.make_graph("hbm-stress")
+    m = graph["movie", "user"]                      # destination = items: the R-expanded matrices are the 8 GB ones
+    eps, _, ips, sps = m.sample_neighbors(symm=True, use_multi_link=True, num_neighbors=-1)
+    plan = MultiLinkPlan(eps, ips, sps, m.shape[1], "cuda")
+    R, D, U = plan.R, 256, 256
+    assert R == 16 and plan.nnz == m.nnz and plan.n_dst * R * D * 4 > 2 ** 32
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(plan.n_src, D, device="cuda", generator=g) * 0.1
+    ws = [torch.randn(U, D, device="cuda", generator=g) * (3.0 / D) ** 0.5 for _ in range(R)]
+    bs = [torch.randn(U, device="cuda", generator=g) * 0.1 for _ in range(R)]
+    outs = {}
+    for order in ("transform_first", "aggregate_first"):
+        xg = x.clone().requires_grad_(True)
+        out = F.multilink_aggregate(xg, ws, bs, plan, accum="sum", act=None, order=order)
+        y = torch.randn(plan.n_dst, U, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+        out.backward(y)
+        const = F.multilink_aggregate(torch.zeros_like(x), ws, bs, plan, accum="sum", act=None, order=order)
+        lhs = float(((out.detach() - const).double() * y.double()).sum())
+        rhs = float((xg.grad.double() * x.double()).sum())
+        assert abs(lhs - rhs) <= 2e-5 * max(1.0, abs(lhs)), (order, lhs, rhs)
+        outs[order] = out.detach()
+    a, b = outs["transform_first"], outs["aggregate_first"]
+    assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+    # float64 definition on a few destination rows, incl. the last one (largest offsets)
+    c_indptr, c_idx, c_w = plan.c_indptr.cpu().numpy(), plan.c_idx.cpu().numpy(), plan.c_w.cpu().numpy()
+    xd = x.double().cpu()
+    for i in (0, 12345, plan.n_dst // 2, plan.n_dst - 1):
+        ref = torch.zeros(U, dtype=torch.float64)
+        for r in range(R):
+            lo, hi = c_indptr[i * R + r], c_indptr[i * R + r + 1]
+            if hi > lo:
+                z = (torch.from_numpy(c_w[lo:hi]).double()[:, None] * xd[c_idx[lo:hi]]).sum(0)
+                ref += ws[r].double().cpu() @ z + float(c_w[lo:hi].astype(np.float64).sum()) * bs[r].double().cpu()
+        assert float((a[i].double().cpu() - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1e-3), i
