@@ -133,7 +133,10 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
   int e = ea + grp;
-  constexpr int U = 4;
+#ifndef SG_GATHER_U
+#define SG_GATHER_U 4
+#endif
+  constexpr int U = SG_GATHER_U;   // rows in flight per edge group (2 / 4 / 8 measured equal on the unsliced path)
   for (; e + (U - 1) * epg < eb; e += U * epg) {
     float x[U][VEC];
     float wv[U];
