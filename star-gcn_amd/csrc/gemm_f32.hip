@@ -325,6 +325,10 @@ static void plan_split(int64_t M, int64_t N, int64_t K, int* splits, int* tiles_
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
   }
+  if (const char* e = getenv("SG_GEMM_SPLITS")) {   // tuning aid
+    const int64_t v = atoll(e);
+    if (v >= 1 && v <= ktiles) s = v;
+  }
   int64_t per = (ktiles + s - 1) / s;
   if (per < 1) per = 1;
   s = (ktiles + per - 1) / per;
