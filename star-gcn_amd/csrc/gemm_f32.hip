@@ -14,8 +14,9 @@
 // operands are staged in LDS K-MAJOR ([k][m] / [k][n]) so that an MFMA operand read is 32 consecutive
 // floats per half-wave (bank-conflict free) whatever the global layout; K-contiguous global operands are
 // transposed on the way in (LDS leading dim 129 makes those b32 stores conflict-free), M/N-contiguous ones
-// are copied with b128 stores (leading dim 132).  Global loads of tile t+1 are issued before the MFMAs of
-// tile t and written to the other LDS buffer afterwards: one barrier per K tile.  Workgroups are remapped so
+// are copied with b128 stores (leading dim 132).  Two register staging sets keep the global loads of K tiles t+1
+// and t+2 in flight while tile t is multiplied; a staged tile is written to the other LDS buffer after the MFMAs of
+// the tile before it: one barrier per K tile.  A 64-row tile variant (32x64 per wave) fills the chip better when M*N is small.  Workgroups are remapped so
 // that the tiles sharing an A row-panel run on the same XCD (private 4 MiB L2 each).  Small-tile-count /
 // large-K problems (weight gradients: K = #nodes) use deterministic split-K through a workspace.
 #include <cmath>

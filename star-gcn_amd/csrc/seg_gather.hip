@@ -12,13 +12,15 @@
 //   * work unit = a CHUNK of 256 consecutive edges handled by ONE 64-lane wavefront (one wave per
 //     workgroup, so the only synchronisation is wave-local).  Edge-balanced: a 35k-edge hub row is split
 //     over ~140 waves, a run of 14-edge rows shares one wave.  No atomics, deterministic.
-//   * the chunk's (index, weight) pairs are loaded once, coalesced, into LDS; the CSR row-pointer tile of
-//     the segments that start in the chunk is staged in LDS 64 pointers at a time.
+//   * the chunk's (source-row offset, weight) pairs are computed/loaded once, coalesced, into LDS; the CSR
+//     row-pointer tile of the segments that start in the chunk is staged in LDS 64 pointers at a time.
 //   * each gathered neighbour row is read as ONE coalesced burst: lanes hold VEC consecutive floats
 //     (float4 -> 1 KiB per wave instruction at C = 256).  For narrow rows (C*4 < 1 KiB) the wave splits
 //     into 64/LPR edge groups that gather different edges concurrently and combine with __shfl_xor.
 //   * segments that straddle a chunk boundary write fp32 partial rows to a workspace; a tiny second
 //     kernel adds the partials of each such segment in chunk order.
+//   * XCD column slicing (cache-resident sources): XCD i only touches the 256-byte column slice i % 4 of every source
+//     row, so its private 4 MB L2 faces a 4x smaller working set (L2 hit 7 % -> 25 % on a 109 MB source).
 #include "common.hpp"
 
 #include <mutex>
