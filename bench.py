@@ -178,7 +178,8 @@ def main():
                                                                                           E_total, R, D),
                    "partition": "single GPU" if world == 1 else "1-D user-block node partition, items replicated, "
                                 "RCCL all-reduce of item-side partials", "order": args.order,
-                   "plan_build_s": round(t_plan, 2), "loss": float(loss_total)},
+                   "plan_build_s": round(t_plan, 2), "loss": float(loss_total),
+                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
         "roofline": roof,
         "step_roofline_frac": value * 8 * (8 + 4 * D) / (world * HBM_PEAK),
     }
