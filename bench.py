@@ -168,7 +168,7 @@ def main():
     ms = elapsed / args.steps * 1e3
     value = E_total / (elapsed / args.steps)
     out = {
-        "metric": "edges/sec (fwd+bwd) 2-layer multi-link GCN, ML-10M shape",
+        "metric": "edges/sec (fwd+bwd) 2-layer multi-link GCN, ML-10M shape, 1/2/4/8 GPU + %HBM roofline",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
