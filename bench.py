@@ -208,8 +208,12 @@ def cpu_baseline(graph, U, I, D, args):
     lv["pairs"] = (sub.end_points, sub.ind_ptr, None)
     C.run_cpu_step(lv, n_u, csr.shape[1], D, steps=1)     # warm-up (page-in, BLAS threads)
     sec = C.run_cpu_step(lv, n_u, csr.shape[1], D, steps=args.cpu_steps)
+    sec_fair = C.run_cpu_step(lv, n_u, csr.shape[1], D, steps=1, fair=True)   # backward parallel over rows (transposed CSR)
     info = C.host_info()
     return {"value": sub.nnz / sec, "unit": "edges/s", "cores": info["logical_cores"], "kind": "port",
+            "fair_value": sub.nnz / sec_fair,
+            "fair_note": "same port with the data-gradient kernel parallelised over destination rows through the "
+                         "transposed CSR (the reference runs it serially for K = 1, seg_op.cc:232-233)",
             "sample": "users [0,%d) x all %d items = %d ratings of the same graph, %d step(s), %.2f s/step; seg ops = C "
                       "restatement of reference seg_op.cc CPU kernels (reference OpenMP placement: forward over rows, "
                       "backward serial), dense = torch-CPU BLAS standing in for MXNet FullyConnected" %

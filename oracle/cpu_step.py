@@ -82,7 +82,7 @@ def run_cpu_step(levels, n_user, n_item, D, steps=1, fair=False, seed=0):
         pred = (pu[seg_of] * pi[items_of]).sum(dim=1)
         loss = (0.5 * (pred - y) ** 2).mean()
         loss.backward()
-        return float(loss)
+        return float(loss.detach())
 
     t0 = time.perf_counter()
     for _ in range(steps):
