@@ -230,7 +230,8 @@ int sg_sample_fix_neighbor_cpu(int32_t* sampled, int32_t* dst_ind_ptr, const int
 /* gen_row_indices_by_indptr  py_ext.cpp:612-627 / graph.py:83-99: COO row index of every edge */
 int sg_gen_row_indices_cpu(int32_t* row_indices, const int32_t* ind_ptr, int64_t row_num, int64_t nnz);
 /* host side of the per-batch index plans (resident training loop) */
-/* edge id (CSR position) of every (row index, col index) pair, -1 when it is not an edge; rows sorted by column */
+/* edge id (CSR position) of every (row index, col index) pair, -1 when it is not an edge; rows sorted by column.
+ * Reference counterpart: the scipy fancy-index lookup of CSRMat.fetch_edges_by_ind (graph.py:595-613). */
 int sg_edge_positions_cpu(int32_t* pos, const int32_t* end_points, const int32_t* ind_ptr, int64_t row_num,
                           const int32_t* rows, const int32_t* cols, int64_t n);
 /* rating-head plan: batch pairs grouped by user (stable) + the stable transpose by item; arrays of n_pairs entries,
@@ -238,8 +239,9 @@ int sg_edge_positions_cpu(int32_t* pos, const int32_t* end_points, const int32_t
 int sg_pair_plan_cpu(int32_t* order, int32_t* inv_order, int32_t* indptr, int32_t* items, int32_t* t_indptr,
                      int32_t* t_pos, int32_t* t_seg, int32_t* identity, const int32_t* user_idx,
                      const int32_t* item_idx, int64_t n_pairs, int64_t n_user, int64_t n_item);
-/* row-take plan: flags bit 0 identity, bit 1 every row taken at most once (inv_ids valid); t_indptr n_rows+1,
- * t_pos n, inv_ids n_rows */
+/* row-take plan for the `take` ops of the path (reference layers.py:360,382 heter_sage; STAR-GCN.py:264-300,440-459)
+ * and their atomic-free gradients: flags bit 0 identity, bit 1 every row taken at most once (inv_ids valid);
+ * t_indptr n_rows+1, t_pos n, inv_ids n_rows */
 int sg_take_plan_cpu(int32_t* t_indptr, int32_t* t_pos, int32_t* inv_ids, int32_t* flags, int64_t* covered,
                      const int32_t* ids, int64_t n, int64_t n_rows);
 
