@@ -2,28 +2,80 @@
 """Benchmark of the STAR-GCN hot path on MI355X: edges/sec for forward+backward of a 2-layer multi-link GCN on a
 MovieLens-10M-SHAPED synthetic bipartite graph (BASELINE.json metric; workload definition SURVEY.md section 8d).
 
-  python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank/GPU)
+  python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: `python bench.py --gpus N` starts the N ranks itself (one process per GPU, RCCL); it is equally happy to be
+started as a rank by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / WORLD_SIZE in
+the environment).  Rank 0 prints ONE JSON line.
 
 One step = embedding gather -> 2 stacked HeterGCNLayers (both node types, all rating levels, full neighbourhood)
--> rating head over ALL ratings -> loss -> full backward to every parameter and the embedding tables.  Plans are
-built once outside the timed region (inputs resident in HBM).  Prints ONE JSON line with `roofline` (dominant
-kernel = seg_gather_kernel, timed with HIP events on the launch stream) and `cpu_baseline` (oracle port timed on
-this host, N = 1 only).
+-> rating head over ALL ratings -> loss -> full backward to every parameter and the embedding tables.  The graph is
+uploaded once and every plan is built ON the device (csrc/plan_build.hip) outside the timed region.
+
+Legs of the default (N = 1) run, all in the same process and reported in the same JSON line:
+  value / ms_per_step   the ML-10M-shaped step (BASELINE config 4 on one GPU)
+  roofline              dominant kernel (seg_gather_kernel) of that step.  At this shape every gathered matrix sits in
+                        the 256 MB Infinity Cache, so the ceiling is NOT HBM: it is measured in the same run with a
+                        best-case streaming read of the same launch geometry (Infinity-Cache-resident and L2-resident
+                        buffers) and combined with the kernel's L2 hit rate (PMC, profiles/)
+  hbm_bound             the one-GPU shard of BASELINE config 5 (1.25 M users x 1 M items, 125 M ratings, 16 levels,
+                        dim 256; built on the device): every gathered matrix is 1-16 GB, the gather is HBM-bound and is
+                        priced against the 8 TB/s HBM peak
+  cpu_baseline          the oracle port of the reference CPU path on this host's physical cores
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+
+def _physical_cores():
+    cores, phys, core = set(), None, None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    return len(cores) or (os.cpu_count() or 1)
+
+
+def _argv_gpus():
+    for k, a in enumerate(sys.argv[1:]):
+        if a == "--gpus" and k + 2 < len(sys.argv):
+            return int(sys.argv[k + 2])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+if int(os.environ.get("WORLD_SIZE", "1")) == 1 and _argv_gpus() == 1:
+    # single-process run: the CPU baseline uses one OpenMP thread per PHYSICAL core, pinned (must be set before the
+    # OpenMP runtime is loaded, i.e. before `import torch`); multi-rank runs leave the host threading alone
+    os.environ.setdefault("OMP_NUM_THREADS", str(_physical_cores()))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
 HBM_PEAK = 8.0e12  # bytes/s, MI355X spec (/opt/skills/guides/MI355X_MICROARCH.md)
+METRIC = "edges/sec (fwd+bwd) 2-layer multi-link GCN, ML-10M shape, 1/2/4/8 GPU + %HBM roofline"
+U, I = "user", "movie"
 
 
 def parse():
@@ -35,13 +87,185 @@ def parse():
     p.add_argument("--dim", type=int, default=256)
     p.add_argument("--order", default="auto", choices=["auto", "transform_first", "aggregate_first"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-user-frac", type=float, default=0.125, help="share of users in the CPU-baseline sample")
-    p.add_argument("--cpu-steps", type=int, default=2)
+    p.add_argument("--no-hbm-leg", action="store_true")
+    p.add_argument("--no-ceiling", action="store_true")
+    p.add_argument("--hbm-only", action="store_true", help="run only the HBM-bound leg (profiling)")
+    p.add_argument("--hbm-steps", type=int, default=3)
+    p.add_argument("--hbm-shape", default="1250000,1000000,125000000,16",
+                   help="n_user,n_item,n_edges,n_levels of the HBM-bound leg (default: 1-GPU shard of BASELINE config 5)")
+    p.add_argument("--cpu-sample-users", type=float, default=1.0, help="share of users in the CPU-baseline sample")
     return p.parse_args()
 
 
-def main():
-    args = parse()
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves
+# ---------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SG_BENCH_SELF_LAUNCHED="1")
+        env.pop("OMP_PROC_BIND", None)
+        env.pop("OMP_PLACES", None)
+        env["OMP_NUM_THREADS"] = str(max(1, _physical_cores() // max(args.gpus, 1)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+            if p.returncode != 0:        # one rank died: the others would wait in a collective for ever
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def build_net(graph_like, D, order, dev, part=None):
+    import star_gcn_amd.model as M
+    net = M.Net(graph_like, U, I, embed_units=D, agg_units=(D, D), out_units=(D, D), nblocks=1, use_dae=False,
+                activation="leaky", dropout=0.0, agg_accum="sum", agg_order=order).to(dev)
+    if part is not None:
+        for enc in net.encoders:
+            for layer in enc._blocks:
+                layer.partition = part
+        net.pair_partition = part
+    return net
+
+
+def timed_steps(step, steps, warmup, dev, dist_on):
+    import torch.distributed as dist
+    import star_gcn_amd.dist as SD
+    import star_gcn_amd.ops as ops
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.gather_profile(True)      # HIP events around every gather launch, on the launch stream, inside the library
+    SD.STATS.reset()
+    SD.STATS.enabled = dist_on
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.gather_profile(False)
+    SD.STATS.enabled = False
+    return elapsed, loss, ops.gather_profile_read()
+
+
+def gather_roofline(timeline, E_local, D, steps):
+    """average HIP-event time of the aggregation launches (width D over all local edges) -> algorithmic rate"""
+    agg = [(t, nnz, C) for t, nnz, C in timeline if C == D and nnz == max(E_local, 1) and t > 0]
+    if not agg:
+        return None
+    avg = sum(t for t, _, _ in agg) / len(agg)
+    bytes_per_launch = (8 + 4 * D) * E_local          # SURVEY 8(d): idx + support + one fp32 row per edge visit
+    return {"kernel": "seg_gather_kernel", "achieved": bytes_per_launch / avg / 1e9, "unit": "GB/s",
+            "launches_per_step": len(agg) / steps, "avg_launch_ms": avg * 1e3,
+            "algorithmic_bytes_per_launch": bytes_per_launch}
+
+
+def measure_stream_ceiling(dev, n_bytes, workgroups, min_total=4e9):
+    """best-case streaming read (sg_stream_read_hip: the gather's launch geometry, perfectly regular addresses) of a
+    resident buffer of n_bytes -> GB/s, HIP events on the current stream; the first pass only warms the caches"""
+    from star_gcn_amd import _lib as L
+    lib = L.lib()
+    buf = torch.empty(n_bytes // 4, dtype=torch.float32, device=dev).normal_()
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    passes = max(2, int(min_total // n_bytes))
+    st = L.stream_ptr()
+    L.check(lib.sg_stream_read_hip(L.ptr(buf), n_bytes, 2, workgroups, L.ptr(sink), st), "sg_stream_read_hip")
+    best = 0.0
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.sg_stream_read_hip(L.ptr(buf), n_bytes, passes, workgroups, L.ptr(sink), st), "sg_stream_read_hip")
+        e1.record()
+        e1.synchronize()
+        best = max(best, n_bytes * passes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    return best
+
+
+def profile_record(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(name)
+    except (OSError, ValueError):
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def hbm_leg(args, dev):
+    """BASELINE config 5 on ONE GPU of the 8: 1.25 M users x 1 M items, >= 125 M ratings, 16 levels, dim 256.  Graph,
+    degrees, support, transposed CSR and both multi-link plans are generated / built on the device."""
+    import star_gcn_amd.functional as SF
+    from star_gcn_amd.device_graph import synthetic_device_graph
+    nu, ni, ne, R = (int(x) for x in args.hbm_shape.split(","))
+    D = args.dim
+    t0 = time.perf_counter()
+    dg = synthetic_device_graph(nu, ni, ne, R, dev, seed=5)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    torch.manual_seed(4321)
+    net = build_net(dg, D, args.order, dev)
+    plan = net.make_plan_device(dg)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter() - t0
+    vals = dg.values()
+    y = ((vals - vals.mean()) / vals.std()).contiguous()
+    del vals
+    E = dg.nnz
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        preds, _, _ = net.run(plan)
+        loss = SF.l2_loss(preds[0].view(-1), y, 1.0 / E)
+        loss.backward()
+        return loss
+
+    elapsed, loss, timeline = timed_steps(step, args.hbm_steps, 1, dev, False)
+    roof = gather_roofline(timeline, E, D, args.hbm_steps)
+    src_small = min(nu, ni) * D * 4
+    out = {"workload": "1-GPU shard of BASELINE config 5 (10 M x 1 M nodes / 1 B edges over 8 GPUs): %d users x %d items, "
+                       "%d ratings, %d rating levels, dim %d; same 2-layer network, fwd+bwd; graph generated and planned "
+                       "on the device" % (nu, ni, E, R, D),
+           "steps": args.hbm_steps, "warmup": 1, "ms_per_step": elapsed / args.hbm_steps * 1e3,
+           "edges_per_s": E / (elapsed / args.hbm_steps), "loss": float(loss),
+           "graph_gen_s": round(t_gen, 2), "plan_build_s": round(t_plan, 2),
+           "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+           "smallest_gathered_matrix_mb": src_small // 2 ** 20}
+    if roof:
+        rec = profile_record("hbm-config5-shard:%d" % D)
+        roof.update(bound="hbm", peak=HBM_PEAK / 1e9, frac=roof["achieved"] * 1e9 / HBM_PEAK,
+                    traffic=(rec["traffic_bytes_per_launch_mean"] * (E / rec["edges_per_launch"]) if rec else None),
+                    traffic_source=(rec.get("source") if rec else None))
+        out["roofline"] = roof
+        out["step_roofline_frac"] = out["edges_per_s"] * 8 * (8 + 4 * D) / HBM_PEAK
+    del net, plan, dg, y
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_rank(args):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -70,41 +294,39 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
     import star_gcn_amd.dist as SD
-    import star_gcn_amd.model as M
     import star_gcn_amd.functional as SF
-    import star_gcn_amd.ops as ops
+    import star_gcn_amd.model as M
     import star_gcn_amd.synthetic as S
+    from star_gcn_amd.device_graph import DeviceBipartite
     from star_gcn_amd.mxgraph.graph import HeterGraph
 
-    U, I = "user", "movie"
-    torch.manual_seed(1234)  # identical replicated parameters on every rank
+    if args.hbm_only:
+        out = {"metric": METRIC, "hbm_bound": hbm_leg(args, dev)}
+        print(json.dumps(out))
+        return
+
     graph, eu, ei, vals = S.make_graph(args.shape)
     csr = graph[U, I]
     n_user, n_item, E_total, R = csr.shape[0], csr.shape[1], csr.nnz, int(csr.multi_link.size)
     mean, std = float(vals.mean()), float(vals.std())
+    lo, hi = 0, n_user
     if dist_on:
         lo, hi = SD.balanced_row_blocks(csr.ind_ptr, world)[rank]
-        sub = S.user_block(graph, U, I, lo, hi)
+        sub = S.user_block(graph, U, I, lo, hi)       # this rank's users x ALL items, GLOBAL item degrees for the support
         lgraph = HeterGraph({U: np.arange(hi - lo, dtype=np.int32), I: np.arange(n_item, dtype=np.int32)}, {(U, I): sub})
     else:
         lgraph, sub = graph, csr
-    pairs = np.stack([sub.edge_row_indices, sub.end_points])
     E_local = sub.nnz
     y = torch.from_numpy(((sub.values - mean) / std).astype(np.float32)).to(dev)
 
     D = args.dim
-    net = M.Net(lgraph, U, I, embed_units=D, agg_units=(D, D), out_units=(D, D), nblocks=1, use_dae=False,
-                activation="leaky", dropout=0.0, agg_accum="sum", agg_order=args.order).to(dev)
-    if dist_on:
-        part = SD.NodePartition([U], [I])
-        for enc in net.encoders:
-            for layer in enc._blocks:
-                layer.partition = part
-        net.pair_partition = part
+    part = SD.NodePartition([U], [I]) if dist_on else None
+    torch.manual_seed(1234)
+    net = build_net(lgraph, D, args.order, dev, part)
     t_plan = time.perf_counter()
-    # every node of the (local) graph is computed, in natural order: index takes between levels are identities
-    plan = net.make_plan(lgraph, rating_node_pairs=pairs, device=dev,
-                         full_node_ids={k: lgraph.node_ids_dict[k] for k in (U, I)})
+    dgraph = DeviceBipartite.from_host(lgraph, U, I, dev)     # one upload of the CSR; every plan is built on the device
+    plan = net.make_plan_device(dgraph)
+    torch.cuda.synchronize()
     t_plan = time.perf_counter() - t_plan
 
     def step():
@@ -116,59 +338,69 @@ def main():
             SD.allreduce_grads(net.local_region_parameters())
         return loss
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ops.gather_profile(True)      # HIP events around every gather launch, on the launch stream, inside the library
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ops.gather_profile(False)
-    timeline = ops.gather_profile_read()
+    step()      # materialises the lazily-shaped parameters ...
+    # ... which are then re-drawn by parameter NAME: identical replicated parameters on every rank, equal to the N = 1
+    # model's, whatever the rank-local row counts and the order of first use (user table = rows [lo, hi) of the global one)
+    M.deterministic_init(net, 1234, {U: (lo, hi, n_user), I: (0, n_item, n_item)})
+    if dist_on and world > 1:      # replicas must agree bit for bit: check once
+        skip = "embed_layers._layers.%d." % net.embed_layers._key2idx[U]        # the row-sharded user table
+        rep = [p.detach().double().sum() for n_, p in net.named_parameters() if skip not in n_]
+        chk = torch.stack(rep)
+        mx, mn = chk.clone(), chk.clone()
+        if backend == "gloo":
+            mx, mn = mx.cpu(), mn.cpu()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        assert torch.equal(mx, mn), "replicated parameters differ between ranks"
+
+    elapsed, loss, timeline = timed_steps(step, args.steps, args.warmup, dev, dist_on)
+    comm = SD.STATS.read() if dist_on else None
     if dist_on:
         tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- roofline of the dominant kernel (aggregation launches: width D over all local edges) ----------
-    agg = [(t, nnz, C) for t, nnz, C in timeline if C == D and nnz == max(E_local, 1) and t > 0]
-    roof = None
-    if agg:
-        avg = sum(t for t, _, _ in agg) / len(agg)
-        bytes_per_launch = (8 + 4 * D) * E_local          # idx + support + one fp32 row per edge visit
-        ach = bytes_per_launch / avg
-        traffic = None   # PMC bytes per launch come from separate rocprofv3 --pmc passes (committed summary)
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                rec = json.load(f).get("%s:%d" % (args.shape, D))
-            if rec and world == 1:
-                traffic = rec["traffic_bytes_per_launch_mean"] * (E_local / rec["edges_per_launch"])
-        except (OSError, ValueError, KeyError):
-            pass
-        roof = {"bound": "hbm", "kernel": "seg_gather_kernel", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic, "launches_per_step": len(agg) / args.steps,
-                "avg_launch_ms": avg * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
-                "note": ("gathered matrices (%d-%d MB) fit the 256 MB Infinity Cache at this shape: the rate is a die-level "
-                         "fabric rate (PMC traffic in profiles/), the HBM-bound case is --shape hbm-stress"
-                         if max(max(n_user, n_item) * D * 4, min(n_user, n_item) * R * D * 4) < 256 * 2 ** 20 else
-                         "gathered matrices (%d-%d MB) exceed the 256 MB Infinity Cache: HBM-bound") %
-                        (max(n_user, n_item) * D * 4 // 2 ** 20, min(n_user, n_item) * R * D * 4 // 2 ** 20)}
+    # ---- roofline of the dominant kernel ---------------------------------------------------------------------------
+    roof = gather_roofline(timeline, E_local, D, args.steps)
+    src_mb = sorted((max(hi - lo, 1) * D * 4 // 2 ** 20, n_item * D * 4 // 2 ** 20,
+                     min(hi - lo, n_item) * R * D * 4 // 2 ** 20))
+    cache_resident = src_mb[-1] * 2 ** 20 < 200 * 2 ** 20
+    if roof:
+        roof["hbm_equiv_frac"] = roof["achieved"] * 1e9 / HBM_PEAK     # secondary: algorithmic bytes over the HBM peak
+        roof["gathered_matrices_mb"] = src_mb
+        rec = profile_record("%s:%d" % (args.shape, D)) if world == 1 else None
+        roof["traffic"] = rec["traffic_bytes_per_launch_mean"] * (E_local / rec["edges_per_launch"]) if rec else None
+        roof["traffic_source"] = rec.get("source") if rec else None
+        if cache_resident and not args.no_ceiling and world == 1:
+            n_wg = (E_local + 255) // 256
+            mall = measure_stream_ceiling(dev, 96 << 20, n_wg)            # > 8 x 4 MB L2, < 256 MB Infinity Cache
+            l2 = measure_stream_ceiling(dev, 2 << 20, n_wg)               # fits every XCD's 4 MB L2
+            hit = rec.get("l2_hit_rate") if rec else None
+            h = hit if hit is not None else 0.0
+            ceiling = 1.0 / ((1.0 - h) / mall + h / l2)
+            roof.update(bound="infinity_cache+l2", peak=ceiling, frac=roof["achieved"] / ceiling,
+                        ceiling={"infinity_cache_stream_gbs": mall, "l2_stream_gbs": l2, "l2_hit_rate": hit,
+                                 "l2_hit_rate_source": rec.get("source") if rec else None,
+                                 "model": "peak = 1 / ((1 - h) / infinity_cache_stream + h / l2_stream): both rates "
+                                          "measured in this run by sg_stream_read_hip (single-wave workgroups, 1 KiB "
+                                          "bursts, same grid as the gather) on a 96 MB and a 2 MB resident buffer; h = "
+                                          "L2 hit rate of the gather launches (PMC TCC_HIT / TCC_MISS)"},
+                        note="gathered matrices (%s MB) sit in the 256 MB Infinity Cache at this shape, so HBM does not "
+                             "bind; the HBM-bound measurement is the `hbm_bound` leg" % "/".join(str(m) for m in src_mb))
+        else:
+            roof.update(bound="hbm", peak=HBM_PEAK / 1e9, frac=roof["achieved"] * 1e9 / HBM_PEAK)
 
     loss_total = loss.detach().clone()
+    edges_per_rank = [E_local]
     if dist_on:      # every rank holds its users' share of the loss; report the whole (outside the timed region)
         loss_total = SD.all_reduce_sum(loss_total.view(1))[0]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, E_local)
+        edges_per_rank = [int(e) for e in gathered]
     ms = elapsed / args.steps * 1e3
     value = E_total / (elapsed / args.steps)
     out = {
-        "metric": "edges/sec (fwd+bwd) 2-layer multi-link GCN, ML-10M shape, 1/2/4/8 GPU + %HBM roofline",
+        "metric": METRIC,
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
@@ -177,48 +409,87 @@ def main():
                                "full neighbourhood, rating head over all ratings, fwd+bwd" % (args.shape, n_user, n_item,
                                                                                           E_total, R, D),
                    "partition": "single GPU" if world == 1 else "1-D user-block node partition, items replicated, "
-                                "RCCL all-reduce of item-side partials", "order": args.order,
-                   "plan_build_s": round(t_plan, 2), "loss": float(loss_total),
+                                "RCCL all-reduce of item-side partials on a side stream, overlapped with the user-side "
+                                "aggregation of the same layer",
+                   "order": args.order, "plan_build_s": round(t_plan, 2), "plan_builder": "device (csrc/plan_build.hip)",
+                   "loss": float(loss_total), "edges_per_rank": edges_per_rank,
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
         "roofline": roof,
         "step_roofline_frac": value * 8 * (8 + 4 * D) / (world * HBM_PEAK),
     }
+    if dist_on:
+        out["collectives"] = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
+                              "calls_per_step": comm["calls"] / args.steps,
+                              "allreduce_bytes_per_step": comm["bytes"] / args.steps,
+                              "collective_ms_per_step": comm["device_ms"] / args.steps,
+                              "note": "rank-0 view; device time of the collectives on the communication stream (they "
+                                      "overlap compute, so this is not exposed time)"}
+    # free the main leg before the big one
+    del net, plan, dgraph, y
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_hbm_leg:
+        torch.cuda.reset_peak_memory_stats(dev)
+        out["hbm_bound"] = hbm_leg(args, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(graph, U, I, D, args)
+        out["cpu_baseline"] = cpu_baseline(graph, D, args)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()
 
 
-def cpu_baseline(graph, U, I, D, args):
-    """Oracle port (oracle/cpu_step.py) timed on this host on a bounded sample: the first `cpu-user-frac` of the users
-    against all items (same generator, same widths, same network)."""
+def cpu_baseline(graph, D, args):
+    """Oracle port (oracle/cpu_step.py) timed on this host: the same network on the same graph (the FULL graph by
+    default), one OpenMP thread per physical core, pinned."""
     import star_gcn_amd.synthetic as S
     from oracle import cpu_step as C
     from star_gcn_amd.mxgraph.graph import HeterGraph
     csr = graph[U, I]
-    n_u = max(1, int(csr.shape[0] * args.cpu_user_frac))
-    sub = S.user_block(graph, U, I, 0, n_u)
-    g = HeterGraph({U: np.arange(n_u, dtype=np.int32), I: np.arange(csr.shape[1], dtype=np.int32)}, {(U, I): sub})
-    lv = dict()
-    for dst, a, b in (("user", U, I), ("item", I, U)):
-        eps, _, ips, sps = g[a, b].sample_neighbors(symm=True, use_multi_link=True, num_neighbors=-1)
-        lv[dst] = ([np.ascontiguousarray(e, np.int32) for e in eps], ips, [np.ascontiguousarray(s, np.float32) for s in sps])
-    lv["pairs"] = (sub.end_points, sub.ind_ptr, None)
-    C.run_cpu_step(lv, n_u, csr.shape[1], D, steps=1)     # warm-up (page-in, BLAS threads)
-    sec = C.run_cpu_step(lv, n_u, csr.shape[1], D, steps=args.cpu_steps)
-    sec_fair = C.run_cpu_step(lv, n_u, csr.shape[1], D, steps=1, fair=True)   # backward parallel over rows (transposed CSR)
+    n_u = max(1, int(csr.shape[0] * args.cpu_sample_users))
+    if n_u < csr.shape[0]:
+        sub = S.user_block(graph, U, I, 0, n_u)
+        g = HeterGraph({U: np.arange(n_u, dtype=np.int32), I: np.arange(csr.shape[1], dtype=np.int32)}, {(U, I): sub})
+    else:
+        sub, g = csr, graph
+
+    def levels_of(gr, s):
+        lv = dict()
+        for dst, a, b in (("user", U, I), ("item", I, U)):
+            eps, _, ips, sps = gr[a, b].sample_neighbors(symm=True, use_multi_link=True, num_neighbors=-1)
+            lv[dst] = ([np.ascontiguousarray(e, np.int32) for e in eps], ips,
+                       [np.ascontiguousarray(x, np.float32) for x in sps])
+        lv["pairs"] = (s.end_points, s.ind_ptr, None)
+        return lv
+
+    # warm-up on 1/32 of the users (page-in, BLAS and OpenMP thread pools), then ONE timed step of each variant
+    n_w = max(1, csr.shape[0] // 32)
+    wsub = S.user_block(graph, U, I, 0, n_w)
+    wg = HeterGraph({U: np.arange(n_w, dtype=np.int32), I: np.arange(csr.shape[1], dtype=np.int32)}, {(U, I): wsub})
+    C.run_cpu_step(levels_of(wg, wsub), n_w, csr.shape[1], D, steps=1)
+    lv = levels_of(g, sub)
+    ph, ph_fair = dict(), dict()
+    sec = C.run_cpu_step(lv, n_u, csr.shape[1], D, steps=1, phases=ph)
+    sec_fair = C.run_cpu_step(lv, n_u, csr.shape[1], D, steps=1, fair=True, phases=ph_fair)
     info = C.host_info()
-    return {"value": sub.nnz / sec, "unit": "edges/s", "cores": info["logical_cores"], "kind": "port",
-            "fair_value": sub.nnz / sec_fair,
+    rnd = lambda d: {k: round(v, 3) for k, v in d.items()}
+    return {"value": sub.nnz / sec, "unit": "edges/s", "cores": int(os.environ.get("OMP_NUM_THREADS", info["physical_cores"])),
+            "kind": "port", "seconds_per_step": round(sec, 3), "phases_s": rnd(ph),
+            "fair_value": sub.nnz / sec_fair, "fair_seconds_per_step": round(sec_fair, 3), "fair_phases_s": rnd(ph_fair),
             "fair_note": "same port with the data-gradient kernel parallelised over destination rows through the "
                          "transposed CSR (the reference runs it serially for K = 1, seg_op.cc:232-233)",
-            "sample": "users [0,%d) x all %d items = %d ratings of the same graph, %d step(s), %.2f s/step; seg ops = C "
-                      "restatement of reference seg_op.cc CPU kernels (reference OpenMP placement: forward over rows, "
-                      "backward serial), dense = torch-CPU BLAS standing in for MXNet FullyConnected" %
-                      (n_u, csr.shape[1], sub.nnz, args.cpu_steps, sec),
+            "sample": "users [0,%d) of %d x all %d items = %d of %d ratings of the same graph, 1 timed fwd+bwd step per "
+                      "variant after a warm-up step on 1/32 of the users; seg ops = C restatement of reference seg_op.cc "
+                      "CPU kernels (reference OpenMP placement: forward over rows, backward serial), dense = torch-CPU "
+                      "BLAS standing in for MXNet FullyConnected; one OpenMP thread per physical core "
+                      "(OMP_PROC_BIND=close, OMP_PLACES=cores)" % (n_u, csr.shape[0], csr.shape[1], sub.nnz, csr.nnz),
             "host": info}
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

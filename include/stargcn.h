@@ -326,6 +326,68 @@ int sg_mask_edges_hip(float* const* w_out, const int32_t* const* pos, const int3
  * ---------------------------------------------------------------------------------------------- */
 int sg_gather_profile_enable(int on);
 int64_t sg_gather_profile_read(float* ms, int64_t* nnz, int64_t* feat_dim, int64_t capacity);
+/* tuning aid (tests, profiling scripts): column-slice count of eligible gather launches (`slices`) and of EVERY launch
+ * it divides (`slices_force`); 0 = library default, -1 = leave unchanged.  The environment variables SG_GATHER_SLICES /
+ * SG_GATHER_SLICES_FORCE give the initial values and are read once, at the first launch.  Returns 0. */
+int sg_gather_tuning(int slices, int slices_force);
+/* measurement aid: best-case streaming read with the gather's launch geometry (single-wave workgroups, 1 KiB bursts, 4 in
+ * flight); bench.py uses it to measure, in the same run, the Infinity-Cache and L2 ceilings that price cache-resident shapes */
+int sg_stream_read_hip(const void* buf, int64_t bytes, int passes, int64_t workgroups, float* sink, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (11) DEVICE-side plan builders (csrc/plan_build.hip): hand-written wave64 exclusive scan + stable LSD radix sort.
+ *      All pointers are device pointers, nothing is copied to the host, everything is enqueued on `stream`.
+ *      Outputs are bit-identical to the host builders of (5) for in-range indices (stable order = original edge order).
+ *
+ *   sg_build_transpose_hip          = sg_build_transpose_cpu on the device.  Replaces the per-call iota + stable radix
+ *                                     sort + GetSegId of the reference backward (seg_op.cu:882-926, :91-110).  Edges at
+ *                                     positions >= indptr[seg_num] (padding) and out-of-range indices are dropped.
+ *   sg_seg_weighted_pool_bwd_data_dev_hip
+ *                                   = `_contrib__backward_seg_take_k_corr_embed2` with the reference operator's own
+ *                                     inputs (ograd(K,nnz) = weights, embed1(K,N,C) = ograd rows, neighbor_ids,
+ *                                     neighbor_indptr -- seg_op.cc:718-752): the transposed plan is built in the caller's
+ *                                     workspace on every call (as the reference re-sorts on every call) and consumed by
+ *                                     the gather.  Callers that keep a graph for more than one step should build the
+ *                                     plan once (sg_build_transpose_hip) and call sg_seg_weighted_pool_bwd_data_hip.
+ *   sg_multilink_fuse_hip           = sg_multilink_fuse_cpu on the device (per-level lists as HOST arrays of device
+ *                                     pointers); nnz = sum_r indptr_l[r][n_dst].  d_indptr / s_indptr (optional): the
+ *                                     un-split row pointers c_indptr[::R] / t_indptr[::R].
+ *   sg_multilink_fuse_csr_hip       the same plan straight from a device-resident CSR (indptr over n_dst rows,
+ *                                     end_points, per-edge level in [0, R), per-edge support): replaces
+ *                                     sample_neighbors(num_neighbors = -1) + multi_link_split + fuse (graph.py:677-748,
+ *                                     graph_sampler.cpp:277-376) for full-neighbourhood plans.  nnz must equal
+ *                                     indptr[n_dst].  c_from / t_from (optional): CSR edge id held by every slot.
+ *   sg_gen_row_indices_hip, sg_count_indices_hip, sg_get_support_hip, sg_level_index_hip
+ *                                   device twins of gen_row_indices_by_indptr, the degree count, get_support
+ *                                     (graph_sampler.cpp:393-420) and the level match of multi_link_split (:300-311).
+ * ---------------------------------------------------------------------------------------------- */
+size_t sg_build_transpose_workspace_bytes(int64_t seg_num, int64_t total_ind_num, int64_t nnz);
+int sg_build_transpose_hip(int32_t* t_indptr, int32_t* t_pos, int32_t* t_seg, const int32_t* indices,
+                           const int32_t* indptr, int64_t seg_num, int64_t total_ind_num, int64_t nnz, void* workspace,
+                           size_t workspace_bytes, void* stream);
+size_t sg_seg_weighted_pool_bwd_data_dev_workspace_bytes(int64_t batch, int64_t seg_num, int64_t total_ind_num,
+                                                         int64_t nnz, int64_t feat_dim);
+int sg_seg_weighted_pool_bwd_data_dev_hip(float* ddata, const float* weights, const float* ograd, const int32_t* indices,
+                                          const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t total_ind_num,
+                                          int64_t nnz, int64_t feat_dim, int req, void* workspace, size_t workspace_bytes,
+                                          void* stream);
+size_t sg_multilink_fuse_workspace_bytes(int64_t num_links, int64_t n_dst, int64_t n_src, int64_t nnz);
+int sg_multilink_fuse_hip(int32_t* c_indptr, int32_t* c_idx, int32_t* c_q, float* c_w, int32_t* t_indptr, int32_t* t_idx,
+                          int32_t* t_q, float* t_w, int32_t* d_indptr, int32_t* s_indptr,
+                          const int32_t* const* end_points_l, const int32_t* const* indptr_l,
+                          const float* const* support_l, int64_t num_links, int64_t n_dst, int64_t n_src, int64_t nnz,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int sg_multilink_fuse_csr_hip(int32_t* c_indptr, int32_t* c_idx, int32_t* c_q, float* c_w, int32_t* t_indptr,
+                              int32_t* t_idx, int32_t* t_q, float* t_w, int32_t* d_indptr, int32_t* s_indptr,
+                              int32_t* c_from, int32_t* t_from, const int32_t* indptr, const int32_t* end_points,
+                              const int32_t* level, const float* support, int64_t num_links, int64_t n_dst,
+                              int64_t n_src, int64_t nnz, void* workspace, size_t workspace_bytes, void* stream);
+int sg_gen_row_indices_hip(int32_t* edge_row, const int32_t* ind_ptr, int64_t row_num, int64_t nnz, void* stream);
+int sg_count_indices_hip(int32_t* counts, const int32_t* idx, int64_t n, int64_t total, void* stream);
+int sg_get_support_hip(float* support, const int32_t* row_degrees, const int32_t* col_degrees, const int32_t* end_points,
+                       const int32_t* edge_row, int64_t nnz, int symm, void* stream);
+int sg_level_index_hip(int32_t* level, const float* values, const float* multi_link, int64_t n, int64_t num_links,
+                       void* stream);
 
 #ifdef __cplusplus
 }

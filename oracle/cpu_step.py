@@ -16,20 +16,27 @@ import torch
 from . import seg as O
 
 
+TIMES = {"seg_fwd": 0.0, "seg_bwd": 0.0}
+
+
 class _SegWeightedPoolCPU(torch.autograd.Function):
     fair = False
 
     @staticmethod
     def forward(ctx, data, weights, indices, indptr):
         ctx.meta = (weights, indices, indptr, data.shape[0])
+        t0 = time.perf_counter()
         out = O.seg_weighted_pool(data.detach().numpy()[None], weights[None], indices, indptr)[0]
+        TIMES["seg_fwd"] += time.perf_counter() - t0
         return torch.from_numpy(out)
 
     @staticmethod
     def backward(ctx, og):
         weights, indices, indptr, T = ctx.meta
+        t0 = time.perf_counter()
         g = O.seg_weighted_pool_bwd_data(weights[None], og.contiguous().numpy()[None], indices, indptr, T,
                                          fair=_SegWeightedPoolCPU.fair)[0]
+        TIMES["seg_bwd"] += time.perf_counter() - t0
         return torch.from_numpy(g), None, None, None
 
 
@@ -37,10 +44,14 @@ def leaky(x):
     return torch.where(x > 0, x, 0.1 * x)
 
 
-def run_cpu_step(levels, n_user, n_item, D, steps=1, fair=False, seed=0):
+def run_cpu_step(levels, n_user, n_item, D, steps=1, fair=False, seed=0, phases=None):
     """levels: dict direction -> (end_points_l, indptr_l, support_l) for ('user','item') [dst=user] and
-    ('item','user') [dst=item]; pairs: the user->item CSR (all ratings).  Returns seconds per step."""
+    ('item','user') [dst=item]; pairs: the user->item CSR (all ratings).  Returns seconds per step.
+    phases (dict, optional): filled with seconds per step of {forward, backward, seg_fwd, seg_bwd, dense_fwd,
+    dense_bwd} -- seg_* are the seg_weighted_pool kernels, dense_* everything else (BLAS, activations, rating head)."""
     _SegWeightedPoolCPU.fair = fair
+    TIMES["seg_fwd"] = TIMES["seg_bwd"] = 0.0
+    t_fwd = [0.0]
     g = torch.Generator().manual_seed(seed)
     R = len(levels["user"][0])
     emb = {"user": (torch.rand(n_user, D, generator=g) * 0.2 - 0.1).requires_grad_(True),
@@ -81,13 +92,22 @@ def run_cpu_step(levels, n_user, n_item, D, steps=1, fair=False, seed=0):
         pi = torch.nn.functional.linear(x["item"], pi_w)
         pred = (pu[seg_of] * pi[items_of]).sum(dim=1)
         loss = (0.5 * (pred - y) ** 2).mean()
+        t_fwd[0] += time.perf_counter() - t_step[0]
         loss.backward()
         return float(loss.detach())
 
+    t_step = [0.0]
     t0 = time.perf_counter()
     for _ in range(steps):
+        t_step[0] = time.perf_counter()
         step()
-    return (time.perf_counter() - t0) / steps
+    total = (time.perf_counter() - t0) / steps
+    if phases is not None:
+        fwd = t_fwd[0] / steps
+        sf, sb = TIMES["seg_fwd"] / steps, TIMES["seg_bwd"] / steps
+        phases.update(forward=fwd, backward=total - fwd, seg_fwd=sf, seg_bwd=sb, dense_fwd=fwd - sf,
+                      dense_bwd=total - fwd - sb)
+    return total
 
 
 def host_info():
@@ -100,4 +120,27 @@ def host_info():
                     break
     except OSError:
         pass
-    return {"cpu_model": model, "logical_cores": os.cpu_count(), "torch_threads": torch.get_num_threads()}
+    return {"cpu_model": model, "logical_cores": os.cpu_count(), "physical_cores": physical_cores(),
+            "torch_threads": torch.get_num_threads(), "omp_num_threads": os.environ.get("OMP_NUM_THREADS"),
+            "omp_proc_bind": os.environ.get("OMP_PROC_BIND"), "omp_places": os.environ.get("OMP_PLACES")}
+
+
+def physical_cores():
+    """number of distinct (package, core) pairs in /proc/cpuinfo (SMT siblings counted once)"""
+    cores, phys, core = set(), None, None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return len(cores) or (os.cpu_count() or 1)

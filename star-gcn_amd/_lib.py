@@ -81,6 +81,19 @@ _SIGS = {
     "sg_l2_loss_hip": (_INT, [_P] * 4 + [_I64, _F32, _P, _SZ, _P]),
     "sg_gather_profile_enable": (_INT, [_INT]),
     "sg_gather_profile_read": (_I64, [_P, _P, _P, _I64]),
+    "sg_gather_tuning": (_INT, [_INT, _INT]),
+    "sg_stream_read_hip": (_INT, [_P, _I64, _INT, _I64, _P, _P]),
+    "sg_build_transpose_workspace_bytes": (_SZ, [_I64] * 3),
+    "sg_build_transpose_hip": (_INT, [_P] * 5 + [_I64] * 3 + [_P, _SZ, _P]),
+    "sg_seg_weighted_pool_bwd_data_dev_workspace_bytes": (_SZ, [_I64] * 5),
+    "sg_seg_weighted_pool_bwd_data_dev_hip": (_INT, [_P] * 5 + [_I64] * 5 + [_INT, _P, _SZ, _P]),
+    "sg_multilink_fuse_workspace_bytes": (_SZ, [_I64] * 4),
+    "sg_multilink_fuse_hip": (_INT, [_P] * 13 + [_I64] * 4 + [_P, _SZ, _P]),
+    "sg_multilink_fuse_csr_hip": (_INT, [_P] * 16 + [_I64] * 4 + [_P, _SZ, _P]),
+    "sg_gen_row_indices_hip": (_INT, [_P, _P, _I64, _I64, _P]),
+    "sg_count_indices_hip": (_INT, [_P, _P, _I64, _I64, _P]),
+    "sg_get_support_hip": (_INT, [_P] * 5 + [_I64, _INT, _P]),
+    "sg_level_index_hip": (_INT, [_P] * 3 + [_I64, _I64, _P]),
     "sg_multilink_agg_resolve_order": (_INT, [_P, _INT]),
     "sg_multilink_agg_saved_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT]),
     "sg_multilink_agg_workspace_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT, _INT]),

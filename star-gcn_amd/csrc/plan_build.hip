@@ -1,0 +1,717 @@
+// plan_build.hip -- DEVICE-side builders of the integer plans of the hot path (gfx950, wave64).
+//
+// Reference behaviour being replaced:
+//   * `_backward_seg_take_k_corr_embed2` receives (ograd, embed1, neighbor_ids, neighbor_indptr) as DEVICE tensors and
+//     sorts the edges by neighbour id on every call: iota + cub::DeviceRadixSort::SortPairs (stable) + FillSegStartIndex
+//     + inclusive max-scan (seg_op.cu:882-926, GetSegId :91-110).  Round 1 of this library only had a HOST builder
+//     (sg_build_transpose_cpu), i.e. a D2H copy + host sort + H2D copy per new graph.
+//   * the per-level neighbour lists of the multi-link aggregator come from host code (graph_sampler.cpp:277-376,
+//     layers.py:260-337) and are uploaded on every call (layers.py:366-377).
+//
+// Here the same integer structures are built where the data already lives:
+//   exclusive_scan   3-kernel decoupled block scan of int32 (wave64 __shfl_up scan + LDS across the 4 waves)
+//   radix_sort_pairs stable LSD radix sort of (uint32 key, int32 payload), 8-bit digits.  One 64-lane wavefront owns a
+//                    tile of 2048 consecutive elements; the rank of an element among the equal digits before it is
+//                    (running per-digit tile counter in LDS) + (lanes below with the same digit, found with 8
+//                    __ballot rounds).  No floating point, no order-dependent atomics: the result is the unique stable
+//                    order, bit-identical to the host counting sorts (sg_build_transpose_cpu, sg_multilink_fuse_cpu).
+// All kernels take their sizes from host arguments except the number of COVERED edges E = indptr[seg_num], which is read
+// on the device (positions >= E are padding, as in the reference's empty_as_zero convention, graph.py:221-222).
+#include "common.hpp"
+
+namespace sg {
+namespace {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;   // 2048
+
+// ---- block-level exclusive scan helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns the exclusive prefix, *total = block sum
+__device__ __forceinline__ int block_excl_scan(int v, int* total, int* s_wave /* [4] */) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int incl = wave_incl_scan(v, lane);
+  if (lane == 63) s_wave[w] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kScanThreads / kWave; ++i) {
+    const int c = s_wave[i];
+    if (i < w) base += c;
+    tot += c;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_tile_sums_kernel(int32_t* __restrict__ sums,
+                                                                      const int32_t* __restrict__ in, long long n) {
+  __shared__ int s_wave[4];
+  const long long base = static_cast<long long>(blockIdx.x) * kScanTile + static_cast<long long>(threadIdx.x) * kScanItems;
+  int v = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i)
+    if (base + i < n) v += in[base + i];
+  int tot;
+  (void)block_excl_scan(v, &tot, s_wave);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// single workgroup: exclusive scan of the tile sums in place (m is small: n / 2048)
+__global__ __launch_bounds__(kScanThreads) void scan_sums_kernel(int32_t* __restrict__ sums, long long m) {
+  __shared__ int s_wave[4];
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (long long b = 0; b < m; b += kScanTile) {
+    const long long base = b + static_cast<long long>(threadIdx.x) * kScanItems;
+    int x[kScanItems];
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+      x[i] = (base + i < m) ? sums[base + i] : 0;
+      v += x[i];
+    }
+    int tot;
+    int pre = block_excl_scan(v, &tot, s_wave) + s_carry;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+      if (base + i < m) sums[base + i] = pre;
+      pre += x[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry += tot;
+    __syncthreads();
+  }
+}
+
+// out[i] = offset(tile) + exclusive prefix inside the tile; out[n] = grand total when `with_total`
+__global__ __launch_bounds__(kScanThreads) void scan_tiles_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ in,
+                                                                  const int32_t* __restrict__ sums, long long n,
+                                                                  int with_total) {
+  __shared__ int s_wave[4];
+  const long long base = static_cast<long long>(blockIdx.x) * kScanTile + static_cast<long long>(threadIdx.x) * kScanItems;
+  int x[kScanItems];
+  int v = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    x[i] = (base + i < n) ? in[base + i] : 0;
+    v += x[i];
+  }
+  int tot;
+  int pre = block_excl_scan(v, &tot, s_wave) + sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < n) out[base + i] = pre;
+    pre += x[i];
+  }
+  if (with_total && base <= n - 1 && n - 1 < base + kScanItems) out[n] = pre;   // the thread owning element n-1
+}
+
+inline size_t al256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
+inline long long scan_tiles(long long n) { return (n + kScanTile - 1) / kScanTile; }
+inline size_t scan_ws_bytes(long long n) { return al256((scan_tiles(n) + 1) * sizeof(int32_t)); }
+
+// exclusive scan of n int32; `in` and `out` may alias; out has n (+1 with_total) entries
+int exclusive_scan(int32_t* out, const int32_t* in, long long n, bool with_total, void* ws, hipStream_t st) {
+  if (n <= 0) {
+    if (with_total && hipMemsetAsync(out, 0, sizeof(int32_t), st) != hipSuccess) return fail(SG_ERR_HIP, "memset");
+    return SG_OK;
+  }
+  int32_t* sums = static_cast<int32_t*>(ws);
+  const long long m = scan_tiles(n);
+  hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(static_cast<unsigned>(m)), dim3(kScanThreads), 0, st, sums, in, n);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kScanThreads), 0, st, sums, m);
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(static_cast<unsigned>(m)), dim3(kScanThreads), 0, st, out, in, sums, n,
+                     with_total ? 1 : 0);
+  return check_launch("exclusive_scan");
+}
+
+// ---- stable LSD radix sort of (key, payload) pairs ----------------------------------------------------------------
+constexpr int kRadixBits = 8;
+constexpr int kRadix = 1 << kRadixBits;
+constexpr int kSortRounds = 32;
+constexpr int kSortTile = kWave * kSortRounds;   // 2048 elements per wavefront
+
+__global__ __launch_bounds__(kWave) void radix_hist_kernel(int32_t* __restrict__ hist, const uint32_t* __restrict__ keys,
+                                                           long long n, long long n_tiles, int shift) {
+  __shared__ int s_cnt[kRadix];
+  const int lane = threadIdx.x;
+  for (int d = lane; d < kRadix; d += kWave) s_cnt[d] = 0;
+  __syncthreads();
+  const long long base = static_cast<long long>(blockIdx.x) * kSortTile;
+#pragma unroll 4
+  for (int r = 0; r < kSortRounds; ++r) {
+    const long long p = base + static_cast<long long>(r) * kWave + lane;
+    if (p < n) atomicAdd(&s_cnt[(keys[p] >> shift) & (kRadix - 1)], 1);   // integer LDS atomics: order-independent
+  }
+  __syncthreads();
+  for (int d = lane; d < kRadix; d += kWave) hist[static_cast<long long>(d) * n_tiles + blockIdx.x] = s_cnt[d];
+}
+
+__global__ __launch_bounds__(kWave) void radix_scatter_kernel(uint32_t* __restrict__ keys_out, int32_t* __restrict__ vals_out,
+                                                              const uint32_t* __restrict__ keys,
+                                                              const int32_t* __restrict__ vals,  // null: payload = position
+                                                              const int32_t* __restrict__ offs, long long n,
+                                                              long long n_tiles, int shift) {
+  __shared__ int s_cnt[kRadix];     // elements of each digit already placed from this tile
+  __shared__ int s_off[kRadix];     // global start of this tile's run of each digit
+  const int lane = threadIdx.x;
+  for (int d = lane; d < kRadix; d += kWave) {
+    s_cnt[d] = 0;
+    s_off[d] = offs[static_cast<long long>(d) * n_tiles + blockIdx.x];
+  }
+  __syncthreads();
+  const long long base = static_cast<long long>(blockIdx.x) * kSortTile;
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < kSortRounds; ++r) {
+    const long long p = base + static_cast<long long>(r) * kWave + lane;
+    const bool valid = p < n;
+    const uint32_t key = valid ? keys[p] : 0u;
+    const int32_t val = valid ? (vals ? vals[p] : static_cast<int32_t>(p)) : 0;
+    const int digit = static_cast<int>((key >> shift) & (kRadix - 1));
+    unsigned long long same = __ballot(valid);       // lanes holding the same digit as this lane
+#pragma unroll
+    for (int b = 0; b < kRadixBits; ++b) {
+      const bool bit = (digit >> b) & 1;
+      const unsigned long long m = __ballot(valid && bit);
+      same &= bit ? m : ~m;
+    }
+    const int rank = __popcll(same & below);
+    const int prior = valid ? s_cnt[digit] : 0;
+    __syncthreads();                                 // every lane has read the counter before a leader bumps it
+    if (valid) {
+      const long long dst = static_cast<long long>(s_off[digit]) + prior + rank;
+      keys_out[dst] = key;
+      vals_out[dst] = val;
+      if (rank == 0) s_cnt[digit] = prior + __popcll(same);
+    }
+    __syncthreads();
+  }
+}
+
+inline long long sort_tiles(long long n) { return (n + kSortTile - 1) / kSortTile; }
+inline int key_passes(long long max_key) {   // digits needed for keys in [0, max_key]
+  int bits = 1;
+  while (bits < 32 && (1ll << bits) <= max_key) ++bits;
+  return (bits + kRadixBits - 1) / kRadixBits;
+}
+struct SortLayout {
+  size_t keys_b, vals_b, hist, scan, total;
+};
+SortLayout sort_layout(long long n) {
+  SortLayout L{};
+  size_t off = 0;
+  auto take = [&](size_t b) { size_t o = off; off += al256(b); return o; };
+  const long long nt = sort_tiles(n > 0 ? n : 1);
+  L.keys_b = take(static_cast<size_t>(n > 0 ? n : 1) * 4);
+  L.vals_b = take(static_cast<size_t>(n > 0 ? n : 1) * 4);
+  L.hist = take(static_cast<size_t>(kRadix) * nt * 4);
+  L.scan = take(scan_ws_bytes(static_cast<long long>(kRadix) * nt));
+  L.total = off;
+  return L;
+}
+
+// Sorts (keys, vals) stably by key.  keys_a/vals_a hold the input and are clobbered; on return *keys_res / *vals_res
+// point at whichever of the a / b buffers holds the result.  vals_a may be null on input (payload = position); then
+// `vals_a_storage` is the buffer to use for the a side.
+int radix_sort_pairs(uint32_t* keys_a, int32_t* vals_a_storage, bool vals_is_iota, long long n, long long max_key,
+                     char* ws, uint32_t** keys_res, int32_t** vals_res, hipStream_t st) {
+  const SortLayout L = sort_layout(n);
+  uint32_t* kb = reinterpret_cast<uint32_t*>(ws + L.keys_b);
+  int32_t* vb = reinterpret_cast<int32_t*>(ws + L.vals_b);
+  int32_t* hist = reinterpret_cast<int32_t*>(ws + L.hist);
+  void* scan_ws = ws + L.scan;
+  uint32_t* kin = keys_a;
+  int32_t* vin = vals_a_storage;
+  uint32_t* kout = kb;
+  int32_t* vout = vb;
+  *keys_res = kin;
+  *vals_res = vin;
+  if (n <= 0) return SG_OK;
+  const long long nt = sort_tiles(n);
+  const int passes = key_passes(max_key);
+  for (int p = 0; p < passes; ++p) {
+    const int shift = p * kRadixBits;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(static_cast<unsigned>(nt)), dim3(kWave), 0, st, hist, kin, n, nt, shift);
+    int rc = exclusive_scan(hist, hist, static_cast<long long>(kRadix) * nt, false, scan_ws, st);
+    if (rc != SG_OK) return rc;
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(static_cast<unsigned>(nt)), dim3(kWave), 0, st, kout, vout, kin,
+                       (p == 0 && vals_is_iota) ? static_cast<const int32_t*>(nullptr) : vin, hist, n, nt, shift);
+    uint32_t* tk = kin; kin = kout; kout = tk;
+    int32_t* tv = vin; vin = vout; vout = tv;
+  }
+  *keys_res = kin;
+  *vals_res = vin;
+  return check_launch("radix_sort_pairs");
+}
+
+// ---- small element-wise kernels ------------------------------------------------------------------------------------
+// key[j] = (j < E && 0 <= idx[j] < T) ? idx[j] : T      (padding and out-of-range entries sort behind every real key)
+__global__ void transpose_keys_kernel(uint32_t* __restrict__ keys, const int32_t* __restrict__ idx,
+                                      const int32_t* __restrict__ indptr, long long seg_num, long long T, long long n) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const long long E = indptr[seg_num];
+  const long long v = idx[j];
+  keys[j] = static_cast<uint32_t>((j < E && v >= 0 && v < T) ? v : T);
+}
+
+// seg[j] = the segment s with indptr[s] <= j < indptr[s+1]  (for j < indptr[seg_num]; else seg_num - 1, never read)
+__global__ void edge_seg_kernel(int32_t* __restrict__ seg, const int32_t* __restrict__ indptr, long long seg_num, long long n) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  long long lo = 0, hi = seg_num;                     // upper_bound(indptr[1..seg_num], j)
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (indptr[mid + 1] <= j) lo = mid + 1; else hi = mid;
+  }
+  seg[j] = static_cast<int32_t>(lo < seg_num ? lo : seg_num - 1);
+}
+
+// out_indptr[k] = first sorted position whose key is >= k, for k in [0, T]  (keys are sorted; keys >= T are padding)
+__global__ void bounds_from_sorted_kernel(int32_t* __restrict__ out_indptr, const uint32_t* __restrict__ keys, long long n,
+                                          long long T) {
+  const long long p = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p > n) return;
+  const long long prev = (p == 0) ? -1 : static_cast<long long>(keys[p - 1] < T ? keys[p - 1] : T);
+  const long long cur = (p < n) ? static_cast<long long>(keys[p] < T ? keys[p] : T) : T;
+  for (long long k = prev + 1; k <= cur; ++k) out_indptr[k] = static_cast<int32_t>(p);
+}
+
+__global__ void gather_i32_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src,
+                                  const int32_t* __restrict__ pos, long long n) {
+  const long long p = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p < n) dst[p] = src[pos[p]];
+}
+
+inline unsigned blocks(long long n) { return static_cast<unsigned>((n + 255) / 256); }
+
+struct TransposeLayout {
+  size_t keys, vals, seg, sort, total;
+};
+TransposeLayout transpose_layout(long long nnz, bool need_seg) {
+  TransposeLayout L{};
+  size_t off = 0;
+  auto take = [&](size_t b) { size_t o = off; off += al256(b); return o; };
+  const size_t n = static_cast<size_t>(nnz > 0 ? nnz : 1);
+  L.keys = take(n * 4);
+  L.vals = take(n * 4);
+  L.seg = need_seg ? take(n * 4) : 0;
+  L.sort = take(sort_layout(nnz).total);
+  L.total = off + 256;
+  return L;
+}
+
+}  // namespace
+}  // namespace sg
+
+using namespace sg;
+
+// ------------------------------------------------------------------------------------------------------------------
+// sg_build_transpose_hip: device twin of sg_build_transpose_cpu (same outputs, bit-exact for in-range indices)
+// ------------------------------------------------------------------------------------------------------------------
+SG_API size_t sg_build_transpose_workspace_bytes(int64_t seg_num, int64_t total_ind_num, int64_t nnz) {
+  (void)seg_num; (void)total_ind_num;
+  if (nnz < 0) return 0;
+  return transpose_layout(nnz, true).total;
+}
+
+SG_API int sg_build_transpose_hip(int32_t* t_indptr, int32_t* t_pos, int32_t* t_seg, const int32_t* indices,
+                                  const int32_t* indptr, int64_t seg_num, int64_t total_ind_num, int64_t nnz,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  if (seg_num < 0 || total_ind_num < 0 || nnz < 0) return fail(SG_ERR_INVALID, "negative dimension");
+  if (!t_indptr || !indptr) return fail(SG_ERR_INVALID, "null pointer argument");
+  if (nnz > 0 && (!t_pos || !indices)) return fail(SG_ERR_INVALID, "null pointer argument");
+  if (total_ind_num >= (1ll << 31) - 1 || nnz >= (1ll << 31) - 1) return fail(SG_ERR_INVALID, "size overflows int32");
+  const TransposeLayout L = transpose_layout(nnz, t_seg != nullptr);
+  if (!workspace || workspace_bytes < L.total)
+    return fail(SG_ERR_WORKSPACE, "transpose workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  uint32_t* keys = reinterpret_cast<uint32_t*>(base + L.keys);
+  int32_t* vals = reinterpret_cast<int32_t*>(base + L.vals);
+  const long long T = total_ind_num;
+  uint32_t* ks = keys;
+  int32_t* vs = vals;
+  if (nnz > 0) {
+    hipLaunchKernelGGL(transpose_keys_kernel, dim3(blocks(nnz)), dim3(256), 0, st, keys, indices, indptr,
+                       static_cast<long long>(seg_num), T, static_cast<long long>(nnz));
+    const int rc = radix_sort_pairs(keys, vals, true, nnz, T, base + L.sort, &ks, &vs, st);
+    if (rc != SG_OK) return rc;
+    if (hipMemcpyAsync(t_pos, vs, static_cast<size_t>(nnz) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return fail(SG_ERR_HIP, "memcpy");
+    if (t_seg) {
+      int32_t* seg = reinterpret_cast<int32_t*>(base + L.seg);
+      if (seg_num > 0) {
+        hipLaunchKernelGGL(edge_seg_kernel, dim3(blocks(nnz)), dim3(256), 0, st, seg, indptr,
+                           static_cast<long long>(seg_num), static_cast<long long>(nnz));
+        hipLaunchKernelGGL(gather_i32_kernel, dim3(blocks(nnz)), dim3(256), 0, st, t_seg, seg, vs,
+                           static_cast<long long>(nnz));
+      }
+    }
+  }
+  hipLaunchKernelGGL(bounds_from_sorted_kernel, dim3(blocks(nnz + 1)), dim3(256), 0, st, t_indptr, ks,
+                     static_cast<long long>(nnz), T);
+  return check_launch("sg_build_transpose_hip");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Reference-shaped backward operator: _backward_seg_take_k_corr_embed2(ograd = weights, embed1 = ograd rows,
+// neighbor_ids, neighbor_indptr) with DEVICE index tensors only (seg_op.cc:718-752, GPU path seg_op.cu:882-926): the
+// transposed plan is built in the caller's workspace (like the reference's per-call sort) and consumed by the gather.
+// ------------------------------------------------------------------------------------------------------------------
+SG_API size_t sg_seg_weighted_pool_bwd_data_dev_workspace_bytes(int64_t batch, int64_t seg_num, int64_t total_ind_num,
+                                                                int64_t nnz, int64_t feat_dim) {
+  if (nnz < 0 || total_ind_num < 0) return 0;
+  const size_t n = static_cast<size_t>(nnz > 0 ? nnz : 1);
+  return al256((static_cast<size_t>(total_ind_num) + 1) * 4) + 2 * al256(n * 4) +
+         al256(sg_build_transpose_workspace_bytes(seg_num, total_ind_num, nnz)) +
+         al256(sg_seg_weighted_pool_bwd_data_workspace_bytes(batch, total_ind_num, nnz, feat_dim)) + 256;
+}
+
+SG_API int sg_seg_weighted_pool_bwd_data_dev_hip(float* ddata, const float* weights, const float* ograd,
+                                                 const int32_t* indices, const int32_t* indptr, int64_t batch,
+                                                 int64_t seg_num, int64_t total_ind_num, int64_t nnz, int64_t feat_dim,
+                                                 int req, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!valid_req(req)) return fail(SG_ERR_INVALID, "req must be 0 (null), 1 (write) or 3 (add), got %d", req);
+  if (req == SG_REQ_NULL) return SG_OK;
+  if (batch < 0 || seg_num < 0 || total_ind_num < 0 || nnz < 0 || feat_dim < 0) return fail(SG_ERR_INVALID, "negative dimension");
+  const size_t need = sg_seg_weighted_pool_bwd_data_dev_workspace_bytes(batch, seg_num, total_ind_num, nnz, feat_dim);
+  if (!workspace || workspace_bytes < need)
+    return fail(SG_ERR_WORKSPACE, "bwd-data workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  const size_t n = static_cast<size_t>(nnz > 0 ? nnz : 1);
+  size_t off = 0;
+  int32_t* t_indptr = reinterpret_cast<int32_t*>(base + off); off += al256((static_cast<size_t>(total_ind_num) + 1) * 4);
+  int32_t* t_pos = reinterpret_cast<int32_t*>(base + off); off += al256(n * 4);
+  int32_t* t_seg = reinterpret_cast<int32_t*>(base + off); off += al256(n * 4);
+  const size_t tb = al256(sg_build_transpose_workspace_bytes(seg_num, total_ind_num, nnz));
+  void* tws = base + off; off += tb;
+  const size_t gb = sg_seg_weighted_pool_bwd_data_workspace_bytes(batch, total_ind_num, nnz, feat_dim);
+  void* gws = base + off;
+  int rc = sg_build_transpose_hip(t_indptr, t_pos, t_seg, indices, indptr, seg_num, total_ind_num, nnz, tws, tb, stream);
+  if (rc != SG_OK) return rc;
+  return sg_seg_weighted_pool_bwd_data_hip(ddata, weights, ograd, t_indptr, t_pos, t_seg, batch, seg_num, total_ind_num,
+                                           nnz, feat_dim, req, gws, gb, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Multi-link plan builders on the device
+// ------------------------------------------------------------------------------------------------------------------
+namespace sg {
+namespace {
+
+struct LevelTable {
+  const int32_t* ep[SG_MAX_LINKS];
+  const int32_t* ip[SG_MAX_LINKS];
+  const float* sp[SG_MAX_LINKS];
+};
+
+// len[i*R + r] = indptr_r[i+1] - indptr_r[i]
+__global__ void level_lens_kernel(int32_t* __restrict__ lens, LevelTable t, long long n_dst, int R) {
+  const long long s = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= n_dst * R) return;
+  const long long i = s / R;
+  const int r = static_cast<int>(s - i * R);
+  lens[s] = t.ip[r][i + 1] - t.ip[r][i];
+}
+
+// slot w of the fused CSR <- entry of level r = seg % R at row i = seg / R
+__global__ void level_fill_kernel(int32_t* __restrict__ c_idx, float* __restrict__ c_w, const int32_t* __restrict__ c_seg,
+                                  const int32_t* __restrict__ c_indptr, LevelTable t, long long nnz, int R) {
+  const long long w = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (w >= nnz) return;
+  const int s = c_seg[w];
+  const int i = s / R, r = s - i * R;
+  const long long src = static_cast<long long>(t.ip[r][i]) + (w - c_indptr[s]);
+  c_idx[w] = t.ep[r][src];
+  c_w[w] = t.sp[r][src];
+}
+
+// key of edge j of a plain CSR for the (row, level)-major fused order; levels outside [0, R) are dropped (key = n_dst*R)
+__global__ void csr_level_keys_kernel(uint32_t* __restrict__ keys, const int32_t* __restrict__ seg,
+                                      const int32_t* __restrict__ level, long long nnz, long long n_dst, int R) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= nnz) return;
+  const int l = level[j];
+  keys[j] = static_cast<uint32_t>((l >= 0 && l < R) ? static_cast<long long>(seg[j]) * R + l : n_dst * R);
+}
+
+__global__ void csr_fill_kernel(int32_t* __restrict__ c_idx, float* __restrict__ c_w, int32_t* __restrict__ c_from,
+                                const int32_t* __restrict__ order, const int32_t* __restrict__ end_points,
+                                const float* __restrict__ support, long long nnz) {
+  const long long w = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (w >= nnz) return;
+  const int j = order[w];
+  c_idx[w] = end_points[j];
+  c_w[w] = support ? support[j] : 1.f;
+  if (c_from) c_from[w] = j;
+}
+
+// c_q[w] = c_idx[w]*R + (c_seg[w] % R); transposed sort key = c_q (or n_src*R for out-of-range sources)
+__global__ void cq_keys_kernel(int32_t* __restrict__ c_q, uint32_t* __restrict__ keys, const int32_t* __restrict__ c_idx,
+                               const int32_t* __restrict__ c_seg, long long nnz, long long n_src, int R) {
+  const long long w = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (w >= nnz) return;
+  const long long n = c_idx[w];
+  const int r = c_seg[w] % R;
+  const bool ok = n >= 0 && n < n_src;
+  const long long q = n * R + r;
+  if (c_q) c_q[w] = static_cast<int32_t>(ok ? q : 0);
+  keys[w] = static_cast<uint32_t>(ok ? q : n_src * R);
+}
+
+// transposed arrays from the sorted order: t_q = fused segment (dst*R + r), t_idx = destination node, t_w = weight
+__global__ void transposed_fill_kernel(int32_t* __restrict__ t_idx, int32_t* __restrict__ t_q, float* __restrict__ t_w,
+                                       int32_t* __restrict__ t_from, const int32_t* __restrict__ order,
+                                       const int32_t* __restrict__ c_seg, const float* __restrict__ c_w,
+                                       const int32_t* __restrict__ c_from, long long nnz, int R) {
+  const long long p = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= nnz) return;
+  const int w = order[p];
+  const int s = c_seg[w];
+  if (t_q) t_q[p] = s;
+  t_idx[p] = s / R;
+  t_w[p] = c_w[w];
+  if (t_from) t_from[p] = c_from ? c_from[w] : w;
+}
+
+__global__ void strided_copy_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src, long long n, int stride) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i * stride];
+}
+
+struct FuseLayout {
+  size_t lens, c_seg, keys, vals, seg_in, sort, scan, total;
+};
+FuseLayout fuse_layout(long long n_dst, long long n_src, long long nnz, int R) {
+  (void)n_src;
+  FuseLayout L{};
+  size_t off = 0;
+  auto take = [&](size_t b) { size_t o = off; off += al256(b); return o; };
+  const size_t n = static_cast<size_t>(nnz > 0 ? nnz : 1);
+  L.lens = take((static_cast<size_t>(n_dst) * R + 1) * 4);
+  L.c_seg = take(n * 4);
+  L.keys = take(n * 4);
+  L.vals = take(n * 4);
+  L.seg_in = take(n * 4);
+  L.sort = take(sort_layout(nnz).total);
+  L.scan = take(scan_ws_bytes(n_dst * R + 1));
+  L.total = off + 256;
+  return L;
+}
+
+// shared second half: given the fused CSR (c_indptr, c_idx, c_w) and the segment of every slot (c_seg), produce c_q,
+// the transposed arrays and the un-split row pointers
+int finish_fuse(int32_t* c_indptr, int32_t* c_idx, int32_t* c_q, float* c_w, int32_t* t_indptr, int32_t* t_idx,
+                int32_t* t_q, float* t_w, int32_t* d_indptr, int32_t* s_indptr, int32_t* t_from, const int32_t* c_from,
+                const int32_t* c_seg, long long n_dst, long long n_src, long long nnz, int R, char* base,
+                const FuseLayout& L, hipStream_t st) {
+  uint32_t* keys = reinterpret_cast<uint32_t*>(base + L.keys);
+  int32_t* vals = reinterpret_cast<int32_t*>(base + L.vals);
+  uint32_t* ks = keys;
+  int32_t* vs = vals;
+  const long long T = n_src * R;
+  if (nnz > 0) {
+    hipLaunchKernelGGL(cq_keys_kernel, dim3(blocks(nnz)), dim3(256), 0, st, c_q, keys, c_idx, c_seg, nnz, n_src, R);
+    const int rc = radix_sort_pairs(keys, vals, true, nnz, T, base + L.sort, &ks, &vs, st);
+    if (rc != SG_OK) return rc;
+    hipLaunchKernelGGL(transposed_fill_kernel, dim3(blocks(nnz)), dim3(256), 0, st, t_idx, t_q, t_w, t_from, vs, c_seg,
+                       c_w, c_from, nnz, R);
+  }
+  hipLaunchKernelGGL(bounds_from_sorted_kernel, dim3(blocks(nnz + 1)), dim3(256), 0, st, t_indptr, ks, nnz, T);
+  if (d_indptr)
+    hipLaunchKernelGGL(strided_copy_kernel, dim3(blocks(n_dst + 1)), dim3(256), 0, st, d_indptr, c_indptr, n_dst + 1, R);
+  if (s_indptr)
+    hipLaunchKernelGGL(strided_copy_kernel, dim3(blocks(n_src + 1)), dim3(256), 0, st, s_indptr, t_indptr, n_src + 1, R);
+  return check_launch("multilink fuse");
+}
+
+int check_fuse_dims(int64_t num_links, int64_t n_dst, int64_t n_src, int64_t nnz) {
+  if (num_links < 1 || num_links > SG_MAX_LINKS) return fail(SG_ERR_INVALID, "num_links outside [1, %d]", SG_MAX_LINKS);
+  if (n_dst < 0 || n_src < 0 || nnz < 0) return fail(SG_ERR_INVALID, "negative dimension");
+  if (n_dst * num_links >= (1ll << 31) - 1 || n_src * num_links >= (1ll << 31) - 1 || nnz >= (1ll << 31) - 1)
+    return fail(SG_ERR_INVALID, "n*R / nnz overflows int32");
+  return SG_OK;
+}
+
+}  // namespace
+}  // namespace sg
+
+SG_API size_t sg_multilink_fuse_workspace_bytes(int64_t num_links, int64_t n_dst, int64_t n_src, int64_t nnz) {
+  if (num_links < 1 || n_dst < 0 || n_src < 0 || nnz < 0) return 0;
+  return fuse_layout(n_dst, n_src, nnz, static_cast<int>(num_links)).total;
+}
+
+// device twin of sg_multilink_fuse_cpu: inputs are the R per-level lists (device pointers in HOST arrays); `nnz` = total
+// number of covered edges = sum_r indptr_l[r][n_dst] (the caller knows it: it sized the output arrays with it).
+SG_API int sg_multilink_fuse_hip(int32_t* c_indptr, int32_t* c_idx, int32_t* c_q, float* c_w, int32_t* t_indptr,
+                                 int32_t* t_idx, int32_t* t_q, float* t_w, int32_t* d_indptr, int32_t* s_indptr,
+                                 const int32_t* const* end_points_l, const int32_t* const* indptr_l,
+                                 const float* const* support_l, int64_t num_links, int64_t n_dst, int64_t n_src,
+                                 int64_t nnz, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_fuse_dims(num_links, n_dst, n_src, nnz);
+  if (rc != SG_OK) return rc;
+  if (!c_indptr || !t_indptr || !end_points_l || !indptr_l || !support_l) return fail(SG_ERR_INVALID, "null pointer argument");
+  if (nnz > 0 && (!c_idx || !c_w || !t_idx || !t_w)) return fail(SG_ERR_INVALID, "null output array");
+  const int R = static_cast<int>(num_links);
+  const FuseLayout L = fuse_layout(n_dst, n_src, nnz, R);
+  if (!workspace || workspace_bytes < L.total)
+    return fail(SG_ERR_WORKSPACE, "fuse workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
+  LevelTable t{};
+  for (int r = 0; r < R; ++r) {
+    if (!indptr_l[r] || (nnz > 0 && (!end_points_l[r] || !support_l[r]))) return fail(SG_ERR_INVALID, "level %d: null array", r);
+    t.ep[r] = end_points_l[r]; t.ip[r] = indptr_l[r]; t.sp[r] = support_l[r];
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  int32_t* lens = reinterpret_cast<int32_t*>(base + L.lens);
+  int32_t* c_seg = reinterpret_cast<int32_t*>(base + L.c_seg);
+  const long long S = n_dst * R;
+  if (S > 0) hipLaunchKernelGGL(level_lens_kernel, dim3(blocks(S)), dim3(256), 0, st, lens, t, static_cast<long long>(n_dst), R);
+  rc = exclusive_scan(c_indptr, lens, S, true, base + L.scan, st);
+  if (rc != SG_OK) return rc;
+  if (nnz > 0) {
+    hipLaunchKernelGGL(edge_seg_kernel, dim3(blocks(nnz)), dim3(256), 0, st, c_seg, c_indptr, S, static_cast<long long>(nnz));
+    hipLaunchKernelGGL(level_fill_kernel, dim3(blocks(nnz)), dim3(256), 0, st, c_idx, c_w, c_seg, c_indptr, t,
+                       static_cast<long long>(nnz), R);
+  }
+  return finish_fuse(c_indptr, c_idx, c_q, c_w, t_indptr, t_idx, t_q, t_w, d_indptr, s_indptr, nullptr, nullptr, c_seg, n_dst,
+                     n_src, nnz, R, base, L, st);
+}
+
+// Same plan straight from a device-resident CSR of the (destination x source) graph: `level[j]` in [0, R) is the
+// rating level of edge j, `support[j]` its weight (null: 1).  Replaces sample_neighbors + multi_link_split + fuse
+// (graph.py:677-748, graph_sampler.cpp:277-376) for full-neighbourhood plans without touching the host.  Optional
+// c_from / t_from: the CSR edge id stored in every slot of the two edge orders (what per-batch edge masking needs).
+SG_API int sg_multilink_fuse_csr_hip(int32_t* c_indptr, int32_t* c_idx, int32_t* c_q, float* c_w, int32_t* t_indptr,
+                                     int32_t* t_idx, int32_t* t_q, float* t_w, int32_t* d_indptr, int32_t* s_indptr,
+                                     int32_t* c_from, int32_t* t_from, const int32_t* indptr, const int32_t* end_points,
+                                     const int32_t* level, const float* support, int64_t num_links, int64_t n_dst,
+                                     int64_t n_src, int64_t nnz, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_fuse_dims(num_links, n_dst, n_src, nnz);
+  if (rc != SG_OK) return rc;
+  if (!c_indptr || !t_indptr || !indptr) return fail(SG_ERR_INVALID, "null pointer argument");
+  if (nnz > 0 && (!c_idx || !c_w || !t_idx || !t_w || !end_points || !level)) return fail(SG_ERR_INVALID, "null array");
+  if (t_from && !c_from) return fail(SG_ERR_INVALID, "t_from needs c_from");
+  const int R = static_cast<int>(num_links);
+  const FuseLayout L = fuse_layout(n_dst, n_src, nnz, R);
+  if (!workspace || workspace_bytes < L.total)
+    return fail(SG_ERR_WORKSPACE, "fuse workspace too small: need %zu bytes, got %zu", L.total, workspace_bytes);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  int32_t* c_seg = reinterpret_cast<int32_t*>(base + L.c_seg);
+  int32_t* seg_in = reinterpret_cast<int32_t*>(base + L.seg_in);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(base + L.keys);
+  int32_t* vals = reinterpret_cast<int32_t*>(base + L.vals);
+  const long long S = n_dst * R;
+  uint32_t* ks = keys;
+  int32_t* vs = vals;
+  if (nnz > 0) {
+    hipLaunchKernelGGL(edge_seg_kernel, dim3(blocks(nnz)), dim3(256), 0, st, seg_in, indptr, static_cast<long long>(n_dst),
+                       static_cast<long long>(nnz));
+    hipLaunchKernelGGL(csr_level_keys_kernel, dim3(blocks(nnz)), dim3(256), 0, st, keys, seg_in, level,
+                       static_cast<long long>(nnz), static_cast<long long>(n_dst), R);
+    rc = radix_sort_pairs(keys, vals, true, nnz, S, base + L.sort, &ks, &vs, st);
+    if (rc != SG_OK) return rc;
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(blocks(nnz)), dim3(256), 0, st, c_idx, c_w, c_from, vs, end_points, support,
+                       static_cast<long long>(nnz));
+  }
+  hipLaunchKernelGGL(bounds_from_sorted_kernel, dim3(blocks(nnz + 1)), dim3(256), 0, st, c_indptr, ks,
+                     static_cast<long long>(nnz), S);
+  if (nnz > 0)   // the sort buffers are reused by finish_fuse: take the slot -> segment map first
+    hipLaunchKernelGGL(edge_seg_kernel, dim3(blocks(nnz)), dim3(256), 0, st, c_seg, c_indptr, S, static_cast<long long>(nnz));
+  return finish_fuse(c_indptr, c_idx, c_q, c_w, t_indptr, t_idx, t_q, t_w, d_indptr, s_indptr, t_from, c_from, c_seg, n_dst,
+                     n_src, nnz, R, base, L, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Small graph primitives on the device (twins of the host helpers in graph_host.cpp)
+// ------------------------------------------------------------------------------------------------------------------
+namespace sg {
+namespace {
+__global__ void support_kernel(float* __restrict__ support, const int32_t* __restrict__ row_deg,
+                               const int32_t* __restrict__ col_deg, const int32_t* __restrict__ end_points,
+                               const int32_t* __restrict__ edge_row, long long nnz, int symm) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= nnz) return;
+  const int dr = row_deg[edge_row[j]];
+  float v;
+  if (symm) {
+    const int dc = col_deg[end_points[j]];
+    v = (dr == 0 || dc == 0) ? 0.f : sqrtf(1.0f / static_cast<float>(dr) / static_cast<float>(dc));
+  } else {
+    v = dr == 0 ? 0.f : 1.0f / static_cast<float>(dr);
+  }
+  support[j] = v;
+}
+__global__ void count_kernel(int32_t* __restrict__ cnt, const int32_t* __restrict__ idx, long long n, long long T) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const long long v = idx[j];
+  if (v >= 0 && v < T) atomicAdd(&cnt[v], 1);   // integer atomics: the result does not depend on the order
+}
+__global__ void level_index_kernel(int32_t* __restrict__ level, const float* __restrict__ values,
+                                   const float* __restrict__ multi_link, long long n, int R) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const float v = values[j];
+  int l = -1;
+  for (int r = 0; r < R; ++r)
+    if (multi_link[r] == v) { l = r; break; }   // exact float equality, as graph_sampler.cpp:300-311
+  level[j] = l;
+}
+}  // namespace
+}  // namespace sg
+
+// edge_row[j] = row of edge j (device twin of sg_gen_row_indices_cpu, reference py_ext.cpp gen_row_indices_by_indptr)
+SG_API int sg_gen_row_indices_hip(int32_t* edge_row, const int32_t* ind_ptr, int64_t row_num, int64_t nnz, void* stream) {
+  if (row_num < 0 || nnz < 0) return fail(SG_ERR_INVALID, "negative dimension");
+  if (nnz == 0 || row_num == 0) return SG_OK;
+  hipLaunchKernelGGL(edge_seg_kernel, dim3(blocks(nnz)), dim3(256), 0, static_cast<hipStream_t>(stream), edge_row, ind_ptr,
+                     static_cast<long long>(row_num), static_cast<long long>(nnz));
+  return check_launch("sg_gen_row_indices_hip");
+}
+
+// counts[v] = #{j : idx[j] == v}, v in [0, T)  (column degrees of a CSR; `counts` is overwritten)
+SG_API int sg_count_indices_hip(int32_t* counts, const int32_t* idx, int64_t n, int64_t total, void* stream) {
+  if (n < 0 || total < 0) return fail(SG_ERR_INVALID, "negative dimension");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (total > 0 && hipMemsetAsync(counts, 0, static_cast<size_t>(total) * 4, st) != hipSuccess) return fail(SG_ERR_HIP, "memset");
+  if (n > 0 && total > 0)
+    hipLaunchKernelGGL(count_kernel, dim3(blocks(n)), dim3(256), 0, st, counts, idx, static_cast<long long>(n),
+                       static_cast<long long>(total));
+  return check_launch("sg_count_indices_hip");
+}
+
+// device twin of sg_get_support_cpu (graph_sampler.cpp:393-420); `edge_row` from sg_gen_row_indices_hip
+SG_API int sg_get_support_hip(float* support, const int32_t* row_degrees, const int32_t* col_degrees,
+                              const int32_t* end_points, const int32_t* edge_row, int64_t nnz, int symm, void* stream) {
+  if (nnz < 0) return fail(SG_ERR_INVALID, "negative nnz");
+  if (nnz == 0) return SG_OK;
+  if (!support || !row_degrees || !edge_row || (symm && (!col_degrees || !end_points))) return fail(SG_ERR_INVALID, "null pointer argument");
+  hipLaunchKernelGGL(support_kernel, dim3(blocks(nnz)), dim3(256), 0, static_cast<hipStream_t>(stream), support, row_degrees,
+                     col_degrees, end_points, edge_row, static_cast<long long>(nnz), symm);
+  return check_launch("sg_get_support_hip");
+}
+
+// level[j] = index of values[j] in multi_link (exact float equality), -1 when it matches no level
+SG_API int sg_level_index_hip(int32_t* level, const float* values, const float* multi_link, int64_t n, int64_t num_links,
+                              void* stream) {
+  if (n < 0 || num_links < 1 || num_links > SG_MAX_LINKS) return fail(SG_ERR_INVALID, "bad size");
+  if (n == 0) return SG_OK;
+  hipLaunchKernelGGL(level_index_kernel, dim3(blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), level, values,
+                     multi_link, static_cast<long long>(n), static_cast<int>(num_links));
+  return check_launch("sg_level_index_hip");
+}

@@ -23,6 +23,7 @@
 //     row, so its private 4 MB L2 faces a 4x smaller working set (L2 hit 7 % -> 25 % on a 109 MB source).
 #include "common.hpp"
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -382,20 +383,39 @@ static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRecord> g_prof;
 
-static ProfRecord* prof_begin(hipStream_t st, int64_t nnz, int64_t C) {
+// returns the index of the new record (-1: profiling off); prof_end records the stop event into THAT record, so
+// concurrent launches from several host threads / streams cannot cross their events
+static long prof_begin(hipStream_t st, int64_t nnz, int64_t C) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (!g_prof_on) return nullptr;
+  if (!g_prof_on) return -1;
   ProfRecord r{};
   r.nnz = nnz; r.C = C;
-  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return nullptr;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
   (void)hipEventRecord(r.a, st);
   g_prof.push_back(r);
-  return &g_prof.back();   // valid until the next push: prof_end follows immediately on the same thread
+  return static_cast<long>(g_prof.size()) - 1;
 }
-static void prof_end(ProfRecord* r, hipStream_t st) {
-  if (!r) return;
+static void prof_end(long rec, hipStream_t st) {
+  if (rec < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  (void)hipEventRecord(g_prof.back().b, st);
+  if (rec < static_cast<long>(g_prof.size())) (void)hipEventRecord(g_prof[rec].b, st);
+}
+
+// tuning environment variables, read ONCE (getenv is off the launch path)
+static int env_int_once(const char* name) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
+}
+static std::atomic<int> g_slices{-1}, g_slices_force{-1};   // -1: not initialised from the environment yet
+static int env_slices() {
+  int v = g_slices.load(std::memory_order_relaxed);
+  if (v < 0) { v = env_int_once("SG_GATHER_SLICES"); if (v < 0) v = 0; g_slices.store(v, std::memory_order_relaxed); }
+  return v;
+}
+static int env_slices_force() {
+  int v = g_slices_force.load(std::memory_order_relaxed);
+  if (v < 0) { v = env_int_once("SG_GATHER_SLICES_FORCE"); if (v < 0) v = 0; g_slices_force.store(v, std::memory_order_relaxed); }
+  return v;
 }
 
 int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs, const float* src, int64_t src_group,
@@ -457,12 +477,10 @@ int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs,
   auto valid = [&](int v) { return (v == 1 || v == 2 || v == 4 || v == 8) && C % (v * vec) == 0; };
   if (vec == 4 && C >= 256 && nnz >= (1 << 20) && src_bytes >= (8ll << 20) && src_bytes <= (160ll << 20)) {
     slices = SG_GATHER_DEFAULT_SLICES;
-    if (const char* e = getenv("SG_GATHER_SLICES")) slices = atoi(e);   // tuning aid: applies to eligible launches only
+    if (env_slices() > 0) slices = env_slices();     // tuning aid: applies to eligible launches only
     if (!valid(slices)) slices = 1;
   }
-  if (const char* e = getenv("SG_GATHER_SLICES_FORCE")) {                // tests: slice every launch it divides
-    if (valid(atoi(e))) slices = atoi(e);
-  }
+  if (env_slices_force() > 0 && valid(env_slices_force())) slices = env_slices_force();   // tests: slice every launch
   a.n_slices = slices;
   a.Cs = static_cast<int32_t>(C / slices);
   int lpr = 1;
@@ -472,7 +490,7 @@ int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs,
   const bool grouped = (src_group > 1);
   dim3 grid(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch));
   if (batch > 65535) return fail(SG_ERR_INVALID, "batch > 65535 not supported");
-  ProfRecord* rec = prof_begin(st, nnz * batch, C);
+  const long rec = prof_begin(st, nnz * batch, C);
   if (vec == 4) launch_variants<4>(a, grid, st, grouped, uni);
   else if (vec == 2) launch_variants<2>(a, grid, st, grouped, uni);
   else launch_variants<1>(a, grid, st, grouped, uni);
@@ -538,6 +556,51 @@ SG_API int sg_seg_weighted_pool_bwd_data_hip(float* ddata, const float* weights,
                            weights, nnz, t_pos, t_seg, t_indptr, batch, total_ind_num, nnz, feat_dim, req, 0, SG_ACT_NONE,
                            0.f, workspace, workspace_bytes, static_cast<hipStream_t>(stream),
                            batch * seg_num * feat_dim * static_cast<int64_t>(sizeof(float)));
+}
+
+// ---- measurement aid: best-case streaming read with the gather's launch geometry ---------------------------------------
+// One 64-lane wavefront per workgroup (as in the gather), every wave instruction reads one contiguous 1 KiB burst
+// (float4 per lane), 4 bursts in flight, grid-stride over the buffer, `passes` times.  With a buffer that fits the
+// Infinity Cache but not the L2s this is the ceiling of a perfectly regular gather from a cache-resident source; with a
+// buffer of a few MB it is the L2 ceiling.  bench.py measures both IN THE SAME RUN to price the cache-resident shapes.
+namespace sg {
+__global__ __launch_bounds__(kWave) void stream_read_kernel(const float4* __restrict__ buf, long long n_vec, int passes,
+                                                            float* __restrict__ sink) {
+  const int lane = threadIdx.x;
+  const long long stride = static_cast<long long>(gridDim.x) * kWave;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = 0; p < passes; ++p) {
+    long long i = static_cast<long long>(blockIdx.x) * kWave + lane;
+    for (; i + 3 * stride < n_vec; i += 4 * stride) {
+      const float4 a = buf[i], b = buf[i + stride], c = buf[i + 2 * stride], d = buf[i + 3 * stride];
+      acc.x += a.x + b.x + c.x + d.x; acc.y += a.y + b.y + c.y + d.y;
+      acc.z += a.z + b.z + c.z + d.z; acc.w += a.w + b.w + c.w + d.w;
+    }
+    for (; i < n_vec; i += stride) {
+      const float4 a = buf[i];
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+  }
+  const float v = acc.x + acc.y + acc.z + acc.w;
+  if (v == 12345.678f) sink[0] = v;   // keeps the loads alive without a store per wave
+}
+}  // namespace sg
+
+// Reads `bytes` (multiple of 16, 16-byte aligned) `passes` times with `workgroups` single-wave workgroups.
+SG_API int sg_stream_read_hip(const void* buf, int64_t bytes, int passes, int64_t workgroups, float* sink, void* stream) {
+  if (!buf || !sink || bytes < 16 || passes < 1 || workgroups < 1 || workgroups >= (1ll << 31))
+    return sg::fail(SG_ERR_INVALID, "bad stream-read arguments");
+  if (!sg::aligned(buf, 16)) return sg::fail(SG_ERR_INVALID, "buffer must be 16-byte aligned");
+  hipLaunchKernelGGL(sg::stream_read_kernel, dim3(static_cast<unsigned>(workgroups)), dim3(sg::kWave), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float4*>(buf), static_cast<long long>(bytes / 16),
+                     passes, sink);
+  return sg::check_launch("stream_read");
+}
+
+SG_API int sg_gather_tuning(int slices, int slices_force) {
+  if (slices >= 0) sg::g_slices.store(slices, std::memory_order_relaxed);
+  if (slices_force >= 0) sg::g_slices_force.store(slices_force, std::memory_order_relaxed);
+  return SG_OK;
 }
 
 SG_API int sg_gather_profile_enable(int on) {

@@ -11,9 +11,17 @@ new design (section 8e):
     passes through `reduce_from_local` (forward all-reduce, backward identity).  Parameters used inside the local
     region get partial gradients (summed by `allreduce_grads`), parameters of the replicated region already see
     the total gradient on every rank.
+  * OVERLAP: every collective of the data path runs on a dedicated communication stream.  The split forms
+    `reduce_start` / `reduce_wait` (forward) and `grad_wait` / `copy_to_local_async` (backward) let the layer put
+    independent rank-local work between the launch of a collective and the first use of its result: the item-side
+    all-reduce of a layer travels over xGMI while the user-side aggregation of the same layer runs, and in the
+    backward pass the all-reduce of d(item features) overlaps the item-side aggregator gradient
+    (mxgraph/layers/layers.py: StackedHeterGCNLayers.heter_sage).
   * xGMI is point-to-point (7 links x ~153 GB/s per GPU): messages are kept few and large (one per layer and
     direction, one flat buffer for all local-region parameter gradients).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -23,7 +31,7 @@ def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-_FORCE_ONE_RANK = __import__("os").environ.get("SG_BENCH_FORCE_DIST") == "1"   # read once: this sits on the hot path
+_FORCE_ONE_RANK = os.environ.get("SG_BENCH_FORCE_DIST") == "1"   # read once: this sits on the hot path
 
 
 def _active():
@@ -36,19 +44,100 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+# ---- communication stream + statistics --------------------------------------------------------------------------
+class _CommStats(object):
+    """Bytes / calls / device time of the data-path collectives (bench.py reports them per step)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.reset()
+
+    def reset(self):
+        self.bytes, self.calls, self.events, self.host_s = 0, 0, [], 0.0
+
+    def read(self):
+        ms = 0.0
+        for a, b in self.events:
+            b.synchronize()
+            ms += a.elapsed_time(b)
+        return {"bytes": int(self.bytes), "calls": int(self.calls), "device_ms": ms + self.host_s * 1e3}
+
+
+STATS = _CommStats()
+_comm_streams = {}
+
+
+def comm_stream(device):
+    """The side stream every data-path collective of this process is enqueued on (one per device)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _comm_streams.get(key)
+    if s is None:
+        s = _comm_streams[key] = torch.cuda.Stream(device=device)
+    return s
+
+
+class _Pending(object):
+    """Completion handle of a collective launched on the communication stream (None event: already complete)."""
+    __slots__ = ("events",)
+
+    def __init__(self):
+        self.events = []
+
+    def wait(self):
+        for e in self.events:
+            torch.cuda.current_stream().wait_event(e)
+        self.events = []
+
+
+def _launch_sum(y, pending=None):
+    """Sum `y` over ranks IN PLACE.  RCCL ('nccl'): enqueued on the communication stream behind the work already
+    queued on the current stream; the caller's stream only waits when `pending.wait()` is called (immediately when
+    `pending` is None).  'gloo' (CPU tests, or two test ranks sharing one GPU): synchronous, device tensors are
+    staged through the host explicitly."""
+    if STATS.enabled:
+        STATS.bytes += y.numel() * y.element_size()
+        STATS.calls += 1
+    if dist.get_backend() != "nccl" or not y.is_cuda:
+        import time
+        t0 = time.perf_counter() if STATS.enabled else 0.0
+        if y.is_cuda:
+            h = y.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            y.copy_(h)
+        else:
+            dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        if STATS.enabled:
+            STATS.host_s += time.perf_counter() - t0
+        return
+    cur = torch.cuda.current_stream(y.device)
+    cs = comm_stream(y.device)
+    cs.wait_stream(cur)
+    with torch.cuda.stream(cs):
+        if STATS.enabled:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cs)
+        dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        if STATS.enabled:
+            e1.record(cs)
+            STATS.events.append((e0, e1))
+        done = torch.cuda.Event()
+        done.record(cs)
+    y.record_stream(cs)
+    if pending is None:
+        cur.wait_event(done)
+    else:
+        pending.events.append(done)
+
+
 def all_reduce_sum(t):
-    """Sum `t` over ranks, returning a NEW tensor (never mutates autograd-owned buffers).  RCCL ('nccl') reduces
-    device tensors in place over xGMI; with the 'gloo' backend (CPU tests, or two test ranks sharing one GPU) device
-    tensors are staged through the host explicitly."""
-    if dist.get_backend() == "gloo" and t.is_cuda:
-        h = t.detach().cpu().contiguous()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM)
-        return h.to(t.device)
+    """Sum `t` over ranks, returning a NEW tensor (never mutates autograd-owned buffers); blocking with respect to
+    the current stream."""
     y = t.detach().contiguous().clone()
-    dist.all_reduce(y, op=dist.ReduceOp.SUM)
+    _launch_sum(y)
     return y
 
 
+# ---- autograd crossings -------------------------------------------------------------------------------------------
 class _CopyToLocal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -69,12 +158,94 @@ class _ReduceFromLocal(torch.autograd.Function):
         return g
 
 
+class _ReduceStart(torch.autograd.Function):
+    """forward: launch the all-reduce of a rank-local partial on the communication stream and return the buffer it
+    lands in (NOT valid on the compute stream before `_ReduceWait`); backward: identity."""
+
+    @staticmethod
+    def forward(ctx, x, pending):
+        y = x.detach().contiguous().clone()
+        _launch_sum(y, pending)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _ReduceWait(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, pending):
+        pending.wait()
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _GradWait(torch.autograd.Function):
+    """forward: identity.  backward: make the compute stream wait for the gradient all-reduces that
+    `_CopyToLocalAsync` launched for this tensor.  Applied where the replicated tensor is PRODUCED, so that in the
+    backward pass it runs after every node created later -- i.e. after the rank-local gradient work that the
+    all-reduce is meant to overlap."""
+
+    @staticmethod
+    def forward(ctx, x, pending):
+        ctx.pending = pending
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.pending.wait()
+        return g, None
+
+
+class _CopyToLocalAsync(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pending):
+        ctx.pending = pending
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        y = g.detach().contiguous().clone()
+        _launch_sum(y, ctx.pending)
+        return y, None
+
+
 def copy_to_local(x):
     return _CopyToLocal.apply(x) if _active() else x
 
 
 def reduce_from_local(x):
     return _ReduceFromLocal.apply(x) if _active() else x
+
+
+def reduce_start(x):
+    """-> (buffer, pending).  The all-reduce of `x` is in flight; call `reduce_wait(buffer, pending)` before use."""
+    if not _active():
+        return x, None
+    p = _Pending()
+    return _ReduceStart.apply(x, p), p
+
+
+def reduce_wait(y, pending):
+    return y if pending is None else _ReduceWait.apply(y, pending)
+
+
+def grad_wait(x):
+    """-> (x', pending) for a replicated tensor about to enter rank-local work through `copy_to_local_async`."""
+    if not _active() or not x.requires_grad:
+        return x, None
+    p = _Pending()
+    return _GradWait.apply(x, p), p
+
+
+def copy_to_local_async(x, pending):
+    if not _active():
+        return x
+    return copy_to_local(x) if pending is None else _CopyToLocalAsync.apply(x, pending)
 
 
 def allreduce_grads(params):
@@ -90,6 +261,46 @@ def allreduce_grads(params):
         n = g.numel()
         g.copy_(flat[off:off + n].view_as(g))
         off += n
+
+
+def broadcast_parameters(params, src=0):
+    """Make replicated parameters bit-identical on every rank (rank `src` wins) through ONE flat buffer."""
+    if not _active():
+        return
+    params = [p for p in params if not isinstance(p, torch.nn.UninitializedParameter)]
+    if not params:
+        return
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    if dist.get_backend() != "nccl" and flat.is_cuda:
+        h = flat.cpu()
+        dist.broadcast(h, src=src)
+        flat = h.to(flat.device)
+    else:
+        dist.broadcast(flat, src=src)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))
+            off += n
+
+
+_rep_generators = {}
+
+
+def replicated_dropout(x, p, training):
+    """Dropout for a REPLICATED tensor of a node-partitioned run: the mask comes from a generator that is seeded
+    identically on every rank and advanced by the same sequence of calls, so replicas stay identical (a per-rank
+    mask would let the replicated activations -- and the gradients of replicated parameters -- drift apart)."""
+    if not training or p <= 0.0:
+        return x
+    key = str(x.device)
+    g = _rep_generators.get(key)
+    if g is None:
+        g = _rep_generators[key] = torch.Generator(device=x.device)
+        g.manual_seed(0x5747C0DE)
+    keep = (torch.rand(x.shape, generator=g, device=x.device) >= p).to(x.dtype)
+    return x * keep / (1.0 - p)
 
 
 class NodePartition(object):

@@ -62,6 +62,26 @@ class PairPlan(object):
         self.tplan = tp
 
 
+def _pair_plan_from_device_csr(cls, indptr, end_points, n_item):
+    """PairPlan over ALL edges of a device-resident user->item CSR, in CSR order (the full-batch rating head of the
+    benchmark): the CSR itself is the pair grouping, its transpose comes from the device builder -- nothing touches
+    the host."""
+    self = cls.__new__(cls)
+    indptr, end_points = L.i32c(indptr), L.i32c(end_points)
+    self.n_user, self.n_item, self.n_pairs = int(indptr.shape[0] - 1), int(n_item), int(end_points.shape[0])
+    self.identity, self.inv_order, self.order = True, None, None
+    self.indptr, self.items = indptr, end_points
+    t = TransposePlan(end_points, indptr, self.n_item, end_points.device)
+    tp = _PairTranspose()
+    tp.t_indptr, tp.t_pos, tp.t_seg = t.t_indptr, t.t_pos, t.t_seg
+    tp.seg_num, tp.nnz, tp.total_ind_num, tp.covered = self.n_user, max(self.n_pairs, 1), self.n_item, self.n_pairs
+    self.tplan = tp
+    return self
+
+
+PairPlan.from_device_csr = classmethod(_pair_plan_from_device_csr)
+
+
 class _PairDot(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pu, pi, pp):
@@ -213,6 +233,34 @@ class Net(nn.Module):
                 idx["req_take"] = {k: TakePlan(v, n_out[k], device) for k, v in idx["req"].items()}
         return plan
 
+    def make_plan_device(self, dgraph, symm=None, rating_head=True):
+        """Full-graph plan for a graph that is RESIDENT ON THE DEVICE (device_graph.DeviceBipartite): every node of
+        both types is computed in natural order at every depth, all index structure is built by the native device
+        builders, nothing is copied to or from the host.  The rating head scores ALL ratings of the graph in CSR order
+        (the benchmark's full-batch step)."""
+        symm = self._norm_symm if symm is None else symm
+        U, I = self._name_user, self._name_item
+        n = {U: dgraph.n_user, I: dgraph.n_item}
+        plans = {U: dgraph.plan(U, symm), I: dgraph.plan(I, symm)}
+        ident = {k: TakePlan.identity_plan(n[k]) for k in (U, I)}
+        plan = dict(enc=[None] * self._nblocks, idx=[None] * self._nblocks, device=dgraph.device)
+        for b in range(self._nblocks):
+            enc = self.encoders[0] if self._use_recurrent else self.encoders[b]
+            cp = []
+            for _depth in range(len(enc)):
+                agg_args = {U: [ident[U], None, {I: plans[U]}], I: [ident[I], None, {U: plans[I]}]}
+                cp.append([dict(dgraph.node_ids_dict), agg_args])
+            plan["enc"][b] = cp
+            idx = {"n_out": dict(n)}
+            if rating_head:
+                idx["pair"] = PairPlan.from_device_csr(dgraph.ind_ptr, dgraph.end_points, dgraph.n_item)
+            if b < self._nblocks - 1 and self._use_dae:
+                idx["req_take"] = dict(ident)
+            plan["idx"][b] = idx
+        plan["input"] = dict(ident)
+        plan["gt"] = None
+        return plan
+
     # ---- device work (reference STAR-GCN.py:399-461) --------------------------------------------------
     def run(self, plan):
         pred_ratings, pred_embeddings = [], []
@@ -257,3 +305,31 @@ def star_gcn_loss(pred_ratings, pred_embeddings, gt_embeddings, gt_ratings_std, 
         for key, pred in block.items():
             loss = loss + recon_lambda * ((gt_embeddings[key] - pred) ** 2).sum(dim=1).mean()
     return loss
+
+
+def deterministic_init(net, seed=1234, embedding_rows=None):
+    """Re-initialise every (materialised) parameter from a CPU generator keyed by (seed, parameter NAME): the values
+    depend neither on construction / first-use order, nor on lazily inferred shapes of OTHER parameters, nor on the
+    number of rank-local rows.  Replicated parameters of a node-partitioned run are therefore bit-identical on every
+    rank and equal to the single-process model's.
+
+    embedding_rows {node key: (lo, hi, n_global)}: this rank holds rows [lo, hi) of a global embedding table.
+    Weights: Xavier-in uniform (reference STAR-GCN.py:548); biases: zeros; embeddings: U(-0.1, 0.1) (:180)."""
+    import zlib
+    emb_names = {"embed_layers._layers.%d.weight" % i: k for k, i in net.embed_layers._key2idx.items()}
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if isinstance(p, nn.UninitializedParameter):
+                raise RuntimeError("deterministic_init needs materialised parameters (run one forward first): " + name)
+            g = torch.Generator().manual_seed((int(seed) << 32) ^ zlib.crc32(name.encode()))
+            if name in emb_names:
+                lo, hi, n_glob = (0, p.shape[0], p.shape[0])
+                if embedding_rows and emb_names[name] in embedding_rows:
+                    lo, hi, n_glob = embedding_rows[emb_names[name]]
+                full = torch.rand(n_glob, p.shape[1], generator=g) * 0.2 - 0.1
+                p.copy_(full[lo:hi].to(p.device))
+            elif p.dim() > 1:
+                s = (3.0 / max(p.shape[1], 1)) ** 0.5
+                p.copy_(((torch.rand(p.shape, generator=g) * 2 - 1) * s).to(p.device))
+            else:
+                p.zero_()

@@ -122,6 +122,8 @@ def empty_as_zero(l, dtype):
 
 
 class _IdMap(object):
+    """node id -> row/column index; ids that are not in the map give -1 (never another node's index)."""
+
     def __init__(self, ids):
         ids = _i32(ids)
         self._lo = int(ids.min()) if ids.size else 0
@@ -130,7 +132,13 @@ class _IdMap(object):
         self._map[ids - self._lo] = np.arange(ids.size, dtype=np.int32)
 
     def __getitem__(self, ids):
-        return self._map[_i32(ids) - self._lo]
+        rel = _i32(ids).astype(np.int64) - self._lo
+        ok = (rel >= 0) & (rel < self._map.size)
+        if ok.all():
+            return self._map[rel]
+        out = -np.ones(rel.shape, dtype=np.int32)
+        out[ok] = self._map[rel[ok]]
+        return out
 
 
 class CSRMat(object):
@@ -252,6 +260,8 @@ class CSRMat(object):
     def sample_neighbors(self, src_ids=None, symm=True, use_multi_link=True, num_neighbors=None, rng=None):
         """reference graph.py:677-748.  num_neighbors None / < 0: whole rows, deterministic."""
         src = np.arange(self.shape[0], dtype=np.int32) if src_ids is None else self.row_id_to_ind(src_ids)
+        if src.size and src.min() < 0:
+            raise ValueError("sample_neighbors: unknown source node id")
         beg, end = self.ind_ptr[src].astype(np.int64), self.ind_ptr[src + 1].astype(np.int64)
         lens = end - beg
         if num_neighbors is not None and num_neighbors >= 0:
@@ -280,9 +290,16 @@ class CSRMat(object):
         split, ptr_l = self.multi_link_split(values, dst_ptr)
         return [ep_ids[s] for s in split], [values[s] for s in split], ptr_l, [support[s] for s in split]
 
-    def remove_edges_by_id(self, node_pair_ids):
-        """reference graph.py:660-675: drop the listed (row id, col id) pairs; a NEW CSRMat (fresh degree caches)."""
+    def remove_edges_by_id(self, node_pair_ids, degree_reducer=None):
+        """reference graph.py:660-675: drop the listed (row id, col id) pairs; a NEW CSRMat (fresh degree caches).
+
+        A rank-local block of a node-partitioned graph carries override degrees for `get_support` (the GLOBAL degrees
+        of the replicated side).  They are carried over minus the removed edges; `degree_reducer(int64 array) ->
+        array summed over ranks` must be given when several ranks remove edges (each rank only sees its own), and its
+        absence in a multi-rank run is an error rather than a silent fall-back to rank-local degrees."""
         r, c = _i32(self.row_id_to_ind(node_pair_ids[0])), _i32(self.col_id_to_ind(node_pair_ids[1]))
+        if np.any(r < 0) or np.any(c < 0):
+            raise ValueError("remove_edges_by_id: unknown row / column id")
         ep = np.empty(max(self.nnz, 1), np.int32)
         vals = np.empty(max(self.nnz, 1), np.float32)
         ind_ptr = np.empty(self.shape[0] + 1, np.int32)
@@ -290,8 +307,24 @@ class CSRMat(object):
         L.check(L.lib().sg_remove_edges_cpu(_vp(ep), _vp(vals), _vp(ind_ptr), ctypes.byref(m), _vp(self.end_points),
                                             _vp(self.values), _vp(self.ind_ptr), self.shape[0], _vp(r), _vp(c), r.size),
                 "sg_remove_edges_cpu")
+        sup_rd, sup_cd = self._sup_rd, self._sup_cd
+        if sup_rd is not None or sup_cd is not None:
+            if degree_reducer is None:
+                from .._native import dist as D
+                if D.world() > 1:
+                    raise ValueError("remove_edges_by_id on a rank-local block (override support degrees) needs a "
+                                     "degree_reducer in a multi-rank run")
+                degree_reducer = lambda a: a
+            pos = self.edge_positions(np.asarray(node_pair_ids))
+            hit = np.unique(pos[pos >= 0])                              # edges that exist, each counted once
+            if sup_cd is not None:
+                dec = np.bincount(self.end_points[hit], minlength=self.shape[1]).astype(np.int64)
+                sup_cd = (sup_cd.astype(np.int64) - degree_reducer(dec)).astype(np.int32)
+            if sup_rd is not None:
+                dec = np.bincount(self.edge_row_indices[hit], minlength=self.shape[0]).astype(np.int64)
+                sup_rd = (sup_rd.astype(np.int64) - degree_reducer(dec)).astype(np.int32)
         return CSRMat(ep[:m.value], ind_ptr, self.row_ids, self.col_ids, vals[:m.value], self.multi_link,
-                      support_row_degrees=None, support_col_degrees=None)
+                      support_row_degrees=sup_rd, support_col_degrees=sup_cd)
 
     def check_consistency(self):
         rows = self.edge_row_indices.astype(np.int64) * self.shape[1] + self.end_points
@@ -324,12 +357,13 @@ class HeterGraph(object):
     def get_multi_link_structure(self):
         return {k: (None if m.multi_link is None else int(m.multi_link.size)) for k, m in self.csr_mat_dict.items()}
 
-    def remove_edges_by_id(self, src_key, dst_key, node_pair_ids):
+    def remove_edges_by_id(self, src_key, dst_key, node_pair_ids, degree_reducer=None):
         """reference graph.py:952-974: remove in BOTH directions; returns a new HeterGraph."""
         node_pair_ids = np.asarray(node_pair_ids)
         new = dict(self.csr_mat_dict)
-        new[(src_key, dst_key)] = self.csr_mat_dict[(src_key, dst_key)].remove_edges_by_id(node_pair_ids)
-        new[(dst_key, src_key)] = self.csr_mat_dict[(dst_key, src_key)].remove_edges_by_id(node_pair_ids[::-1])
+        new[(src_key, dst_key)] = self.csr_mat_dict[(src_key, dst_key)].remove_edges_by_id(node_pair_ids, degree_reducer)
+        new[(dst_key, src_key)] = self.csr_mat_dict[(dst_key, src_key)].remove_edges_by_id(node_pair_ids[::-1],
+                                                                                          degree_reducer)
         return HeterGraph(self.node_ids_dict, new, self.features)
 
     def fetch_edges_by_id(self, src_key, dst_key, node_pair_ids):

@@ -65,7 +65,15 @@ class HeterGCNLayer(nn.Module):
     def forward_single(self, key, base_feas, neighbor_data):
         """neighbor_data: {neighbor_key: (feas, end_points, edge_values, indptr, support)} as in the reference, or
         {neighbor_key: (feas, MultiLinkPlan)}."""
-        outs = []
+        return self.forward_finish(key, base_feas, self.forward_start(key, neighbor_data))
+
+    def forward_start(self, key, neighbor_data, grad_pending=None):
+        """First half of `forward_single`: run the aggregators of node type `key`.  In a node-partitioned run
+        (dist.py) an aggregate over rank-local sources that is destined to a replicated node type is a PARTIAL sum:
+        its all-reduce is launched here on the communication stream and only awaited in `forward_finish`, so the
+        caller can run rank-local work in between.  grad_pending {neighbor_key: dist pending handle}: replicated
+        neighbour features whose gradient all-reduce is awaited where they were produced (dist.grad_wait)."""
+        started = []
         part = self.partition
         for dst_key in self._meta_graph[key]:
             item = neighbor_data[dst_key]
@@ -74,16 +82,26 @@ class HeterGCNLayer(nn.Module):
             defer = False
             if part is not None:   # node-partitioned run (dist.py): wrap the two kinds of crossing
                 if part.crossing_in(key, dst_key):
-                    feas = D.copy_to_local(feas)
+                    feas = D.copy_to_local_async(feas, None if grad_pending is None else grad_pending.get(dst_key))
                 defer = part.crossing_out(key, dst_key)
             if len(item) == 2:
                 out = agg(feas, item[1], defer_act=defer)
             else:
                 _f, end_points, _edge_values, indptr, support = item
                 out = agg(feas, end_points, indptr, support, defer_act=defer)
-            if defer:   # partial sums over this rank's sources -> all-reduce, THEN the aggregator activation
-                out = agg.activation(D.reduce_from_local(out))
-            outs.append(self.dropout(out))
+            pending = None
+            if defer:   # partial sums over this rank's sources -> all-reduce (in flight), THEN the aggregator activation
+                out, pending = D.reduce_start(out)
+            started.append((out, pending, agg, defer))
+        return started
+
+    def forward_finish(self, key, base_feas, started):
+        outs = []
+        replicated = self.partition is not None and key in self.partition.replicated_keys
+        for out, pending, agg, defer in started:
+            if defer:
+                out = agg.activation(D.reduce_wait(out, pending))
+            outs.append(D.replicated_dropout(out, self.dropout.p, self.training) if replicated else self.dropout(out))
         if self._accum_self:
             outs.append(self._self_fcs[key](base_feas))
         if len(outs) == 1:
@@ -212,18 +230,44 @@ class StackedHeterGCNLayers(nn.Module):
         return computing_plan[0][0], computing_plan
 
     def heter_sage(self, input_dict, computing_plan):
-        """Bottom-up execution of the plan (reference layers.py:339-385)."""
+        """Bottom-up execution of the plan (reference layers.py:339-385).
+
+        Node-partitioned runs (layer.partition set, dist.py) reorder the work of a depth so that collectives overlap
+        rank-local kernels: node types whose aggregate is a partial sum (replicated destinations) go FIRST and only
+        launch their all-reduce; the rank-local node types run while it is in flight; then the replicated types
+        finish (activation, output Dense).  The results equal the sequential order."""
         ret = dict()
         for depth in range(len(self)):
             ret = dict()
             _prev_ids, agg_args = computing_plan[depth]
             layer = self[depth]
-            for src_key, (base_take, sel_take, plans) in agg_args.items():
-                base = SF.take_rows(input_dict[src_key], base_take) if layer._accum_self else None
+            part = layer.partition
+            grad_pending = dict()
+            if part is not None and not layer._accum_self:
+                # replicated features consumed by exactly one rank-local aggregation: their gradient all-reduce is
+                # launched asynchronously there and awaited here (runs last in the backward pass of this depth)
+                input_dict = dict(input_dict)
+                for rkey in part.replicated_keys:
+                    users = [s for s in agg_args if rkey in agg_args[s][2] and part.crossing_in(s, rkey)]
+                    if rkey in input_dict and len(users) == 1:
+                        input_dict[rkey], pend = D.grad_wait(input_dict[rkey])
+                        if pend is not None:
+                            grad_pending[rkey] = pend
+            order = list(agg_args)
+            if part is not None:
+                order.sort(key=lambda k: 0 if k in part.replicated_keys else 1)
+            started = dict()
+            for src_key in order:
+                base_take, sel_take, plans = agg_args[src_key]
                 neighbor_data = {dst_key: (input_dict[dst_key], plan) for dst_key, plan in plans.items()}
-                out = layer.forward_single(key=src_key, base_feas=base, neighbor_data=neighbor_data)
+                started[src_key] = layer.forward_start(src_key, neighbor_data, grad_pending)
+            for src_key in reversed(order):          # rank-local types finish first, replicated types last
+                base_take, sel_take, plans = agg_args[src_key]
+                base = SF.take_rows(input_dict[src_key], base_take) if layer._accum_self else None
+                out = layer.forward_finish(src_key, base, started[src_key])
                 if depth == len(self) - 1 and sel_take is not None:
                     out = SF.take_rows(out, sel_take)
                 ret[src_key] = out
+            ret = {k: ret[k] for k in agg_args}      # keep the plan's key order for callers that iterate
             input_dict = ret
         return ret

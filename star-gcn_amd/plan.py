@@ -30,11 +30,30 @@ def _vp(a):
 class TransposePlan(object):
     """Stable transpose of a CSR (indices, indptr): for every source row n the edges j with indices[j] == n in
     increasing j (t_pos) and the segment each belongs to (t_seg).  Same summation order as the reference's
-    stable radix sort + run scan (seg_op.cu:906-925)."""
+    stable radix sort + run scan (seg_op.cu:906-925).
+
+    Device index tensors are transposed ON the device (sg_build_transpose_hip: wave64 radix sort, no host round trip);
+    host arrays go through the native host builder (sg_build_transpose_cpu) and one upload."""
 
     def __init__(self, indices, indptr, total_ind_num, device):
+        T = int(total_ind_num)
+        if isinstance(indices, torch.Tensor) and indices.is_cuda:
+            idx, ip = L.i32c(indices), L.i32c(indptr)
+            S, nnz = ip.shape[0] - 1, idx.shape[0]
+            dev = idx.device
+            self.t_indptr = torch.empty(T + 1, dtype=torch.int32, device=dev)
+            self.t_pos = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+            self.t_seg = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+            lib = L.lib()
+            ws, wsn = L.workspace(lib.sg_build_transpose_workspace_bytes(S, T, nnz), dev)
+            L.check(lib.sg_build_transpose_hip(L.ptr(self.t_indptr), L.ptr(self.t_pos), L.ptr(self.t_seg), L.ptr(idx),
+                                               L.ptr(ip), S, T, nnz, L.ptr(ws), wsn, L.stream_ptr()),
+                    "sg_build_transpose_hip")
+            self.seg_num, self.nnz, self.total_ind_num = S, nnz, T
+            self.covered = None          # = t_indptr[-1], on the device; nothing on the hot path needs it on the host
+            return
         idx, ip = _np_i32(indices), _np_i32(indptr)
-        S, nnz, T = ip.shape[0] - 1, idx.shape[0], int(total_ind_num)
+        S, nnz = ip.shape[0] - 1, idx.shape[0]
         t_indptr = np.empty(T + 1, np.int32)
         t_pos = np.empty(max(nnz, 1), np.int32)
         t_seg = np.empty(max(nnz, 1), np.int32)
@@ -52,8 +71,10 @@ _TPLAN_CACHE_MAX = 64
 
 
 def transpose_plan_for(indices, indptr, total_ind_num):
-    """Cached TransposePlan for device index tensors (first use copies them to the host once).  The cache holds
-    references to the key tensors so their storage cannot be recycled under a stale entry."""
+    """Cached TransposePlan for device index tensors (built on the device at first use: the torch autograd wrappers of
+    `contrib` keep a graph's plan across steps instead of re-sorting per call as the reference does).  The cache holds
+    references to the key tensors so their storage cannot be recycled under a stale entry.  The stateless C-ABI form
+    for foreign runtimes is sg_seg_weighted_pool_bwd_data_dev_hip."""
     key = (indices.data_ptr(), indptr.data_ptr(), indices._version, indptr._version, indices.numel(),
            indptr.numel(), int(total_ind_num), str(indices.device))
     hit = _tplan_cache.get(key)
@@ -81,6 +102,9 @@ class MultiLinkPlan(object):
         R = len(end_points_l)
         if R == 0 or len(indptr_l) != R or len(support_l) != R:
             raise L.StarGCNError("MultiLinkPlan needs equally long, non-empty per-level lists")
+        if all(isinstance(a, torch.Tensor) and a.is_cuda for a in list(end_points_l) + list(indptr_l) + list(support_l)):
+            self._init_from_device_lists(end_points_l, indptr_l, support_l, int(n_src))
+            return
         ips = [_np_i32(a) for a in indptr_l]
         n_dst = ips[0].shape[0] - 1
         for a in ips:
@@ -113,6 +137,63 @@ class MultiLinkPlan(object):
         self.c_w, self.t_w = cw.view(torch.float32), tw.view(torch.float32)
         self._rowsum = None
         self._struct = None
+        self.c_from = self.t_from = None
+
+    def _alloc(self, R, n_dst, n_src, nnz, dev, with_from=False):
+        self.R, self.n_dst, self.n_src, self.nnz, self.device = int(R), int(n_dst), int(n_src), int(nnz), dev
+        m = max(self.nnz, 1)
+        i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
+        self.c_indptr, self.t_indptr = i32(self.n_dst * self.R + 1), i32(self.n_src * self.R + 1)
+        self.c_idx, self.c_q, self.t_idx, self.t_q = i32(m), i32(m), i32(m), i32(m)
+        self.c_w = torch.zeros(m, dtype=torch.float32, device=dev)
+        self.t_w = torch.zeros(m, dtype=torch.float32, device=dev)
+        self.d_indptr, self.s_indptr = i32(self.n_dst + 1), i32(self.n_src + 1)
+        self.c_from, self.t_from = (i32(m), i32(m)) if with_from else (None, None)
+        self._rowsum = None
+        self._struct = None
+
+    def _init_from_device_lists(self, end_points_l, indptr_l, support_l, n_src):
+        """Per-level lists that already live in HBM: fused on the device (sg_multilink_fuse_hip), no host round trip
+        except the R level sizes."""
+        R = len(end_points_l)
+        eps, ips = [L.i32c(a) for a in end_points_l], [L.i32c(a) for a in indptr_l]
+        sps = [L.f32c(a) for a in support_l]
+        n_dst = ips[0].shape[0] - 1
+        for a in ips:
+            if a.shape[0] != n_dst + 1:
+                raise L.StarGCNError("every level must carry a full-length indptr (n_dst+1)")
+        nnz = int(torch.stack([a[-1] for a in ips]).sum().item())
+        dev = eps[0].device
+        self._alloc(R, n_dst, n_src, nnz, dev)
+        lib = L.lib()
+        ws, wsn = L.workspace(lib.sg_multilink_fuse_workspace_bytes(R, n_dst, n_src, nnz), dev)
+        arr = ctypes.c_void_p * R
+        L.check(lib.sg_multilink_fuse_hip(
+            L.ptr(self.c_indptr), L.ptr(self.c_idx), L.ptr(self.c_q), L.ptr(self.c_w), L.ptr(self.t_indptr),
+            L.ptr(self.t_idx), L.ptr(self.t_q), L.ptr(self.t_w), L.ptr(self.d_indptr), L.ptr(self.s_indptr),
+            ctypes.cast(arr(*[a.data_ptr() for a in eps]), ctypes.c_void_p),
+            ctypes.cast(arr(*[a.data_ptr() for a in ips]), ctypes.c_void_p),
+            ctypes.cast(arr(*[a.data_ptr() for a in sps]), ctypes.c_void_p), R, n_dst, n_src, nnz, L.ptr(ws), wsn,
+            L.stream_ptr()), "sg_multilink_fuse_hip")
+
+    @classmethod
+    def from_device_csr(cls, indptr, end_points, level, support, n_src, num_links, with_from=False):
+        """Plan of the full-neighbourhood aggregation straight from a device-resident CSR (rows = destinations,
+        end_points = sources, level[j] in [0, R), support[j]) -- sg_multilink_fuse_csr_hip.  with_from: also keep, for
+        every slot of the two edge orders, the CSR edge id it holds (c_from / t_from)."""
+        self = cls.__new__(cls)
+        indptr, end_points, level = L.i32c(indptr), L.i32c(end_points), L.i32c(level)
+        support = None if support is None else L.f32c(support)
+        n_dst, nnz, dev = indptr.shape[0] - 1, end_points.shape[0], indptr.device
+        self._alloc(num_links, n_dst, n_src, nnz, dev, with_from)
+        lib = L.lib()
+        ws, wsn = L.workspace(lib.sg_multilink_fuse_workspace_bytes(self.R, n_dst, int(n_src), nnz), dev)
+        L.check(lib.sg_multilink_fuse_csr_hip(
+            L.ptr(self.c_indptr), L.ptr(self.c_idx), L.ptr(self.c_q), L.ptr(self.c_w), L.ptr(self.t_indptr),
+            L.ptr(self.t_idx), L.ptr(self.t_q), L.ptr(self.t_w), L.ptr(self.d_indptr), L.ptr(self.s_indptr),
+            L.ptr(self.c_from), L.ptr(self.t_from), L.ptr(indptr), L.ptr(end_points), L.ptr(level), L.ptr(support),
+            self.R, n_dst, int(n_src), nnz, L.ptr(ws), wsn, L.stream_ptr()), "sg_multilink_fuse_csr_hip")
+        return self
 
     def c_struct(self, need_rowsum):
         """ctypes `sg_multilink_plan` view of the resident arrays (kept alive by this object)."""
@@ -166,6 +247,15 @@ class TakePlan(object):
     (-1 = row not taken -> zero); otherwise the transposed plan groups the positions i by id, so
     d table[n] = sum of dout rows in segment n (gather kernel again).  Built by native code (sg_take_plan_cpu),
     uploaded with one copy."""
+
+    @classmethod
+    def identity_plan(cls, n):
+        """take of rows 0..n-1 in order: costs nothing forward or backward (no index arrays at all)."""
+        self = cls.__new__(cls)
+        self.n = self.n_rows = self.covered = int(n)
+        self.identity = True
+        self.ids = self.inv_ids = self.t_indptr = self.t_pos = None
+        return self
 
     def __init__(self, ids, n_rows, device):
         ids = _np_i32(ids).reshape(-1)

@@ -36,6 +36,10 @@ class ResidentPlan(object):
         self.plan = net.make_plan(graph, symm=self.symm, device=device, full_node_ids=full)
         self.csr = graph[U, I]
         m = self.csr
+        if m._sup_rd is not None or m._sup_cd is not None:
+            # a rank-local block normalises with GLOBAL degrees: the per-batch decrements of every rank would have to be
+            # all-reduced inside sg_mask_edges_hip's degree pass; refuse instead of silently using rank-local degrees
+            raise L.StarGCNError("ResidentPlan does not support rank-local graph blocks (override support degrees)")
         self.n_user, self.n_item, self.nnz = m.shape[0], m.shape[1], m.nnz
         eu, ei = m.edge_row_indices.astype(np.int64), m.end_points.astype(np.int64)
         R = int(m.multi_link.size) if m.multi_link is not None else 1
@@ -77,7 +81,14 @@ class ResidentPlan(object):
         self._edge_row, self._edge_col = _dev(eu, self.device), _dev(ei, self.device)
         self._row_deg, self._col_deg = _dev(m.row_degrees, self.device), _dev(m.col_degrees, self.device)
         self._all_ids = {k: np.arange(graph.node_ids_dict[k].size, dtype=np.int32) for k in graph.meta_graph}
-        self._id_maps = {U: m.row_id_to_ind, I: m.col_id_to_ind}
+        def _checked(fn, what):
+            def look(ids):
+                ind = fn(ids)
+                if ind.size and ind.min() < 0:
+                    raise L.StarGCNError("unknown %s id in the batch (not a node of the resident graph)" % what)
+                return ind
+            return look
+        self._id_maps = {U: _checked(m.row_id_to_ind, U), I: _checked(m.col_id_to_ind, I)}
         self.masked = 0
 
     # ---- device-side edge removal ------------------------------------------------------------------------------

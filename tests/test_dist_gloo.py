@@ -46,12 +46,23 @@ def _flat(params):
     return [p for grp in params for p in (grp if isinstance(grp, list) else [grp])]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, split=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import star_gcn_amd.dist as SD
     assert SD.world() == world and SD.rank() == rank
+    cross_in, cross_out = SD.copy_to_local, SD.reduce_from_local
+    if split:   # the overlap-capable split forms used by heter_sage: launch / wait as separate autograd nodes
+        def cross_in(x):
+            xw, pend = SD.grad_wait(x)
+            return SD.copy_to_local_async(xw, pend)
+
+        def cross_out(x):
+            y, pend = SD.reduce_start(x)
+            return SD.reduce_wait(y, pend)
+    SD.STATS.reset()
+    SD.STATS.enabled = True
     A, xu, xi, params = _make()
     blocks = [(0, 5), (5, 12)]
     lo, hi = blocks[rank]
@@ -61,8 +72,11 @@ def _worker(rank, world, port, out_dir):
         p.requires_grad_(True)
     xu_l = xu[lo:hi].clone().requires_grad_(True)     # user embeddings: row-sharded
     xi_r = xi.clone().requires_grad_(True)            # item embeddings: replicated
-    loss = _model(A[lo:hi], xu_l, xi_r, params, SD.copy_to_local, SD.reduce_from_local, leaky)
+    loss = _model(A[lo:hi], xu_l, xi_r, params, cross_in, cross_out, leaky)
     loss.backward()
+    st = SD.STATS.read()
+    # 2 forward + 3 backward data-path all-reduces (the layer-0 item embedding needs no gradient crossing beyond its own)
+    assert st["calls"] == 5 and st["bytes"] > 0, st
     W_ui, W_iu, O_u, O_i, P_u, P_i = params
     local_region = W_ui + W_iu + O_u + [P_u]          # item-side O_i / P_i sit in the replicated region
     SD.allreduce_grads(local_region)
@@ -73,9 +87,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_partition_pattern_matches_single_process(tmp_path):
+@pytest.mark.parametrize("split", [False, True])
+def test_partition_pattern_matches_single_process(tmp_path, split):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), split), nprocs=2, join=True)
     A, xu, xi, params = _make()
     flat = _flat(params)
     for p in flat:
@@ -100,3 +115,10 @@ def test_single_process_helpers_are_identity():
     assert SD.copy_to_local(x) is x and SD.reduce_from_local(x) is x
     SD.allreduce_grads([x])
     assert SD.world() == 1 and SD.rank() == 0
+    y, pend = SD.reduce_start(x)
+    assert y is x and pend is None and SD.reduce_wait(y, pend) is x
+    xw, pend = SD.grad_wait(x)
+    assert xw is x and pend is None and SD.copy_to_local_async(x, None) is x
+    assert SD.replicated_dropout(x, 0.5, training=False) is x
+    d1 = SD.replicated_dropout(torch.ones(64, 8), 0.5, training=True)
+    assert set(d1.unique().tolist()) <= {0.0, 2.0}

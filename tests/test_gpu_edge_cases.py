@@ -105,10 +105,11 @@ def test_errors_are_python_exceptions():
 
 
 @pytest.mark.parametrize("slices", ["2", "4", "8"])
-def test_column_sliced_gather_matches_unsliced(slices, monkeypatch):
-    """XCD column slicing of the gather (SG_GATHER_SLICES_FORCE): every addressing mode, write / add, fused activation,
+def test_column_sliced_gather_matches_unsliced(slices):
+    """XCD column slicing of the gather (sg_gather_tuning(-1, slices) == SG_GATHER_SLICES_FORCE): every addressing mode, write / add, fused activation,
     empty segments, a hub segment spanning many chunks -- against the unsliced launch (same values up to the different
     but fixed summation order) and the float64 definition."""
+    from star_gcn_amd import _lib as L
     from star_gcn_amd import ops
     rng = np.random.default_rng(int(slices))
     g = torch.Generator().manual_seed(int(slices))
@@ -130,10 +131,13 @@ def test_column_sliced_gather_matches_unsliced(slices, monkeypatch):
             ref.index_add_(0, torch.from_numpy(seg), (w.double().cpu()[:, None] * rows.double().cpu()[idx.cpu().long()]))
             for req, act in ((ops.REQ_WRITE, None), (ops.REQ_ADD, None), (ops.REQ_WRITE, "leaky")):
                 base = torch.randn(n_seg, C, generator=g).cuda()
-                monkeypatch.delenv("SG_GATHER_SLICES_FORCE", raising=False)
+                L.lib().sg_gather_tuning(-1, 0)
                 plain = ops.gather_sum(base.clone(), src, idx, indptr, w, n_seg, C, req=req, act=act, **kw)
-                monkeypatch.setenv("SG_GATHER_SLICES_FORCE", slices)
-                sliced = ops.gather_sum(base.clone(), src, idx, indptr, w, n_seg, C, req=req, act=act, **kw)
+                L.lib().sg_gather_tuning(-1, int(slices))
+                try:
+                    sliced = ops.gather_sum(base.clone(), src, idx, indptr, w, n_seg, C, req=req, act=act, **kw)
+                finally:
+                    L.lib().sg_gather_tuning(-1, 0)
                 want = ref + (base.double().cpu() if req == ops.REQ_ADD else 0)
                 if act:
                     want = torch.where(want > 0, want, 0.1 * want)
