@@ -54,6 +54,38 @@ def _physical_cores():
     return len(cores) or (os.cpu_count() or 1)
 
 
+def _cpu_quota():
+    """CPUs this container may use at once (cgroup v2 cpu.max / v1 cfs quota), None when unlimited"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        return None if q == "max" else max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        return None if q <= 0 else max(1, q // per)
+    except (OSError, ValueError):
+        return None
+
+
+def _host_threads():
+    """one thread per physical core, capped by the container's CPU quota and the affinity mask (more threads than
+    schedulable CPUs only adds throttling: the round-1 baseline ran 256 threads under a 16-CPU quota)"""
+    n = _physical_cores()
+    q = _cpu_quota()
+    if q:
+        n = min(n, q)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return max(1, n)
+
+
 def _argv_gpus():
     for k, a in enumerate(sys.argv[1:]):
         if a == "--gpus" and k + 2 < len(sys.argv):
@@ -66,7 +98,7 @@ def _argv_gpus():
 if int(os.environ.get("WORLD_SIZE", "1")) == 1 and _argv_gpus() == 1:
     # single-process run: the CPU baseline uses one OpenMP thread per PHYSICAL core, pinned (must be set before the
     # OpenMP runtime is loaded, i.e. before `import torch`); multi-rank runs leave the host threading alone
-    os.environ.setdefault("OMP_NUM_THREADS", str(_physical_cores()))
+    os.environ.setdefault("OMP_NUM_THREADS", str(_host_threads()))
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
 
@@ -111,7 +143,7 @@ def launch_ranks(args):
                    MASTER_PORT=str(port), SG_BENCH_SELF_LAUNCHED="1")
         env.pop("OMP_PROC_BIND", None)
         env.pop("OMP_PLACES", None)
-        env["OMP_NUM_THREADS"] = str(max(1, _physical_cores() // max(args.gpus, 1)))
+        env["OMP_NUM_THREADS"] = str(max(1, _host_threads() // max(args.gpus, 1)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
@@ -167,39 +199,45 @@ def timed_steps(step, steps, warmup, dev, dist_on):
     elapsed = time.perf_counter() - t0
     ops.gather_profile(False)
     SD.STATS.enabled = False
-    return elapsed, loss, ops.gather_profile_read()
+    return elapsed, loss, ops.gather_profile_read(with_src_bytes=True)
 
 
 def gather_roofline(timeline, E_local, D, steps):
     """average HIP-event time of the aggregation launches (width D over all local edges) -> algorithmic rate"""
-    agg = [(t, nnz, C) for t, nnz, C in timeline if C == D and nnz == max(E_local, 1) and t > 0]
+    agg = [(t, sb) for t, nnz, C, sb in timeline if C == D and nnz == max(E_local, 1) and t > 0]
     if not agg:
         return None
-    avg = sum(t for t, _, _ in agg) / len(agg)
+    avg = sum(t for t, _ in agg) / len(agg)
     bytes_per_launch = (8 + 4 * D) * E_local          # SURVEY 8(d): idx + support + one fp32 row per edge visit
+    classes = dict()                                  # launches by footprint of the gathered matrix
+    for t, sb in agg:
+        c = classes.setdefault(sb, [0, 0.0])
+        c[0] += 1
+        c[1] += t
     return {"kernel": "seg_gather_kernel", "achieved": bytes_per_launch / avg / 1e9, "unit": "GB/s",
             "launches_per_step": len(agg) / steps, "avg_launch_ms": avg * 1e3,
-            "algorithmic_bytes_per_launch": bytes_per_launch}
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "_classes": {sb: (n, tt / n) for sb, (n, tt) in classes.items()}}
 
 
-def measure_stream_ceiling(dev, n_bytes, workgroups, min_total=4e9):
-    """best-case streaming read (sg_stream_read_hip: the gather's launch geometry, perfectly regular addresses) of a
-    resident buffer of n_bytes -> GB/s, HIP events on the current stream; the first pass only warms the caches"""
+def measure_stream_ceiling(dev, n_bytes, workgroups, bursts=256):
+    """best-case streaming read (sg_stream_read_hip: the gather's launch geometry -- one wave per workgroup, 256 row
+    reads of 1 KiB per wave, 4 in flight -- with perfectly regular addresses) of a resident buffer of n_bytes -> GB/s,
+    HIP events on the current stream; the first launch only warms the caches"""
     from star_gcn_amd import _lib as L
     lib = L.lib()
     buf = torch.empty(n_bytes // 4, dtype=torch.float32, device=dev).normal_()
     sink = torch.zeros(4, dtype=torch.float32, device=dev)
-    passes = max(2, int(min_total // n_bytes))
     st = L.stream_ptr()
-    L.check(lib.sg_stream_read_hip(L.ptr(buf), n_bytes, 2, workgroups, L.ptr(sink), st), "sg_stream_read_hip")
+    L.check(lib.sg_stream_read_hip(L.ptr(buf), n_bytes, bursts, workgroups, L.ptr(sink), st), "sg_stream_read_hip")
     best = 0.0
     for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.check(lib.sg_stream_read_hip(L.ptr(buf), n_bytes, passes, workgroups, L.ptr(sink), st), "sg_stream_read_hip")
+        L.check(lib.sg_stream_read_hip(L.ptr(buf), n_bytes, bursts, workgroups, L.ptr(sink), st), "sg_stream_read_hip")
         e1.record()
         e1.synchronize()
-        best = max(best, n_bytes * passes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        best = max(best, workgroups * bursts * 1024 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
     return best
 
 
@@ -248,7 +286,7 @@ def hbm_leg(args, dev):
                        "%d ratings, %d rating levels, dim %d; same 2-layer network, fwd+bwd; graph generated and planned "
                        "on the device" % (nu, ni, E, R, D),
            "steps": args.hbm_steps, "warmup": 1, "ms_per_step": elapsed / args.hbm_steps * 1e3,
-           "edges_per_s": E / (elapsed / args.hbm_steps), "loss": float(loss),
+           "edges_per_s": E / (elapsed / args.hbm_steps), "loss": float(loss.detach()),
            "graph_gen_s": round(t_gen, 2), "plan_build_s": round(t_plan, 2),
            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
            "smallest_gathered_matrix_mb": src_small // 2 ** 20}
@@ -257,6 +295,7 @@ def hbm_leg(args, dev):
         roof.update(bound="hbm", peak=HBM_PEAK / 1e9, frac=roof["achieved"] * 1e9 / HBM_PEAK,
                     traffic=(rec["traffic_bytes_per_launch_mean"] * (E / rec["edges_per_launch"]) if rec else None),
                     traffic_source=(rec.get("source") if rec else None))
+        roof.pop("_classes", None)
         out["roofline"] = roof
         out["step_roofline_frac"] = out["edges_per_s"] * 8 * (8 + 4 * D) / HBM_PEAK
     del net, plan, dg, y
@@ -372,24 +411,33 @@ def run_rank(args):
         roof["traffic"] = rec["traffic_bytes_per_launch_mean"] * (E_local / rec["edges_per_launch"]) if rec else None
         roof["traffic_source"] = rec.get("source") if rec else None
         if cache_resident and not args.no_ceiling and world == 1:
+            # ceiling of every launch class = the same bytes at the rate of a best-case streaming read, measured NOW, of
+            # a resident buffer with that launch's source footprint and the gather's launch geometry
             n_wg = (E_local + 255) // 256
-            mall = measure_stream_ceiling(dev, 96 << 20, n_wg)            # > 8 x 4 MB L2, < 256 MB Infinity Cache
-            l2 = measure_stream_ceiling(dev, 2 << 20, n_wg)               # fits every XCD's 4 MB L2
-            hit = rec.get("l2_hit_rate") if rec else None
-            h = hit if hit is not None else 0.0
-            ceiling = 1.0 / ((1.0 - h) / mall + h / l2)
-            roof.update(bound="infinity_cache+l2", peak=ceiling, frac=roof["achieved"] / ceiling,
-                        ceiling={"infinity_cache_stream_gbs": mall, "l2_stream_gbs": l2, "l2_hit_rate": hit,
-                                 "l2_hit_rate_source": rec.get("source") if rec else None,
-                                 "model": "peak = 1 / ((1 - h) / infinity_cache_stream + h / l2_stream): both rates "
-                                          "measured in this run by sg_stream_read_hip (single-wave workgroups, 1 KiB "
-                                          "bursts, same grid as the gather) on a 96 MB and a 2 MB resident buffer; h = "
-                                          "L2 hit rate of the gather launches (PMC TCC_HIT / TCC_MISS)"},
-                        note="gathered matrices (%s MB) sit in the 256 MB Infinity Cache at this shape, so HBM does not "
-                             "bind; the HBM-bound measurement is the `hbm_bound` leg" % "/".join(str(m) for m in src_mb))
+            t_ceiling = t_actual = 0.0
+            per_class = []
+            for sb, (n, t_avg) in sorted(roof["_classes"].items()):
+                rate = measure_stream_ceiling(dev, max(1 << 20, (sb >> 20) << 20), n_wg)
+                t_c = roof["algorithmic_bytes_per_launch"] / (rate * 1e9)
+                t_ceiling += n * t_c
+                t_actual += n * t_avg
+                per_class.append({"gathered_matrix_mb": sb >> 20, "launches_per_step": n / args.steps,
+                                  "avg_launch_ms": t_avg * 1e3, "achieved_gbs": roof["algorithmic_bytes_per_launch"] / t_avg / 1e9,
+                                  "stream_ceiling_gbs": rate, "frac": t_c / t_avg})
+            roof.update(bound="infinity_cache+l2", peak=roof["achieved"] * t_actual / t_ceiling,
+                        frac=t_ceiling / t_actual, per_class=per_class,
+                        ceiling_method="sg_stream_read_hip in this run: one wave per workgroup, the gather's grid, 256 "
+                                       "consecutive 1 KiB bursts per wave (4 in flight) over a resident buffer of the "
+                                       "launch's source footprint; frac = time at that rate / measured time, summed "
+                                       "over the step's aggregation launches",
+                        note="gathered matrices (%s MB) sit in the 256 MB Infinity Cache / partly in the 8 x 4 MB L2s at "
+                             "this shape, so HBM does not bind (hbm_equiv_frac > 1 is the cache hierarchy at work); the "
+                             "HBM-bound measurement is the `hbm_bound` leg" % "/".join(str(m) for m in src_mb))
         else:
             roof.update(bound="hbm", peak=HBM_PEAK / 1e9, frac=roof["achieved"] * 1e9 / HBM_PEAK)
 
+    if roof:
+        roof.pop("_classes", None)
     loss_total = loss.detach().clone()
     edges_per_rank = [E_local]
     if dist_on:      # every rank holds its users' share of the loss; report the whole (outside the timed region)
@@ -473,6 +521,7 @@ def cpu_baseline(graph, D, args):
     info = C.host_info()
     rnd = lambda d: {k: round(v, 3) for k, v in d.items()}
     return {"value": sub.nnz / sec, "unit": "edges/s", "cores": int(os.environ.get("OMP_NUM_THREADS", info["physical_cores"])),
+            "cpu_quota_cores": _cpu_quota(),
             "kind": "port", "seconds_per_step": round(sec, 3), "phases_s": rnd(ph),
             "fair_value": sub.nnz / sec_fair, "fair_seconds_per_step": round(sec_fair, 3), "fair_phases_s": rnd(ph_fair),
             "fair_note": "same port with the data-gradient kernel parallelised over destination rows through the "
@@ -480,8 +529,8 @@ def cpu_baseline(graph, D, args):
             "sample": "users [0,%d) of %d x all %d items = %d of %d ratings of the same graph, 1 timed fwd+bwd step per "
                       "variant after a warm-up step on 1/32 of the users; seg ops = C restatement of reference seg_op.cc "
                       "CPU kernels (reference OpenMP placement: forward over rows, backward serial), dense = torch-CPU "
-                      "BLAS standing in for MXNet FullyConnected; one OpenMP thread per physical core "
-                      "(OMP_PROC_BIND=close, OMP_PLACES=cores)" % (n_u, csr.shape[0], csr.shape[1], sub.nnz, csr.nnz),
+                      "BLAS standing in for MXNet FullyConnected; one OpenMP thread per physical core the container may "
+                      "use (cgroup CPU quota respected; OMP_PROC_BIND=close, OMP_PLACES=cores)" % (n_u, csr.shape[0], csr.shape[1], sub.nnz, csr.nnz),
             "host": info}
 
 

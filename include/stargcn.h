@@ -326,13 +326,16 @@ int sg_mask_edges_hip(float* const* w_out, const int32_t* const* pos, const int3
  * ---------------------------------------------------------------------------------------------- */
 int sg_gather_profile_enable(int on);
 int64_t sg_gather_profile_read(float* ms, int64_t* nnz, int64_t* feat_dim, int64_t capacity);
+/* same, plus the footprint of the gathered matrix of every launch (the caller's hint, 0 = unknown) */
+int64_t sg_gather_profile_read2(float* ms, int64_t* nnz, int64_t* feat_dim, int64_t* src_bytes, int64_t capacity);
 /* tuning aid (tests, profiling scripts): column-slice count of eligible gather launches (`slices`) and of EVERY launch
  * it divides (`slices_force`); 0 = library default, -1 = leave unchanged.  The environment variables SG_GATHER_SLICES /
  * SG_GATHER_SLICES_FORCE give the initial values and are read once, at the first launch.  Returns 0. */
 int sg_gather_tuning(int slices, int slices_force);
-/* measurement aid: best-case streaming read with the gather's launch geometry (single-wave workgroups, 1 KiB bursts, 4 in
- * flight); bench.py uses it to measure, in the same run, the Infinity-Cache and L2 ceilings that price cache-resident shapes */
-int sg_stream_read_hip(const void* buf, int64_t bytes, int passes, int64_t workgroups, float* sink, void* stream);
+/* measurement aid: best-case streaming read with the gather's launch geometry: `workgroups` single-wave workgroups each
+ * read `bursts` consecutive 1 KiB bursts (4 in flight) of a `bytes`-long buffer, wrapping around; bench.py uses it to
+ * measure, in the same run, the Infinity-Cache and L2 ceilings that price cache-resident shapes */
+int sg_stream_read_hip(const void* buf, int64_t bytes, int bursts, int64_t workgroups, float* sink, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (11) DEVICE-side plan builders (csrc/plan_build.hip): hand-written wave64 exclusive scan + stable LSD radix sort.

@@ -81,6 +81,7 @@ _SIGS = {
     "sg_l2_loss_hip": (_INT, [_P] * 4 + [_I64, _F32, _P, _SZ, _P]),
     "sg_gather_profile_enable": (_INT, [_INT]),
     "sg_gather_profile_read": (_I64, [_P, _P, _P, _I64]),
+    "sg_gather_profile_read2": (_I64, [_P, _P, _P, _P, _I64]),
     "sg_gather_tuning": (_INT, [_INT, _INT]),
     "sg_stream_read_hip": (_INT, [_P, _I64, _INT, _I64, _P, _P]),
     "sg_build_transpose_workspace_bytes": (_SZ, [_I64] * 3),

@@ -377,7 +377,7 @@ static void launch_variants(const GatherArgs& a, dim3 fix_grid, hipStream_t st, 
 // points stay stateless otherwise.
 struct ProfRecord {
   hipEvent_t a, b;
-  int64_t nnz, C;
+  int64_t nnz, C, src_bytes;
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -385,11 +385,11 @@ static std::vector<ProfRecord> g_prof;
 
 // returns the index of the new record (-1: profiling off); prof_end records the stop event into THAT record, so
 // concurrent launches from several host threads / streams cannot cross their events
-static long prof_begin(hipStream_t st, int64_t nnz, int64_t C) {
+static long prof_begin(hipStream_t st, int64_t nnz, int64_t C, int64_t src_bytes) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof_on) return -1;
   ProfRecord r{};
-  r.nnz = nnz; r.C = C;
+  r.nnz = nnz; r.C = C; r.src_bytes = src_bytes;
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
   (void)hipEventRecord(r.a, st);
   g_prof.push_back(r);
@@ -490,7 +490,7 @@ int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs,
   const bool grouped = (src_group > 1);
   dim3 grid(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch));
   if (batch > 65535) return fail(SG_ERR_INVALID, "batch > 65535 not supported");
-  const long rec = prof_begin(st, nnz * batch, C);
+  const long rec = prof_begin(st, nnz * batch, C, src_bytes);
   if (vec == 4) launch_variants<4>(a, grid, st, grouped, uni);
   else if (vec == 2) launch_variants<2>(a, grid, st, grouped, uni);
   else launch_variants<1>(a, grid, st, grouped, uni);
@@ -559,41 +559,49 @@ SG_API int sg_seg_weighted_pool_bwd_data_hip(float* ddata, const float* weights,
 }
 
 // ---- measurement aid: best-case streaming read with the gather's launch geometry ---------------------------------------
-// One 64-lane wavefront per workgroup (as in the gather), every wave instruction reads one contiguous 1 KiB burst
-// (float4 per lane), 4 bursts in flight, grid-stride over the buffer, `passes` times.  With a buffer that fits the
-// Infinity Cache but not the L2s this is the ceiling of a perfectly regular gather from a cache-resident source; with a
-// buffer of a few MB it is the L2 ceiling.  bench.py measures both IN THE SAME RUN to price the cache-resident shapes.
+// One 64-lane wavefront per workgroup (as in the gather); wave w reads `bursts` consecutive 1 KiB bursts (float4 per
+// lane, 4 in flight -- the gather's row reads at width 256 with a perfectly regular index stream) starting at burst
+// w * bursts, wrapping around the buffer.  With a buffer inside the Infinity Cache but several times the aggregate L2
+// the waves in flight are spread over the whole buffer, so (almost) every burst misses L2 and hits the Infinity Cache;
+// with a buffer of a few MB every burst hits L2.  bench.py measures both IN THE SAME RUN to price cache-resident shapes.
 namespace sg {
-__global__ __launch_bounds__(kWave) void stream_read_kernel(const float4* __restrict__ buf, long long n_vec, int passes,
+__global__ __launch_bounds__(kWave) void stream_read_kernel(const float4* __restrict__ buf, long long n_bursts, int bursts,
                                                             float* __restrict__ sink) {
   const int lane = threadIdx.x;
-  const long long stride = static_cast<long long>(gridDim.x) * kWave;
+  long long b = (static_cast<long long>(blockIdx.x) * bursts) % n_bursts;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int p = 0; p < passes; ++p) {
-    long long i = static_cast<long long>(blockIdx.x) * kWave + lane;
-    for (; i + 3 * stride < n_vec; i += 4 * stride) {
-      const float4 a = buf[i], b = buf[i + stride], c = buf[i + 2 * stride], d = buf[i + 3 * stride];
-      acc.x += a.x + b.x + c.x + d.x; acc.y += a.y + b.y + c.y + d.y;
-      acc.z += a.z + b.z + c.z + d.z; acc.w += a.w + b.w + c.w + d.w;
-    }
-    for (; i < n_vec; i += stride) {
-      const float4 a = buf[i];
-      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
-    }
+  int k = 0;
+  for (; k + 3 < bursts; k += 4) {
+    long long b1 = b + 1, b2 = b + 2, b3 = b + 3;
+    if (b1 >= n_bursts) b1 -= n_bursts;
+    if (b2 >= n_bursts) b2 -= n_bursts;
+    if (b3 >= n_bursts) b3 -= n_bursts;
+    const float4 x0 = buf[b * kWave + lane], x1 = buf[b1 * kWave + lane], x2 = buf[b2 * kWave + lane],
+                 x3 = buf[b3 * kWave + lane];
+    acc.x += x0.x + x1.x + x2.x + x3.x; acc.y += x0.y + x1.y + x2.y + x3.y;
+    acc.z += x0.z + x1.z + x2.z + x3.z; acc.w += x0.w + x1.w + x2.w + x3.w;
+    b += 4;
+    if (b >= n_bursts) b -= n_bursts;
+  }
+  for (; k < bursts; ++k) {
+    const float4 x0 = buf[b * kWave + lane];
+    acc.x += x0.x; acc.y += x0.y; acc.z += x0.z; acc.w += x0.w;
+    if (++b >= n_bursts) b -= n_bursts;
   }
   const float v = acc.x + acc.y + acc.z + acc.w;
   if (v == 12345.678f) sink[0] = v;   // keeps the loads alive without a store per wave
 }
 }  // namespace sg
 
-// Reads `bytes` (multiple of 16, 16-byte aligned) `passes` times with `workgroups` single-wave workgroups.
-SG_API int sg_stream_read_hip(const void* buf, int64_t bytes, int passes, int64_t workgroups, float* sink, void* stream) {
-  if (!buf || !sink || bytes < 16 || passes < 1 || workgroups < 1 || workgroups >= (1ll << 31))
+// `workgroups` single-wave workgroups each read `bursts` 1 KiB bursts of the `bytes`-long buffer (multiple of 1024,
+// 16-byte aligned): workgroups * bursts KiB in total.
+SG_API int sg_stream_read_hip(const void* buf, int64_t bytes, int bursts, int64_t workgroups, float* sink, void* stream) {
+  if (!buf || !sink || bytes < 1024 || bytes % 1024 || bursts < 1 || workgroups < 1 || workgroups >= (1ll << 31))
     return sg::fail(SG_ERR_INVALID, "bad stream-read arguments");
   if (!sg::aligned(buf, 16)) return sg::fail(SG_ERR_INVALID, "buffer must be 16-byte aligned");
   hipLaunchKernelGGL(sg::stream_read_kernel, dim3(static_cast<unsigned>(workgroups)), dim3(sg::kWave), 0,
-                     static_cast<hipStream_t>(stream), static_cast<const float4*>(buf), static_cast<long long>(bytes / 16),
-                     passes, sink);
+                     static_cast<hipStream_t>(stream), static_cast<const float4*>(buf), static_cast<long long>(bytes / 1024),
+                     bursts, sink);
   return sg::check_launch("stream_read");
 }
 
@@ -614,7 +622,11 @@ SG_API int sg_gather_profile_enable(int on) {
   return was;
 }
 
+SG_API int64_t sg_gather_profile_read2(float* ms, int64_t* nnz, int64_t* feat_dim, int64_t* src_bytes, int64_t capacity);
 SG_API int64_t sg_gather_profile_read(float* ms, int64_t* nnz, int64_t* feat_dim, int64_t capacity) {
+  return sg_gather_profile_read2(ms, nnz, feat_dim, nullptr, capacity);
+}
+SG_API int64_t sg_gather_profile_read2(float* ms, int64_t* nnz, int64_t* feat_dim, int64_t* src_bytes, int64_t capacity) {
   std::lock_guard<std::mutex> lk(sg::g_prof_mu);
   int64_t n = 0;
   for (auto& r : sg::g_prof) {
@@ -625,6 +637,7 @@ SG_API int64_t sg_gather_profile_read(float* ms, int64_t* nnz, int64_t* feat_dim
       if (ms) ms[n] = t;
       if (nnz) nnz[n] = r.nnz;
       if (feat_dim) feat_dim[n] = r.C;
+      if (src_bytes) src_bytes[n] = r.src_bytes;
       ++n;
     }
     (void)hipEventDestroy(r.a);

@@ -14,13 +14,17 @@ def gather_profile(enable):
     return L.lib().sg_gather_profile_enable(int(bool(enable)))
 
 
-def gather_profile_read(capacity=1 << 16):
-    """-> list of (seconds, edges visited, feature width) per gather launch since the profile was enabled."""
+def gather_profile_read(capacity=1 << 16, with_src_bytes=False):
+    """-> list of (seconds, edges visited, feature width[, bytes of the gathered matrix]) per gather launch since the
+    profile was enabled."""
     import ctypes
     ms = (ctypes.c_float * capacity)()
     nnz = (ctypes.c_int64 * capacity)()
     fd = (ctypes.c_int64 * capacity)()
-    n = L.lib().sg_gather_profile_read(ms, nnz, fd, capacity)
+    sb = (ctypes.c_int64 * capacity)()
+    n = L.lib().sg_gather_profile_read2(ms, nnz, fd, sb, capacity)
+    if with_src_bytes:
+        return [(ms[i] * 1e-3, int(nnz[i]), int(fd[i]), int(sb[i])) for i in range(n)]
     return [(ms[i] * 1e-3, int(nnz[i]), int(fd[i])) for i in range(n)]
 
 

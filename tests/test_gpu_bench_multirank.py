@@ -32,7 +32,7 @@ def test_bench_self_launches_two_ranks_and_matches_single_rank():
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["collectives"]["rccl_ranks"] == 2 and two["collectives"]["backend"] == "gloo"
     assert two["collectives"]["calls_per_step"] >= 5 and two["collectives"]["allreduce_bytes_per_step"] > 0
-    assert len(two["config"]["edges_per_rank"]) == 2 and sum(two["config"]["edges_per_rank"]) == 100000
+    assert len(two["config"]["edges_per_rank"]) == 2 and sum(two["config"]["edges_per_rank"]) == one["config"]["edges_per_rank"][0]
     l1, l2 = one["config"]["loss"], two["config"]["loss"]
     assert abs(l1 - l2) <= 1e-5 * max(1.0, abs(l1)), (l1, l2)
     assert one["metric"] == two["metric"] and one["roofline"] is not None
