@@ -230,11 +230,50 @@ def test_take_rows_and_masked_embed():
     assert torch.equal(t2.grad.cpu(), gref)
 
 
+def _rows_vs_definition(plan, x, ws, bs, out, y, xgrad, n_rows, seed, tol):
+    """float64 definition of `n_rows` sampled output rows and `n_rows` sampled gradient rows of
+    out = sum_r A_r (x W_r^T + b_r)  (aggregators.py:141-149), d x = sum_r A_r^T (y W_r); always includes the first and
+    the last row (largest element offsets) and the destination / source with the most edges."""
+    R = plan.R
+    rng = np.random.default_rng(seed)
+    c_ip, t_ip = plan.c_indptr.cpu().numpy().astype(np.int64), plan.t_indptr.cpu().numpy().astype(np.int64)
+    hub_d = int(np.argmax(c_ip[R::R] - c_ip[:-R:R]))
+    hub_s = int(np.argmax(t_ip[R::R] - t_ip[:-R:R]))
+    dst_rows = np.unique(np.concatenate([[0, plan.n_dst - 1, hub_d], rng.integers(0, plan.n_dst, n_rows)]))
+    src_rows = np.unique(np.concatenate([[0, plan.n_src - 1, hub_s], rng.integers(0, plan.n_src, n_rows)]))
+    W = [w.double() for w in ws]
+    B = [b.double() for b in bs]
+    worst = 0.0
+    for i in dst_rows:
+        ref = torch.zeros(W[0].shape[0], dtype=torch.float64, device=x.device)
+        for r in range(R):
+            lo, hi = int(c_ip[i * R + r]), int(c_ip[i * R + r + 1])
+            if hi > lo:
+                w = plan.c_w[lo:hi].double()
+                z = (w[:, None] * x[plan.c_idx[lo:hi].long()].double()).sum(0)
+                ref += W[r] @ z + w.sum() * B[r]
+        err = float((out[i].double() - ref).abs().max()) / max(float(ref.abs().max()), 1e-3)
+        worst = max(worst, err)
+        assert err <= tol, ("output row", int(i), err)
+    for n in src_rows:
+        ref = torch.zeros(x.shape[1], dtype=torch.float64, device=x.device)
+        for r in range(R):
+            lo, hi = int(t_ip[n * R + r]), int(t_ip[n * R + r + 1])
+            if hi > lo:
+                g = (plan.t_w[lo:hi].double()[:, None] * y[plan.t_idx[lo:hi].long()].double()).sum(0)
+                ref += g @ W[r]
+        err = float((xgrad[n].double() - ref).abs().max()) / max(float(ref.abs().max()), 1e-3)
+        worst = max(worst, err)
+        assert err <= tol, ("gradient row", int(n), err)
+    return len(dst_rows), len(src_rows), worst
+
+
 def test_fused_aggregator_properties_at_ml10m_size():
     """BASELINE config 4 size (69878 x 10677, 10 M ratings, 10 levels, dim 256): the oracle cannot run this in seconds,
-    so check size-independent properties of the fused aggregation: (1) both association orders agree, (2) linearity in
-    the features (activation off), (3) the adjoint identity <A x, y> == <x, A^T y> through autograd, (4) rows of users
-    without any rating of a level get no bias of that level (empty segment => 0)."""
+    so check (0) >= 64 sampled output rows and >= 64 sampled gradient rows against the float64 DEFINITION, for both
+    association orders, plus size-independent properties of the fused aggregation: (1) both orders agree,
+    (2) linearity in the features (activation off), (3) the adjoint identity <A x, y> == <x, A^T y> through autograd,
+    (4) rows of users without any rating of a level get no bias of that level (empty segment => 0)."""
     import star_gcn_amd.synthetic as S
     from star_gcn_amd import functional as F
     from star_gcn_amd.plan import MultiLinkPlan
@@ -257,12 +296,15 @@ def test_fused_aggregator_properties_at_ml10m_size():
     lin = f(2 * x1 - 3 * x2, bz, "transform_first")
     ref = 2 * f(x1, bz, "transform_first") - 3 * f(x2, bz, "transform_first")
     assert float((lin - ref).abs().max()) <= 2e-5 * float(ref.abs().max())         # (2)
-    for order in ("transform_first", "aggregate_first"):                           # (3)
+    for order in ("transform_first", "aggregate_first"):                           # (0) + (3)
         xg = x1.clone().requires_grad_(True)
         y = torch.randn(plan.n_dst, U, device="cuda", generator=g)
-        out = f(xg, bz, order)
+        out = f(xg, bs, order)
         out.backward(y)
-        lhs = float((out.detach().double() * y.double()).sum())
+        nd, ns, _w = _rows_vs_definition(plan, x1, ws, bs, out.detach(), y, xg.grad, 64, 4, 1e-5)
+        assert nd >= 64 and ns >= 64
+        const = f(torch.zeros_like(x1), bs, order)
+        lhs = float(((out.detach() - const).double() * y.double()).sum())
         rhs = float((xg.grad.double() * x1.double()).sum())
         assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs)), (order, lhs, rhs)
     zero_x = torch.zeros_like(x1)                                                   # (4) bias only through non-empty levels
@@ -289,46 +331,34 @@ def test_l2_loss_value_and_gradient(n):
     assert float(again) == float(loss)          # fixed-order reduction: bit-reproducible
 
 
-@pytest.mark.skipif(__import__("os").environ.get("SG_TEST_STRESS") != "1",
-                    reason="opt-in (SG_TEST_STRESS=1): ~2 min, 60 M edges, 16 levels, multi-GB matrices")
-def test_fused_aggregator_properties_at_hbm_stress_size():
-    """The HBM-bound stress shape (600 k users x 500 k items, 60 M ratings, 16 levels, dim 256; every gathered matrix
-    0.5 - 8 GB, element offsets beyond 2^31): association orders agree, adjoint identity through autograd, and a
-    float64 spot check of individual output rows against the definition."""
-    import star_gcn_amd.synthetic as S
+def test_fused_aggregator_at_config5_scale():
+    """BASELINE config 5 territory, always on: 620 k users x 600 k items, >= 40 M ratings, 16 levels, dim 256 -- graph
+    generated and planned ON THE DEVICE.  Every R-expanded matrix is ~10 GB (far beyond the 256 MB Infinity Cache) and
+    its element offsets exceed 2^31.  Both association orders: agreement, adjoint identity through autograd, and the
+    float64 definition on sampled output rows and gradient rows (incl. the last rows = largest offsets and the hubs)."""
     from star_gcn_amd import functional as F
-    from star_gcn_amd.plan import MultiLinkPlan
-    graph, eu, ei, vals = S.make_graph("hbm-stress")
-    m = graph["movie", "user"]                      # destination = items: the R-expanded matrices are the 8 GB ones
-    eps, _, ips, sps = m.sample_neighbors(symm=True, use_multi_link=True, num_neighbors=-1)
-    plan = MultiLinkPlan(eps, ips, sps, m.shape[1], "cuda")
+    from star_gcn_amd.device_graph import synthetic_device_graph
+    dg = synthetic_device_graph(620000, 600000, 40000000, 16, "cuda", seed=7)
+    plan = dg.plan("movie")                         # destination = items, sources = users
     R, D, U = plan.R, 256, 256
-    assert R == 16 and plan.nnz == m.nnz and plan.n_dst * R * D * 4 > 2 ** 32
+    assert R == 16 and plan.nnz == dg.nnz >= 40000000
+    assert plan.n_dst * (R * D + R) > 2 ** 31 and plan.n_src * R * U > 2 ** 31          # element offsets beyond int32
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(plan.n_src, D, device="cuda", generator=g) * 0.1
     ws = [torch.randn(U, D, device="cuda", generator=g) * (3.0 / D) ** 0.5 for _ in range(R)]
     bs = [torch.randn(U, device="cuda", generator=g) * 0.1 for _ in range(R)]
+    y = torch.randn(plan.n_dst, U, device="cuda", generator=g)
     outs = {}
     for order in ("transform_first", "aggregate_first"):
         xg = x.clone().requires_grad_(True)
         out = F.multilink_aggregate(xg, ws, bs, plan, accum="sum", act=None, order=order)
-        y = torch.randn(plan.n_dst, U, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
         out.backward(y)
+        _rows_vs_definition(plan, x, ws, bs, out.detach(), y, xg.grad, 24, 9, 1e-5)
         const = F.multilink_aggregate(torch.zeros_like(x), ws, bs, plan, accum="sum", act=None, order=order)
         lhs = float(((out.detach() - const).double() * y.double()).sum())
         rhs = float((xg.grad.double() * x.double()).sum())
         assert abs(lhs - rhs) <= 2e-5 * max(1.0, abs(lhs)), (order, lhs, rhs)
         outs[order] = out.detach()
+        del out, xg, const
     a, b = outs["transform_first"], outs["aggregate_first"]
     assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
-    # float64 definition on a few destination rows, incl. the last one (largest offsets)
-    c_indptr, c_idx, c_w = plan.c_indptr.cpu().numpy(), plan.c_idx.cpu().numpy(), plan.c_w.cpu().numpy()
-    xd = x.double().cpu()
-    for i in (0, 12345, plan.n_dst // 2, plan.n_dst - 1):
-        ref = torch.zeros(U, dtype=torch.float64)
-        for r in range(R):
-            lo, hi = c_indptr[i * R + r], c_indptr[i * R + r + 1]
-            if hi > lo:
-                z = (torch.from_numpy(c_w[lo:hi]).double()[:, None] * xd[c_idx[lo:hi]]).sum(0)
-                ref += ws[r].double().cpu() @ z + float(c_w[lo:hi].astype(np.float64).sum()) * bs[r].double().cpu()
-        assert float((a[i].double().cpu() - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1e-3), i

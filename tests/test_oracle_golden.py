@@ -138,3 +138,37 @@ def test_layer_oracles_agree_dense_vs_segment_order():
                                eps[0][:max(ips[0][-1], 1)], ips[0])
     t = OM.seg_weighted_pool(torch.from_numpy(h).double(), torch.from_numpy(sps[0]).double(), eps[0], ips[0])
     np.testing.assert_allclose(c, t.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def _bwd_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bwd_data_golden.npz"))
+
+
+def test_bwd_data_oracle_matches_reference_derived_goldens():
+    """The data gradient (seg_op.cc:209-240) against vectors derived from the REFERENCE's own forward models by
+    linearity (tests/golden/make_bwd_golden.py): P^T . ograd with P = npy_seg_weighted_pool on the identity, and the
+    embed2 gradient of seg_take_k_corr from npy_seg_take_k_corr on unit tensors.  Both OpenMP placements of the oracle
+    (reference: serial; fair: row-parallel) must agree with them -- at the reference tests' own shapes incl. the
+    (4, 1000, 10000, 50000, 4) one -- and with each other bit for bit."""
+    g = _bwd_golden()
+    tags = sorted({k[:k.rindex("_")] for k in g.files if k.startswith("wp_") and k.endswith("_ddata")})
+    assert len(tags) >= 11
+    for p in tags:
+        w, og, idx, ip = g[p + "_weights"], g[p + "_ograd"], g[p + "_indices"], g[p + "_indptr"]
+        T = int(g[p + "_total_ind_num"])
+        got = O.seg_weighted_pool_bwd_data(w, og, idx, ip, T)
+        fair = O.seg_weighted_pool_bwd_data(w, og, idx, ip, T, fair=True)
+        assert np.array_equal(got, fair), p
+        want = g[p + "_ddata"]
+        assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), p
+        base = np.random.default_rng(0).normal(size=want.shape).astype(np.float32)
+        acc = base.copy()
+        O.seg_weighted_pool_bwd_data(w, og, idx, ip, T, out=acc, req=O.REQ_ADD)
+        assert np.abs(acc - (base + want)).max() <= 2e-5 * max(1.0, np.abs(want).max()), p
+    for p in ("tk_g0", "tk_g1"):
+        # _backward_seg_take_k_corr_embed2(ograd, embed1, ids, indptr): same kernel, `ograd` in the weights slot
+        got = O.seg_weighted_pool_bwd_data(g[p + "_ograd"], g[p + "_embed1"], g[p + "_ids"], g[p + "_indptr"],
+                                           int(g[p + "_total_ind_num"]))
+        want = g[p + "_dembed2"]
+        assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), p
