@@ -19,6 +19,7 @@
 // the tile before it: one barrier per K tile.  A 64-row tile variant (32x64 per wave) fills the chip better when M*N is small.  Workgroups are remapped so
 // that the tiles sharing an A row-panel run on the same XCD (private 4 MiB L2 each).  Small-tile-count /
 // large-K problems (weight gradients: K = #nodes) use deterministic split-K through a workspace.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 
@@ -55,6 +56,32 @@ struct GemmArgs {
 };
 
 void launch_gemm_bf16x6(const GemmArgs& g, bool transA, bool transB, hipStream_t st);   // gemm_bf16x6.hip
+void launch_gemm_x6v2(const GemmArgs& g, bool transA, bool transB, int n_cus, hipStream_t st);   // gemm_x6v2.hip
+bool x6v2_supported(const GemmArgs& g, bool transA, bool transB);
+
+#ifndef SG_GEMM_DEFAULT_BACKEND
+#define SG_GEMM_DEFAULT_BACKEND 2      // 0 exact-fp32 MFMA (this file), 1 bf16x6, 2 x6v2 (wave-specialised bf16x6)
+#endif
+static int gemm_backend() {            // SG_GEMM_BACKEND = fp32 | bf16x6 | x6v2, read once
+  static const int v = [] {
+    const char* e = getenv("SG_GEMM_BACKEND");
+    if (!e) return SG_GEMM_DEFAULT_BACKEND;
+    if (e[0] == 'x') return 2;
+    if (e[0] == 'b') return 1;
+    return 0;
+  }();
+  return v;
+}
+static std::atomic<int> g_backend_override{-1};
+static int cu_count() {
+  static const int n = [] {
+    int dev = 0, c = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0)
+      c = 256;
+    return c;
+  }();
+  return n;
+}
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {
@@ -461,9 +488,14 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
   // backend: exact-fp32 MFMA (this file) or the fp32-accurate bf16x6 split on the bf16 matrix cores (gemm_bf16x6.hip)
   // measured (profiles/): bf16x6 wins for row-major A (forward / data-gradient GEMMs), fp32 MFMA for the transposed-A
   // weight gradients; tiny K has nothing to amortise the split
-  bool use_bx6 = SG_GEMM_DEFAULT_BF16X6 && !transA && K >= 128;
-  if (const char* be = getenv("SG_GEMM_BACKEND")) use_bx6 = (be[0] == 'b') && K >= 1;
-  if (use_bx6) tm = 128;
+  int backend = g_backend_override.load(std::memory_order_relaxed);
+  if (backend < 0) backend = gemm_backend();
+  if (K < 1) backend = 0;
+  g.vecA = (lda % 4 == 0) && aligned(A, 16);
+  g.vecB = (ldb % 4 == 0) && aligned(B, 16);
+  if (backend == 2 && !x6v2_supported(g, transA != 0, transB != 0)) backend = 0;   // odd K / unaligned operands: exact-fp32 kernel
+  const bool use_bx6 = backend == 1, use_v2 = backend == 2;
+  if (use_bx6 || use_v2) tm = 128;
   g.tiles_m = static_cast<int>((M + tm - 1) / tm);
   g.tiles_n = static_cast<int>((N + BN - 1) / BN);
   if (static_cast<int64_t>(g.tiles_m) * g.tiles_n >= (1ll << 31)) return fail(SG_ERR_INVALID, "too many tiles");
@@ -482,7 +514,9 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
     if (tm == 128) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, 128>), grid, dim3(kThreads), 0, st, g); \
     else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, 64>), grid, dim3(kThreads), 0, st, g);            \
   } while (0)
-  if (use_bx6) {
+  if (use_v2) {
+    launch_gemm_x6v2(g, transA != 0, transB != 0, cu_count(), st);
+  } else if (use_bx6) {
     launch_gemm_bf16x6(g, transA != 0, transB != 0, st);
   } else if (transA) {
     if (transB) SG_LAUNCH_GEMM(true, true); else SG_LAUNCH_GEMM(true, false);
@@ -495,6 +529,12 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, g);
   }
   return check_launch("gemm_f32");
+}
+
+// tuning aid (tests, benchmarks): GEMM backend 0 exact-fp32 MFMA, 1 bf16x6, 2 x6v2; -1 = environment / build default
+SG_API int sg_gemm_backend(int backend) {
+  g_backend_override.store(backend < 0 || backend > 2 ? -1 : backend, std::memory_order_relaxed);
+  return SG_OK;
 }
 
 SG_API int sg_act_bwd_hip(float* dpre, const float* dout, const float* out, int64_t n, int act, float slope,

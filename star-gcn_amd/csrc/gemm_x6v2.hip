@@ -1,0 +1,377 @@
+// gemm_x6v2.hip -- fp32-accurate GEMM on the bf16 matrix cores of gfx950, wave-specialised and persistent.
+//
+// Same arithmetic as gemm_bf16x6.hip (every fp32 operand split into three bf16 planes, a product formed from the six
+// plane pairs with i + j <= 4, v_mfma_f32_32x32x16_bf16 with fp32 accumulation: dropped terms <= 2^-24 |a b|), but
+// organised for the matrix pipe instead of around it.  What limited the first version (profiles/) was not
+// the arithmetic: one LDS buffer with two barriers per K tile, the split VALU work and the matrix work of a workgroup
+// running in lock-step (VALU idle while the MFMAs run and vice versa), and a prologue / epilogue bubble per 128x128
+// tile that the K = 256 shapes of the step cannot amortise.  Here:
+//
+//   * 512 threads = 8 waves per workgroup, ONE workgroup per CU (2 x 60 KB LDS stages).  Waves 0-3 are CONSUMERS: each
+//     owns a 64x64 sub-tile (2x2 MFMA tiles, 64 accumulators), reads bf16 fragments with ds_read_b128 and issues
+//     nothing but LDS reads and MFMAs.  Waves 4-7 are PRODUCERS: global loads (two register staging sets, loads run two
+//     K tiles ahead), the fp32 -> 3 x bf16 split (pure VALU) and the LDS stores of the NEXT stage.  One producer and
+//     one consumer wave share each SIMD, so the VALU and the matrix pipe work at the same time by construction.
+//   * double-buffered LDS, ONE barrier per K tile.
+//   * persistent workgroups walk a flat list of work items (tile x split-K slice): the producers run ahead across item
+//     boundaries, so the first K tiles of the next item are already in LDS while the consumers store the finished tile.
+//   * row-contiguous operands (A^T of the weight gradients, B of the data gradients) are loaded with coalesced dword
+//     loads that leave every thread with 16 consecutive k of ONE tile row: the bf16 planes are then written with
+//     16-byte LDS stores at the conflict-free 80-byte row pitch (the first version's transposing 8-byte stores hit
+//     two banks with all 32 lanes).
+//
+// Epilogue / split-K contract identical to gemm_f32.hip (GemmArgs); selected by sg_gemm_f32_hip.
+#include "common.hpp"
+
+namespace sg {
+
+struct GemmArgs {   // must match gemm_f32.hip
+  float* C;
+  const float* A;
+  const float* B;
+  const float* bias;
+  float* ws;
+  long long lda, ldb, ldc;
+  int M, N, K;
+  int act;
+  float slope;
+  int accumulate;
+  int splits, tiles_per_split;
+  int tiles_m, tiles_n;
+  int vecA, vecB;
+};
+
+namespace x6v2 {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int kThreads = 512;
+constexpr int kRole = 256;               // threads per role
+constexpr int ROWB = 80;                 // bytes per LDS row: 32 bf16 (64 B) + 16 B pad -> conflict-free b128 accesses
+constexpr int PLANE = BM * ROWB;         // one bf16 plane of one operand tile
+constexpr int OPER = 3 * PLANE;
+constexpr int STAGE = 2 * OPER;          // A planes then B planes
+constexpr int CPITCH = 68;               // floats per row of a consumer wave's private C staging block (32 x 64 + pad)
+constexpr int CSTAGE = 32 * CPITCH * 4;  // bytes per consumer wave
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+// the six plane pairs (i + j <= 4) of a product, smallest terms first
+__device__ constexpr int kPA[6] = {0, 2, 1, 0, 1, 0};
+__device__ constexpr int kPB[6] = {2, 0, 1, 1, 0, 0};
+
+__device__ __forceinline__ float act_fn(float v, int act, float slope) {
+  switch (act) {
+    case SG_ACT_LEAKY: return v > 0.f ? v : slope * v;
+    case SG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case SG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case SG_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// two consecutive-k fp32 values -> one packed bf16 pair per plane: x = p1 + p2 + p3 with v_cvt_pk_bf16_f32 (round to
+// nearest even) at every level; the residuals are exact fp32 subtractions
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+  f32x2 v = {x0, x1};
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  f32x2 r = {v.x - __builtin_bit_cast(float, p1 << 16), v.y - __builtin_bit_cast(float, p1 & 0xffff0000u)};
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  f32x2 q = {r.x - __builtin_bit_cast(float, p2 << 16), r.y - __builtin_bit_cast(float, p2 & 0xffff0000u)};
+  p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
+}
+
+// ---- producer side: one operand tile (128 rows x 32 k) per K tile, 16 fp32 values per thread -----------------------
+// Every load is issued UNCONDITIONALLY with clamped coordinates (rows / columns beyond the matrix only feed C entries that
+// are never stored; k beyond K is zeroed at store time when K % 32 != 0): a fixed number of load instructions per step is
+// what lets the compiler keep the loads of the next two K tiles in flight (a data-dependent count degrades every wait
+// to vmcnt(0), i.e. exposes the full global-load latency once per K tile -- measured: 83 instead of > 160 TFLOP/s).
+// K-contiguous operand (element (r,k) at p[r*ld + k], K % 4 == 0): thread pt holds rows (pt/8 + 32 i), k = 4 (pt%8) .. +3
+__device__ __forceinline__ void gload_kc(float (&v)[16], const float* __restrict__ p, long long ld, int row0, int k0, int R,
+                                         int K, int pt) {
+  const int k = min(k0 + (pt & 7) * 4, K - 4), rr = row0 + (pt >> 3);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = min(rr + 32 * i, R - 1);
+    const float4 x = *reinterpret_cast<const float4*>(p + static_cast<long long>(row) * ld + k);
+    v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+  }
+}
+template <bool KTAIL>
+__device__ __forceinline__ void sstore_kc(char* __restrict__ s, float (&v)[16], int k0, int K, int pt) {
+  const int kc = (pt & 7) * 4, rr = pt >> 3;
+  const bool dead = KTAIL && (k0 + kc >= K);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned a1, a2, a3, b1, b2, b3;
+    split2(dead ? 0.f : v[4 * i], dead ? 0.f : v[4 * i + 1], a1, a2, a3);
+    split2(dead ? 0.f : v[4 * i + 2], dead ? 0.f : v[4 * i + 3], b1, b2, b3);
+    char* d = s + (rr + 32 * i) * ROWB + kc * 2;
+    *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(a2, b2);
+    *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(a3, b3);
+  }
+}
+// row-contiguous operand (element (k,c) at p[k*ld + c]): thread pt holds tile row c = pt % 128, k = 16 (pt/128) + i -> v[i]
+// every load instruction of a wave reads 64 consecutive floats of one k row (coalesced dword loads)
+__device__ __forceinline__ void gload_rc(float (&v)[16], const float* __restrict__ p, long long ld, int col0, int k0, int Ccols,
+                                         int K, int pt) {
+  const int c = min(col0 + (pt & 127), Ccols - 1), kb = k0 + (pt >> 7) * 16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = p[static_cast<long long>(min(kb + i, K - 1)) * ld + c];
+}
+template <bool KTAIL>
+__device__ __forceinline__ void sstore_rc(char* __restrict__ s, float (&v)[16], int k0, int K, int pt) {
+  char* d = s + (pt & 127) * ROWB + (pt >> 7) * 32;
+  const int kb = k0 + (pt >> 7) * 16;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 8 * h + 2 * j;
+      const float x0 = (KTAIL && kb + i >= K) ? 0.f : v[i], x1 = (KTAIL && kb + i + 1 >= K) ? 0.f : v[i + 1];
+      split2(x0, x1, p1[j], p2[j], p3[j]);
+    }
+    *reinterpret_cast<uint4*>(d + 16 * h) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+    *reinterpret_cast<uint4*>(d + 16 * h + PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+    *reinterpret_cast<uint4*>(d + 16 * h + 2 * PLANE) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+  }
+}
+
+// position of a workgroup in its flat list of work items; item = blockIdx.x + j * gridDim.x; item -> (tile, split slice)
+struct Cursor {
+  int item, kt, kt_end, m0, n0;
+  bool valid;
+};
+__device__ __forceinline__ void cursor_set(Cursor& c, const GemmArgs& g, int item, int n_items, int ktiles) {
+  c.item = item;
+  c.valid = item < n_items;
+  if (!c.valid) return;
+  const int nt = g.tiles_m * g.tiles_n;
+  const int z = item / nt, lin = item - z * nt;
+  // XCD-aware bijective remap of the tile index (hardware places workgroup b on XCD b % 8; a persistent workgroup keeps
+  // its XCD): tiles that share an A row panel are handled by workgroups of the same XCD
+  const int q = nt >> 3, r = nt & 7, x = lin & 7;
+  const int tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (lin >> 3);
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  c.m0 = tm * BM;
+  c.n0 = tn * BN;
+  c.kt = z * g.tiles_per_split;
+  c.kt_end = min(ktiles, c.kt + g.tiles_per_split);
+  (void)z;
+}
+__device__ __forceinline__ void cursor_next(Cursor& c, const GemmArgs& g, int n_items, int ktiles, int stride) {
+  if (!c.valid) return;
+  if (++c.kt >= c.kt_end) cursor_set(c, g, c.item + stride, n_items, ktiles);
+}
+
+template <bool TA, bool TB, bool KTAIL>
+__global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, int n_items) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 4 * CSTAGE];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool consumer = wave < 4;
+  const int pt = t & (kRole - 1);
+  const int ktiles = (g.K + BK - 1) / BK;
+  const int stride = gridDim.x;
+
+  // number of (item, K tile) steps of this workgroup: every thread needs it to run the same number of barriers
+  long long total = 0;
+  {
+    const int per = g.tiles_per_split;
+    for (int item = blockIdx.x; item < n_items; item += stride) {
+      const int z = item / (g.tiles_m * g.tiles_n);
+      const int b = z * per;
+      total += max(0, min(ktiles, b + per) - b);
+    }
+  }
+  if (total == 0) return;
+  const long long total2 = (total + 1) & ~1ll;   // barriers come in pairs (one per LDS stage): no exit in mid-iteration
+
+  if (consumer) {
+    // ---------------------------------------------------------------------------------------------- consumers ----
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    Cursor c;
+    cursor_set(c, g, blockIdx.x, n_items, ktiles);
+    while (c.valid && c.kt >= c.kt_end) cursor_set(c, g, c.item + stride, n_items, ktiles);
+    const int a_off = (wm * 64 + l31) * ROWB + kh * 16;
+    const int b_off = OPER + (wn * 64 + l31) * ROWB + kh * 16;
+    for (long long s = 0; s < total2; ++s) {
+      __syncthreads();               // stage (s & 1) holds step s; the producers go on to fill the other stage
+      if (s >= total) break;         // odd number of steps: the pairing barrier only
+      const char* st = smem + (s & 1) * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            a[i][p] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 32 * ROWB + p * PLANE + ks * 32);
+            b[i][p] = *reinterpret_cast<const bf16x8*>(st + b_off + i * 32 * ROWB + p * PLANE + ks * 32);
+          }
+        // plane pairs ordered smallest terms first; the four accumulators interleave so that consecutive MFMAs never
+        // depend on each other
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kPA[term]], b[j][kPB[term]], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (c.kt + 1 >= c.kt_end) {
+        // ---- epilogue of this item.  The MFMA result layout (col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 kh) gives a
+        // lane ONE column: stored directly, every wave instruction writes 128-byte pieces of 64 different rows, and at
+        // small K the GEMM is bound by exactly those writes (measured: C written at 1.3 TB/s).  Each wave therefore
+        // turns its 32 x 64 blocks around in a private LDS block and writes 16 bytes per lane, 256 contiguous bytes per row.
+        const bool partial = (g.splits > 1);
+        const int z = c.item / (g.tiles_m * g.tiles_n);
+        float* out = partial ? g.ws + static_cast<long long>(z) * g.M * g.N : g.C;
+        const long long ldo = partial ? g.N : g.ldc;
+        const bool vec_c = ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((ldo & 3) == 0);
+        float* cst = reinterpret_cast<float*>(smem + 2 * STAGE + wave * CSTAGE);
+        const int c4 = (lane & 15) * 4, r4 = lane >> 4;
+        const int col = c.n0 + wn * 64 + c4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!partial && g.bias) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bv[q] = (col + q < g.N) ? g.bias[col + q] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              cst[((e & 3) + 8 * (e >> 2) + 4 * kh) * CPITCH + j * 32 + l31] = acc[i][j][e];
+              acc[i][j][e] = 0.f;
+            }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int r = r4 + 4 * it;
+            const int row = c.m0 + wm * 64 + i * 32 + r;
+            const float4 t4 = *reinterpret_cast<const float4*>(cst + r * CPITCH + c4);
+            float v[4] = {t4.x, t4.y, t4.z, t4.w};
+            if (row < g.M && col < g.N) {
+              float* o = out + static_cast<long long>(row) * ldo + col;
+              const bool full = vec_c && (col + 3 < g.N);
+              if (!partial) {
+                if (g.accumulate) {
+                  if (full) {
+                    const float4 old = *reinterpret_cast<const float4*>(o);
+                    v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+                  } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (col + q < g.N) v[q] += o[q];
+                  }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q] + bv[q], g.act, g.slope);
+              }
+              if (full) {
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (col + q < g.N) o[q] = v[q];
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+      }
+      cursor_next(c, g, n_items, ktiles, stride);
+    }
+  } else {
+    // ---------------------------------------------------------------------------------------------- producers ----
+    float va0[16], vb0[16], va1[16], vb1[16];     // two staging sets: tile of step s lives in set (s & 1)
+    int k0_0 = 0, k0_1 = 0;                       // first k of the tile held by each set (K-tail masking)
+    Cursor ld;      // next step to LOAD
+    cursor_set(ld, g, blockIdx.x, n_items, ktiles);
+    while (ld.valid && ld.kt >= ld.kt_end) cursor_set(ld, g, ld.item + stride, n_items, ktiles);
+    int lm0 = ld.m0, ln0 = ld.n0, lk0 = ld.kt * BK;     // coordinates of the next load (held at the last valid step)
+    auto gload = [&](float (&va)[16], float (&vb)[16], int& k0_set) {
+      if (TA) gload_rc(va, g.A, g.lda, lm0, lk0, g.M, g.K, pt); else gload_kc(va, g.A, g.lda, lm0, lk0, g.M, g.K, pt);
+      if (TB) gload_kc(vb, g.B, g.ldb, ln0, lk0, g.N, g.K, pt); else gload_rc(vb, g.B, g.ldb, ln0, lk0, g.N, g.K, pt);
+      k0_set = lk0;
+      cursor_next(ld, g, n_items, ktiles, stride);
+      if (ld.valid) { lm0 = ld.m0; ln0 = ld.n0; lk0 = ld.kt * BK; }     // scalar bookkeeping only: no load is conditional
+      // opaque to the optimiser: past the last step the coordinates stop changing, and the compiler would otherwise
+      // prove the next loads redundant, make them conditional and lose the load count again
+      asm volatile("" : "+s"(lm0), "+s"(ln0), "+s"(lk0));
+    };
+    auto sstore = [&](int stage, float (&va)[16], float (&vb)[16], int k0_set) {
+      char* st = smem + stage * STAGE;
+      if (TA) sstore_rc<KTAIL>(st, va, k0_set, g.K, pt); else sstore_kc<KTAIL>(st, va, k0_set, g.K, pt);
+      if (TB) sstore_kc<KTAIL>(st + OPER, vb, k0_set, g.K, pt); else sstore_rc<KTAIL>(st + OPER, vb, k0_set, g.K, pt);
+    };
+    // Steady state, identical on the entry edge and on the back edge of the loop (so the compiler's wait counts are
+    // exact): the loads of two steps are in flight, the older set is converted and stored, then refilled.
+    //   producers:  store(s) -> stage0 | B | store(s+1) -> stage1 | B | store(s+2) -> stage0 | B ...
+    //   consumers:                       B | multiply stage0        B | multiply stage1         B ...
+    // A stage is rewritten only after the barrier that follows its multiplication.  Past the last step the producers
+    // keep converting / loading clamped data that nobody reads: cheaper than a data-dependent load count.
+    gload(va0, vb0, k0_0);           // step 0
+    gload(va1, vb1, k0_1);           // step 1
+    // (a mid-loop exit for an odd step count gives the loop a second path to its header on which only one set is in
+    //  flight, and the compiler then waits for BOTH sets at the top of every iteration -- total2 keeps the body branch-free)
+    for (long long s = 0; s < total2; s += 2) {
+      sstore(0, va0, vb0, k0_0);     // step s
+      gload(va0, vb0, k0_0);         // step s + 2
+      __syncthreads();
+      sstore(1, va1, vb1, k0_1);     // step s + 1
+      gload(va1, vb1, k0_1);         // step s + 3
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace x6v2
+
+int x6v2_items(const GemmArgs& g) { return g.tiles_m * g.tiles_n * g.splits; }
+
+// x6v2 handles 16-byte aligned operands whose K-contiguous dimension is a multiple of 4 (everything the step produces);
+// sg_gemm_f32_hip falls back to the exact-fp32 kernel otherwise
+bool x6v2_supported(const GemmArgs& g, bool transA, bool transB) {
+  if (!g.vecA || !g.vecB || g.K < 4 || g.M < 1 || g.N < 1) return false;
+  if ((!transA || transB) && (g.K % 4 != 0)) return false;     // a K-contiguous operand is loaded as float4 along k
+  return true;
+}
+
+// launched by sg_gemm_f32_hip (gemm_f32.hip) when the x6v2 backend is selected; tiles are 128 x 128, g.tiles_m / tiles_n
+// must have been computed for them
+void launch_gemm_x6v2(const GemmArgs& g, bool transA, bool transB, int n_cus, hipStream_t st) {
+  const int n_items = x6v2_items(g);
+  const int grid_x = n_items < n_cus ? n_items : n_cus;      // persistent: at most one workgroup per CU
+  dim3 grid(static_cast<unsigned>(grid_x));
+  const bool ktail = (g.K % x6v2::BK) != 0;
+#define SG_X6V2(TA_, TB_)                                                                                              \
+  do {                                                                                                                \
+    if (ktail) hipLaunchKernelGGL((x6v2::gemm_x6v2_kernel<TA_, TB_, true>), grid, dim3(x6v2::kThreads), 0, st, g, n_items); \
+    else hipLaunchKernelGGL((x6v2::gemm_x6v2_kernel<TA_, TB_, false>), grid, dim3(x6v2::kThreads), 0, st, g, n_items);      \
+  } while (0)
+  if (transA) {
+    if (transB) SG_X6V2(true, true); else SG_X6V2(true, false);
+  } else {
+    if (transB) SG_X6V2(false, true); else SG_X6V2(false, false);
+  }
+#undef SG_X6V2
+}
+
+}  // namespace sg

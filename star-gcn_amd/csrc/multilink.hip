@@ -125,7 +125,12 @@ int make_dims(Dims* d, const sg_multilink_plan* p, int64_t in_dim, int64_t upl, 
   d->RU = d->R * upl;
   d->outw = d->stack ? d->RU : upl;
   const int64_t used = d->R * in_dim + d->R;
-  d->ld = used + ((4 - used % 4) % 4);
+  // row pitch of the R-expanded matrices (Zext / dZ): every level block of a row is gathered / scattered as one burst of
+  // 4*D bytes, so when that burst is a multiple of 256 B the pitch is rounded to 256 B as well -- otherwise (pitch =
+  // R*D + R rounded to 16 B, round 1) every row starts 64 B off a cache-line boundary: 9 instead of 8 lines per 1 KiB
+  // burst and 3 instead of 2 per 256-B column slice (measured: the dZ gather 1.27 ms vs 0.84 ms for the aligned H gather)
+  const int64_t align = (in_dim % 64 == 0) ? 64 : 4;
+  d->ld = (used + align - 1) / align * align;
   return SG_OK;
 }
 

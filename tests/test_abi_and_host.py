@@ -151,8 +151,9 @@ def test_fused_aggregator_entry_sizes_orders_and_errors():
     assert lib.sg_multilink_agg_resolve_order(ref, 0) == 2          # expansion on the smaller (destination) side
     assert lib.sg_multilink_agg_resolve_order(ref, 1) == 1
     D, U = 64, 50
-    ld = 5 * D + 5 + 3                                              # R*D + R rowsum columns, padded to a multiple of 4
+    ld = 6 * 64                          # R*D + R rowsum columns = 325, row pitch rounded to 256 B because 4*D is (64 floats)
     assert lib.sg_multilink_agg_saved_bytes(ref, D, U, 2, 0) == 300 * ld * 4
+    assert lib.sg_multilink_agg_saved_bytes(ref, 50, U, 2, 0) == 300 * (5 * 50 + 5 + 1) * 4   # otherwise to 16 B
     assert lib.sg_multilink_agg_saved_bytes(ref, D, U, 1, 0) == 0
     for order in (1, 2):
         for accum in (0, 1):

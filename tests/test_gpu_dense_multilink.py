@@ -24,7 +24,9 @@ def rel_close(got, ref, tol=1e-5, what=""):
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("tile_rows", ["64", "128"])
 def test_gemm_layouts_and_edges(M, N, K, ta, tb, tile_rows, monkeypatch):
+    from star_gcn_amd import _lib as L
     from star_gcn_amd import ops
+    L.lib().sg_gemm_backend(0)                    # the exact-fp32 MFMA kernel, whatever the build default is
     monkeypatch.setenv("SG_GEMM_TM", tile_rows)   # exercise both tile shapes (normally picked by a wave-count model)
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     A = torch.randn((K, M) if ta else (M, K), generator=g)
@@ -38,16 +40,27 @@ def test_gemm_layouts_and_edges(M, N, K, ta, tb, tile_rows, monkeypatch):
     c0 = torch.randn(M, N, generator=g)
     out = ops.gemm(A.cuda(), B.cuda(), trans_a=ta, trans_b=tb, out=c0.clone().cuda(), accumulate=True)
     rel_close(out, ref + c0.double(), 2e-6 * max(1, K ** 0.5), "accumulate")
+    L.lib().sg_gemm_backend(-1)
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1, 1, 1), (130, 250, 75), (257, 64, 2570), (64, 515, 64),
                                    (1000, 75, 250), (5, 300, 1027), (700, 2576, 256)])
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
-def test_gemm_bf16x6_backend_is_fp32_accurate(M, N, K, ta, tb, monkeypatch):
-    """The bf16 matrix-core backend (three bf16 planes per operand, six MFMAs per product group) must meet the SAME
-    fp64-referenced tolerance as the exact-fp32 MFMA kernel, on every layout and on ragged edges."""
+@pytest.mark.parametrize("backend", [1, 2])
+def test_gemm_bf16x6_backend_is_fp32_accurate(M, N, K, ta, tb, backend):
+    """The bf16 matrix-core backends (three bf16 planes per operand, six MFMAs per product group; 1 = first version,
+    2 = wave-specialised persistent x6v2) must meet the SAME fp64-referenced tolerance as the exact-fp32 MFMA kernel,
+    on every layout and on ragged edges."""
+    from star_gcn_amd import _lib as L
     from star_gcn_amd import ops
-    monkeypatch.setenv("SG_GEMM_BACKEND", "bf16x6")
+    try:
+        L.lib().sg_gemm_backend(backend)
+        _bf16_backend_case(M, N, K, ta, tb, ops, L)
+    finally:
+        L.lib().sg_gemm_backend(-1)
+
+
+def _bf16_backend_case(M, N, K, ta, tb, ops, L):
     g = torch.Generator().manual_seed(M * 5 + N * 11 + K)
     scale_rows = torch.logspace(-3, 3, M)   # rows of op(A) span six decades
     A = torch.randn((K, M) if ta else (M, K), generator=g) * (scale_rows.view(1, -1) if ta else scale_rows.view(-1, 1))
@@ -60,14 +73,49 @@ def test_gemm_bf16x6_backend_is_fp32_accurate(M, N, K, ta, tb, monkeypatch):
     err = (out.double().cpu() - want).abs()
     mag = (A.double().abs().t() if ta else A.double().abs()) @ (B.double().abs().t() if tb else B.double().abs()) + bias.abs().double()
     assert float((err / (mag + 1e-30)).max()) <= 4e-7 * max(1.0, K ** 0.5), float((err / (mag + 1e-30)).max())
-    monkeypatch.setenv("SG_GEMM_BACKEND", "fp32")
+    c0 = torch.randn(M, N, generator=g)
+    acc = ops.gemm(A.cuda(), B.cuda(), trans_a=ta, trans_b=tb, out=c0.clone().cuda(), accumulate=True)
+    eacc = (acc.double().cpu() - (ref + c0.double())).abs() / (mag + c0.double().abs() + 1e-30)
+    assert float(eacc.max()) <= 4e-7 * max(1.0, K ** 0.5)
+    L.lib().sg_gemm_backend(0)
     out32 = ops.gemm(A.cuda(), B.cuda(), trans_a=ta, trans_b=tb, bias=bias.cuda(), act="leaky", slope=0.1)
     e32 = float(((out32.double().cpu() - want).abs() / (mag + 1e-30)).max())
     assert float((err / (mag + 1e-30)).max()) <= 4 * e32 + 2e-7     # same accuracy class as the exact-fp32 MFMA kernel
 
 
-def test_gemm_split_k_and_strided_views():
+@pytest.mark.parametrize("backend", [0, 1, 2])
+def test_gemm_split_k_and_strided_views(backend):
+    from star_gcn_amd import _lib as L
     from star_gcn_amd import ops
+    try:
+        L.lib().sg_gemm_backend(backend)
+        _split_k_case(ops)
+    finally:
+        L.lib().sg_gemm_backend(-1)
+
+
+def test_gemm_x6v2_persistent_multi_item_shapes():
+    """x6v2 walks several work items per workgroup once there are more tiles than CUs, and several K slices per tile in
+    split-K mode: shapes with > 256 tiles, short K (prologue / epilogue hand-over between items), long K, all layouts."""
+    from star_gcn_amd import _lib as L
+    from star_gcn_amd import ops
+    g = torch.Generator().manual_seed(9)
+    try:
+        L.lib().sg_gemm_backend(2)
+        for (M, N, K, ta, tb) in [(5000, 1300, 32, False, True), (4200, 1030, 96, False, False), (2304, 2560, 256, False, True),
+                                  (640, 300, 30000, True, False), (3000, 2576, 64, True, True), (129, 129, 33, False, True)]:
+            A = torch.randn((K, M) if ta else (M, K), generator=g)
+            B = torch.randn((N, K) if tb else (K, N), generator=g)
+            ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+            out = ops.gemm(A.cuda(), B.cuda(), trans_a=ta, trans_b=tb)
+            rel_close(out, ref, 2e-6 * max(1, K ** 0.5), "x6v2 %s" % ((M, N, K, ta, tb),))
+            again = ops.gemm(A.cuda(), B.cuda(), trans_a=ta, trans_b=tb)
+            assert torch.equal(out, again)                      # deterministic
+    finally:
+        L.lib().sg_gemm_backend(-1)
+
+
+def _split_k_case(ops):
     g = torch.Generator().manual_seed(1)
     # weight-gradient shape: tiny M,N, huge K (split-K path), operands are column slices of wider matrices
     Kbig, M, N = 40000, 96, 200

@@ -28,7 +28,7 @@ def timeit(fn, n=10, warm=3):
 
 def gemm_cases():
     nu, ni, R, D = 69878, 10677, 10, 256
-    ld = R * D + 16
+    ld = (R * D + R + 63) // 64 * 64
     cases = [("TF fwd   H=X Wcat^T", ni, R * D, D, False, True), ("AF fwd   Zext Wext^T", ni, D, ld, False, True),
              ("out_fc user", nu, D, D, False, True), ("dX = dH Wcat (NN)", ni, D, R * D, False, False),
              ("dW = dH^T X (TN)", R * D, D, ni, True, False), ("dZ = dpre Wext (NN)", ni, ld, D, False, False),
@@ -37,10 +37,40 @@ def gemm_cases():
     for name, M, N, K, ta, tb in cases:
         a = torch.randn((K, M) if ta else (M, K), device="cuda")
         b = torch.randn((N, K) if tb else (K, N), device="cuda")
-        t = timeit(lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb))
+        from star_gcn_amd import _lib as L
+        res = []
+        for be, nm in ((0, "fp32"), (1, "x6"), (2, "x6v2")):
+            L.lib().sg_gemm_backend(be)
+            t = timeit(lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb))
+            res.append("%s %6.3f ms %5.1f TF/s" % (nm, t * 1e3, 2.0 * M * N * K / t / 1e12))
+        L.lib().sg_gemm_backend(-1)
         tt = timeit(lambda: torch.matmul(a.t() if ta else a, b.t() if tb else b))
-        print("gemm %-28s M=%6d N=%5d K=%6d  %7.3f ms  %6.1f TF/s   (torch/rocBLAS %7.3f ms %6.1f TF/s)" %
-              (name, M, N, K, t * 1e3, 2.0 * M * N * K / t / 1e12, tt * 1e3, 2.0 * M * N * K / tt / 1e12))
+        print("gemm %-26s M=%6d N=%5d K=%6d  %s   (torch %6.3f ms %5.1f TF/s)" %
+              (name, M, N, K, "  ".join(res), tt * 1e3, 2.0 * M * N * K / tt / 1e12), flush=True)
+
+
+def gemm_big_cases():
+    """GEMM shapes of the 1-GPU shard of BASELINE config 5 (1.25 M x 1 M nodes, R = 16, dim 256), tile-height sweep"""
+    nu, ni, R, D = 1250000, 1000000, 16, 256
+    ld = (R * D + R + 63) // 64 * 64
+    cases = [("c5 TF fwd H=X Wcat^T", ni, R * D, D, False, True), ("c5 AF fwd Zext Wext^T", ni, D, ld, False, True),
+             ("c5 out_fc user", nu, D, D, False, True), ("c5 dX = dH Wcat (NN)", ni, D, R * D, False, False),
+             ("c5 dW = dH^T X (TN)", R * D, D, ni, True, False), ("c5 dZ = dpre Wext (NN)", ni, ld, D, False, False),
+             ("c5 dWext (TN)", D, ld, ni, True, False)]
+    for name, M, N, K, ta, tb in cases:
+        a = torch.randn((K, M) if ta else (M, K), device="cuda")
+        b = torch.randn((N, K) if tb else (K, N), device="cuda")
+        res = []
+        from star_gcn_amd import _lib as L
+        for be, nm in ((0, "fp32"), (1, "x6"), (2, "x6v2")):
+            L.lib().sg_gemm_backend(be)
+            t = timeit(lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb), n=5, warm=2)
+            res.append("%s %8.3f ms %6.1f TF/s" % (nm, t * 1e3, 2.0 * M * N * K / t / 1e12))
+        L.lib().sg_gemm_backend(-1)
+        tt = timeit(lambda: torch.matmul(a.t() if ta else a, b.t() if tb else b), n=5, warm=2)
+        print("gemm %-24s M=%7d N=%5d K=%7d  %s   (torch %8.3f ms %6.1f TF/s)" %
+              (name, M, N, K, "  ".join(res), tt * 1e3, 2.0 * M * N * K / tt / 1e12), flush=True)
+        del a, b
 
 
 def gather_cases():
@@ -69,5 +99,7 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "gather"]
     if "gemm" in which:
         gemm_cases()
+    if "gemm5" in which:
+        gemm_big_cases()
     if "gather" in which:
         gather_cases()
