@@ -11,7 +11,7 @@ import torch  # imported first so libamdhip64 (SONAME libamdhip64.so.7) is the o
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libstargcn_hip.so")
+SO_PATH = os.environ.get("SG_LIB_OVERRIDE") or os.path.join(CSRC, "libstargcn_hip.so")   # override: ablation builds (tools/)
 
 REQ_NULL, REQ_WRITE, REQ_ADD = 0, 1, 3
 POOL = {"sum": 0, "avg": 1, "max": 2}

@@ -41,6 +41,10 @@ struct GemmArgs {   // must match gemm_f32.hip
   int vecA, vecB;
 };
 
+#ifndef SG_X6V2_ABLATE
+#define SG_X6V2_ABLATE 0      // development: 1 producers skip split + LDS stores, 2 consumers skip MFMAs, 3 consumers skip LDS reads
+#endif
+
 namespace x6v2 {
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -169,7 +173,10 @@ __device__ __forceinline__ void cursor_next(Cursor& c, const GemmArgs& g, int n_
   if (++c.kt >= c.kt_end) cursor_set(c, g, c.item + stride, n_items, ktiles);
 }
 
-template <bool TA, bool TB, bool KTAIL>
+// NSETS: register staging sets of the producers = how many K tiles of global loads are in flight (measured L2 / HBM load
+// latency under this kernel's own traffic is about 2 us = three K-tile periods).  Bounded by the 6-bit vmcnt counter:
+// a set is 8 (both operands K-contiguous), 20 or 32 load instructions.
+template <bool TA, bool TB, bool KTAIL, int NSETS>
 __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, int n_items) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 4 * CSTAGE];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -189,11 +196,18 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
     }
   }
   if (total == 0) return;
-  const long long total2 = (total + 1) & ~1ll;   // barriers come in pairs (one per LDS stage): no exit in mid-iteration
+  constexpr int kUnroll = (NSETS % 2 == 0) ? NSETS : 2 * NSETS;   // steps per producer-loop iteration (stage parity repeats)
+  const long long total2 = (total + kUnroll - 1) / kUnroll * kUnroll;   // whole iterations only: no exit in mid-iteration
 
   if (consumer) {
     // ---------------------------------------------------------------------------------------------- consumers ----
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kh = lane >> 5;
+    // The consumer's MFMAs and its partner producer's VALU stream are arbitrated on one SIMD issue port by priority,
+    // then age.  At equal priority the producer's ~270 independent VALU instructions per K tile win every slot and the
+    // MFMAs only start once the burst is over (PMC: matrix pipe busy 44 %, VALU + MFMA issue time adds up to the step
+    // time).  With the consumer at a higher static priority an MFMA takes its slot as soon as the pipe frees up and the
+    // VALU work fills the 32-cycle shadows in between.
+    __builtin_amdgcn_s_setprio(3);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -217,11 +231,17 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int p = 0; p < 3; ++p) {
+#if SG_X6V2_ABLATE != 3
             a[i][p] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 32 * ROWB + p * PLANE + ks * 32);
             b[i][p] = *reinterpret_cast<const bf16x8*>(st + b_off + i * 32 * ROWB + p * PLANE + ks * 32);
+#else
+            a[i][p] = __builtin_bit_cast(bf16x8, make_uint4(s, ks, i, p));
+            b[i][p] = __builtin_bit_cast(bf16x8, make_uint4(p, i, ks, s));
+#endif
           }
         // plane pairs ordered smallest terms first; the four accumulators interleave so that consecutive MFMAs never
         // depend on each other
+#if SG_X6V2_ABLATE != 2
 #pragma unroll
         for (int term = 0; term < 6; ++term) {
 #pragma unroll
@@ -230,6 +250,12 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
             for (int j = 0; j < 2; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kPA[term]], b[j][kPB[term]], acc[i][j], 0, 0, 0);
         }
+#else
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) acc[i][0][p] += static_cast<float>(a[i][p][0]) + static_cast<float>(b[i][p][0]);
+#endif
       }
       if (c.kt + 1 >= c.kt_end) {
         // ---- epilogue of this item.  The MFMA result layout (col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 kh) gives a
@@ -300,8 +326,8 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
     }
   } else {
     // ---------------------------------------------------------------------------------------------- producers ----
-    float va0[16], vb0[16], va1[16], vb1[16];     // two staging sets: tile of step s lives in set (s & 1)
-    int k0_0 = 0, k0_1 = 0;                       // first k of the tile held by each set (K-tail masking)
+    float va[NSETS][16], vb[NSETS][16];           // staging sets: the tile of step s lives in set (s % NSETS)
+    int k0s[NSETS];                               // first k of the tile held by each set (K-tail masking)
     Cursor ld;      // next step to LOAD
     cursor_set(ld, g, blockIdx.x, n_items, ktiles);
     while (ld.valid && ld.kt >= ld.kt_end) cursor_set(ld, g, ld.item + stride, n_items, ktiles);
@@ -318,26 +344,30 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
     };
     auto sstore = [&](int stage, float (&va)[16], float (&vb)[16], int k0_set) {
       char* st = smem + stage * STAGE;
+#if SG_X6V2_ABLATE == 1
+      if (va[0] + vb[0] + va[15] + vb[15] + va[7] + vb[9] == 1.2345e-30f) *reinterpret_cast<float*>(st) = 1.f;   // keep the loads
+      return;
+#endif
       if (TA) sstore_rc<KTAIL>(st, va, k0_set, g.K, pt); else sstore_kc<KTAIL>(st, va, k0_set, g.K, pt);
       if (TB) sstore_kc<KTAIL>(st + OPER, vb, k0_set, g.K, pt); else sstore_rc<KTAIL>(st + OPER, vb, k0_set, g.K, pt);
     };
     // Steady state, identical on the entry edge and on the back edge of the loop (so the compiler's wait counts are
-    // exact): the loads of two steps are in flight, the older set is converted and stored, then refilled.
+    // exact): the loads of NSETS steps are in flight, the oldest set is converted and stored, then refilled.
     //   producers:  store(s) -> stage0 | B | store(s+1) -> stage1 | B | store(s+2) -> stage0 | B ...
     //   consumers:                       B | multiply stage0        B | multiply stage1         B ...
     // A stage is rewritten only after the barrier that follows its multiplication.  Past the last step the producers
     // keep converting / loading clamped data that nobody reads: cheaper than a data-dependent load count.
-    gload(va0, vb0, k0_0);           // step 0
-    gload(va1, vb1, k0_1);           // step 1
-    // (a mid-loop exit for an odd step count gives the loop a second path to its header on which only one set is in
-    //  flight, and the compiler then waits for BOTH sets at the top of every iteration -- total2 keeps the body branch-free)
-    for (long long s = 0; s < total2; s += 2) {
-      sstore(0, va0, vb0, k0_0);     // step s
-      gload(va0, vb0, k0_0);         // step s + 2
-      __syncthreads();
-      sstore(1, va1, vb1, k0_1);     // step s + 1
-      gload(va1, vb1, k0_1);         // step s + 3
-      __syncthreads();
+    // (a mid-loop exit gives the loop a second path to its header on which fewer sets are in flight, and the compiler
+    //  then waits for ALL sets at the top of every iteration -- total2 keeps the body branch-free)
+#pragma unroll
+    for (int u = 0; u < NSETS; ++u) gload(va[u], vb[u], k0s[u]);      // steps 0 .. NSETS-1
+    for (long long s = 0; s < total2; s += kUnroll) {
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        sstore(u & 1, va[u % NSETS], vb[u % NSETS], k0s[u % NSETS]);  // step s + u
+        gload(va[u % NSETS], vb[u % NSETS], k0s[u % NSETS]);          // step s + u + NSETS
+        __syncthreads();
+      }
     }
   }
 }
@@ -361,15 +391,16 @@ void launch_gemm_x6v2(const GemmArgs& g, bool transA, bool transB, int n_cus, hi
   const int grid_x = n_items < n_cus ? n_items : n_cus;      // persistent: at most one workgroup per CU
   dim3 grid(static_cast<unsigned>(grid_x));
   const bool ktail = (g.K % x6v2::BK) != 0;
-#define SG_X6V2(TA_, TB_)                                                                                              \
-  do {                                                                                                                \
-    if (ktail) hipLaunchKernelGGL((x6v2::gemm_x6v2_kernel<TA_, TB_, true>), grid, dim3(x6v2::kThreads), 0, st, g, n_items); \
-    else hipLaunchKernelGGL((x6v2::gemm_x6v2_kernel<TA_, TB_, false>), grid, dim3(x6v2::kThreads), 0, st, g, n_items);      \
+#define SG_X6V2(TA_, TB_, NS_)                                                                                              \
+  do {                                                                                                                     \
+    if (ktail) hipLaunchKernelGGL((x6v2::gemm_x6v2_kernel<TA_, TB_, true, NS_>), grid, dim3(x6v2::kThreads), 0, st, g, n_items); \
+    else hipLaunchKernelGGL((x6v2::gemm_x6v2_kernel<TA_, TB_, false, NS_>), grid, dim3(x6v2::kThreads), 0, st, g, n_items);      \
   } while (0)
+  // loads per set: NT 8, NN / TT 20, TN 32; at most 63 may be outstanding per wave
   if (transA) {
-    if (transB) SG_X6V2(true, true); else SG_X6V2(true, false);
+    if (transB) SG_X6V2(true, true, 3); else SG_X6V2(true, false, 2);
   } else {
-    if (transB) SG_X6V2(false, true); else SG_X6V2(false, false);
+    if (transB) SG_X6V2(false, true, 4); else SG_X6V2(false, false, 3);
   }
 #undef SG_X6V2
 }
