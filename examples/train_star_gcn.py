@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--lr", type=float, default=0.002)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--resident", action="store_true")
+    ap.add_argument("--device-sampler", action="store_true",
+                    help="with --resident: draw the rating batch / reconstruction nodes and build the batch plans on the "
+                         "device as well (star_gcn_amd/device_sampler.py): no per-iteration host work besides launches")
     ap.add_argument("--eval-every", type=int, default=20)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -69,25 +72,38 @@ def main():
     recon_it = it.recon_nodes_sampler(1000000)
     opt = None
     resident = None
+    dsampler = None
     if args.resident:
         from star_gcn_amd.resident import ResidentPlan
         resident = ResidentPlan(net, it.train_graph, device=dev)
+        if args.device_sampler:
+            from star_gcn_amd.device_sampler import DeviceBatchSampler
+            dsampler = DeviceBatchSampler(resident, args.batch, embed_P_mask=0.1, embed_p_zero=0.0, seed=args.seed)
     t0 = time.time()
     t_train = 0.0
     for step in range(1, args.iters + 1):
         torch.cuda.synchronize()
         t_it = time.perf_counter()
-        batch = next(rating_it)
-        pairs, ratings = batch[0], batch[1]
-        noise, recon_ids, _ = next(recon_it)
-        if resident is not None:    # never aggregate over the edges being predicted: masked on the device
+        if dsampler is not None:    # samplers, batch plans and edge masking all on the device
+            dbatch = dsampler.next_batch()
+            preds, recons, gt = net.run(resident.set_batch_device(dbatch))
+            y = (dbatch["ratings"] - mean) / std
+            batch = None
+        else:
+            batch = next(rating_it)
+            pairs, ratings = batch[0], batch[1]
+            noise, recon_ids, _ = next(recon_it)
+        if batch is None:
+            pass
+        elif resident is not None:    # never aggregate over the edges being predicted: masked on the device
             preds, recons, gt = net.run(resident.set_batch(rating_node_pairs=pairs, edge_ids=batch[2],
                                                            embed_noise_dict=noise, recon_node_ids_dict=recon_ids))
         else:                       # reference-style: new CSRs, new plan, new uploads every iteration
             g = it.train_graph.remove_edges_by_id(U, I, pairs)
             preds, recons, gt = net(g, rating_node_pairs=pairs, embed_noise_dict=noise, recon_node_ids_dict=recon_ids,
                                     device=dev)
-        y = torch.from_numpy(((ratings - mean) / std).astype(np.float32)).to(dev)
+        if batch is not None:
+            y = torch.from_numpy(((ratings - mean) / std).astype(np.float32)).to(dev)
         loss = M.star_gcn_loss(preds, recons, gt, y, recon_lambda=0.1)
         if opt is None:   # parameters are created lazily on the first forward
             opt = torch.optim.Adam(net.parameters(), lr=args.lr)
@@ -104,7 +120,7 @@ def main():
             net.train()
             print("iter %4d  loss %.4f  valid RMSE %.4f  (%.1f s)" % (step, float(loss.detach()), rmse, time.time() - t0))
     print("training iterations: %.2f ms/iter (%s planning, batch %d, after 3 warm-up iterations)" %
-          (1e3 * t_train / max(args.iters - 3, 1), "resident/device" if resident is not None else "host re-", args.batch))
+          (1e3 * t_train / max(args.iters - 3, 1), ("resident plan + device samplers" if dsampler is not None else "resident/device") if resident is not None else "host re-", args.batch))
     net.eval()
     print("test RMSE %.4f" % evaluate(net, it, it.test_graph, "test", mean, std, dev, lo, hi))
 

@@ -395,6 +395,28 @@ int sg_get_support_hip(float* support, const int32_t* row_degrees, const int32_t
 int sg_level_index_hip(int32_t* level, const float* values, const float* multi_link, int64_t n, int64_t num_links,
                        void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (12) per-iteration samplers and batch plans ON THE DEVICE.  Reference: DataIterator.rating_sampler /
+ *      recon_nodes_sampler (iterators.py:264-370) draw with numpy's Mersenne Twister on the host and every batch's index
+ *      arrays are uploaded.  The device samplers are COUNTER-BASED (a keyed 4-round Feistel bijection of the index range
+ *      with cycle walking: element i of the sample depends on (seed, counter, i) only): the same distribution -- a
+ *      uniform sample without replacement -- but deliberately not the reference's random stream.
+ *   sg_sample_distinct_hip     k distinct uniform elements of [0, n)
+ *   sg_recon_mask_hip          noise / reconstruction-node arrays of one node type
+ *   sg_sort_i32_hip, sg_bounds_from_sorted_hip, sg_gather_i32_hip, sg_inverse_index_hip
+ *                              the pieces a batch plan is made of: sorted batch edge ids -> (user, item) pairs grouped by
+ *                              user (CSR) -> transpose (sg_build_transpose_hip); unique take -> inverse index
+ * ---------------------------------------------------------------------------------------------- */
+int sg_sample_distinct_hip(int32_t* out, int64_t n, int64_t k, uint64_t seed, uint64_t counter, void* stream);
+int sg_recon_mask_hip(int32_t* noise, int32_t* recon, int64_t n, int64_t k, float p_zero, uint64_t seed, uint64_t counter,
+                      void* stream);
+size_t sg_sort_i32_workspace_bytes(int64_t n);
+int sg_sort_i32_hip(int32_t* keys_out, int32_t* vals_out, const int32_t* keys, const int32_t* vals, int64_t n,
+                    int64_t max_key, void* workspace, size_t workspace_bytes, void* stream);
+int sg_bounds_from_sorted_hip(int32_t* out_indptr, const int32_t* sorted_keys, int64_t n, int64_t total, void* stream);
+int sg_gather_i32_hip(int32_t* dst, const int32_t* src, const int32_t* pos, int64_t n, void* stream);
+int sg_inverse_index_hip(int32_t* inv, const int32_t* ids, int64_t n_ids, int64_t n_rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,13 @@ _SIGS = {
     "sg_count_indices_hip": (_INT, [_P, _P, _I64, _I64, _P]),
     "sg_get_support_hip": (_INT, [_P] * 5 + [_I64, _INT, _P]),
     "sg_level_index_hip": (_INT, [_P] * 3 + [_I64, _I64, _P]),
+    "sg_sample_distinct_hip": (_INT, [_P, _I64, _I64, _c.c_uint64, _c.c_uint64, _P]),
+    "sg_recon_mask_hip": (_INT, [_P, _P, _I64, _I64, _F32, _c.c_uint64, _c.c_uint64, _P]),
+    "sg_sort_i32_workspace_bytes": (_SZ, [_I64]),
+    "sg_sort_i32_hip": (_INT, [_P] * 4 + [_I64, _I64, _P, _SZ, _P]),
+    "sg_bounds_from_sorted_hip": (_INT, [_P, _P, _I64, _I64, _P]),
+    "sg_gather_i32_hip": (_INT, [_P, _P, _P, _I64, _P]),
+    "sg_inverse_index_hip": (_INT, [_P, _P, _I64, _I64, _P]),
     "sg_multilink_agg_resolve_order": (_INT, [_P, _INT]),
     "sg_multilink_agg_saved_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT]),
     "sg_multilink_agg_workspace_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT, _INT]),

@@ -715,3 +715,157 @@ SG_API int sg_level_index_hip(int32_t* level, const float* values, const float* 
                      multi_link, static_cast<long long>(n), static_cast<int>(num_links));
   return check_launch("sg_level_index_hip");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Per-iteration samplers on the device (second half).  Reference: DataIterator.rating_sampler draws
+// `rng.choice(n, batch, replace=False)` and recon_nodes_sampler permutes the node ids with numpy's Mersenne Twister on the
+// host (iterators.py:264-370).  A stateful sequential generator cannot be reproduced in parallel, so the device samplers
+// use a COUNTER-BASED construction instead (documented deviation: same distribution -- a uniform sample without
+// replacement -- not the same stream): a keyed bijection pi of [0, 2^b) (4-round Feistel network over the two halves of
+// the b-bit index, b = smallest even width with 2^b >= n; round function = a 32-bit integer finaliser keyed by
+// (seed, counter, round)), restricted to [0, n) by cycle walking.  pi(0), pi(1), ..., pi(k-1) are k DISTINCT uniform
+// elements of [0, n); every thread computes its own element from (seed, counter, i) alone.
+// ------------------------------------------------------------------------------------------------------------------
+namespace sg {
+namespace {
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {   // integer finaliser (avalanche), the Feistel round function
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint64_t feistel(uint64_t x, int half_bits, uint32_t k0, uint32_t k1) {
+  const uint32_t mask = (half_bits >= 32) ? 0xffffffffU : ((1U << half_bits) - 1U);
+  uint32_t l = static_cast<uint32_t>(x >> half_bits) & mask, r = static_cast<uint32_t>(x) & mask;
+#pragma unroll
+  for (int round = 0; round < 4; ++round) {
+    const uint32_t f = mix32(r ^ mix32(k0 + 0x9e3779b9U * (round + 1)) ^ (k1 * (2 * round + 1))) & mask;
+    const uint32_t nl = r;
+    r = l ^ f;
+    l = nl;
+  }
+  return (static_cast<uint64_t>(l) << half_bits) | r;
+}
+__global__ void sample_kernel(int32_t* __restrict__ out, long long n, long long k, int half_bits, uint32_t k0, uint32_t k1) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  uint64_t x = static_cast<uint64_t>(i);
+  do { x = feistel(x, half_bits, k0, k1); } while (x >= static_cast<uint64_t>(n));   // cycle walking: expected < 4 rounds
+  out[i] = static_cast<int32_t>(x);
+}
+__global__ void iota_kernel(int32_t* __restrict__ a, long long n) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = static_cast<int32_t>(i);
+}
+__global__ void fill_i32_kernel(int32_t* __restrict__ a, long long n, int32_t v) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+__global__ void inverse_index_kernel(int32_t* __restrict__ inv, const int32_t* __restrict__ ids, long long n_ids, long long n_rows) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= n_ids) return;
+  const long long r = ids[j];
+  if (r >= 0 && r < n_rows) inv[r] = static_cast<int32_t>(j);
+}
+// noise[node] of the nodes picked for reconstruction: -1 (zero-mask) with probability p_zero, the node itself otherwise
+__global__ void recon_noise_kernel(int32_t* __restrict__ noise, const int32_t* __restrict__ recon, long long k, long long n,
+                                   float p_zero, uint32_t k0, uint32_t k1) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  const long long node = recon[j];
+  if (node < 0 || node >= n) return;
+  const float u = (mix32(static_cast<uint32_t>(j) ^ mix32(k0 ^ 0x5bd1e995U) ^ (k1 * 0x27d4eb2fU)) >> 8) * (1.0f / 16777216.0f);
+  noise[node] = (u < p_zero) ? -1 : static_cast<int32_t>(node);
+}
+inline void sampler_keys(uint64_t seed, uint64_t counter, uint32_t* k0, uint32_t* k1) {
+  const uint64_t a = seed * 0x9e3779b97f4a7c15ULL + counter;
+  const uint64_t b = (a ^ (a >> 31)) * 0xbf58476d1ce4e5b9ULL + (counter << 1 | 1);
+  *k0 = static_cast<uint32_t>(a ^ (a >> 32));
+  *k1 = static_cast<uint32_t>(b ^ (b >> 29)) | 1U;
+}
+}  // namespace
+}  // namespace sg
+
+// out[i] = pi_{seed,counter}(i) for i < k: k distinct uniform elements of [0, n)  (k <= n < 2^31)
+SG_API int sg_sample_distinct_hip(int32_t* out, int64_t n, int64_t k, uint64_t seed, uint64_t counter, void* stream) {
+  if (n < 0 || k < 0 || k > n || n >= (1ll << 31)) return fail(SG_ERR_INVALID, "need 0 <= k <= n < 2^31 (k=%lld n=%lld)", (long long)k, (long long)n);
+  if (k == 0) return SG_OK;
+  if (!out) return fail(SG_ERR_INVALID, "null pointer argument");
+  int bits = 2;
+  while ((1ll << bits) < n) bits += 2;       // even width: two equal halves
+  uint32_t k0, k1;
+  sampler_keys(seed, counter, &k0, &k1);
+  hipLaunchKernelGGL(sample_kernel, dim3(blocks(k)), dim3(256), 0, static_cast<hipStream_t>(stream), out,
+                     static_cast<long long>(n), static_cast<long long>(k), bits / 2, k0, k1);
+  return check_launch("sg_sample_distinct_hip");
+}
+
+// stable ascending sort of non-negative int32 keys (<= max_key) with an int32 payload (vals == null: payload = position)
+SG_API size_t sg_sort_i32_workspace_bytes(int64_t n) {
+  if (n < 0) return 0;
+  return 2 * al256(static_cast<size_t>(n > 0 ? n : 1) * 4) + al256(sort_layout(n).total) + 256;
+}
+SG_API int sg_sort_i32_hip(int32_t* keys_out, int32_t* vals_out, const int32_t* keys, const int32_t* vals, int64_t n,
+                           int64_t max_key, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n < 0 || max_key < 0 || n >= (1ll << 31) - 1) return fail(SG_ERR_INVALID, "bad size");
+  if (n == 0) return SG_OK;
+  if (!keys || (!keys_out && !vals_out)) return fail(SG_ERR_INVALID, "null pointer argument");
+  if (!workspace || workspace_bytes < sg_sort_i32_workspace_bytes(n)) return fail(SG_ERR_WORKSPACE, "sort workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  const size_t nb = al256(static_cast<size_t>(n) * 4);
+  uint32_t* ka = reinterpret_cast<uint32_t*>(base);
+  int32_t* va = reinterpret_cast<int32_t*>(base + nb);
+  if (hipMemcpyAsync(ka, keys, static_cast<size_t>(n) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(SG_ERR_HIP, "memcpy");
+  if (vals && hipMemcpyAsync(va, vals, static_cast<size_t>(n) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(SG_ERR_HIP, "memcpy");
+  uint32_t* ks; int32_t* vs;
+  const int rc = radix_sort_pairs(ka, va, vals == nullptr, n, max_key, base + 2 * nb, &ks, &vs, st);
+  if (rc != SG_OK) return rc;
+  if (keys_out && hipMemcpyAsync(keys_out, ks, static_cast<size_t>(n) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(SG_ERR_HIP, "memcpy");
+  if (vals_out && hipMemcpyAsync(vals_out, vs, static_cast<size_t>(n) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(SG_ERR_HIP, "memcpy");
+  return SG_OK;
+}
+
+// out_indptr[k] = first position of the SORTED keys whose key is >= k, k in [0, total]  (CSR row pointer of sorted keys)
+SG_API int sg_bounds_from_sorted_hip(int32_t* out_indptr, const int32_t* sorted_keys, int64_t n, int64_t total, void* stream) {
+  if (n < 0 || total < 0 || !out_indptr) return fail(SG_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(bounds_from_sorted_kernel, dim3(blocks(n + 1)), dim3(256), 0, static_cast<hipStream_t>(stream), out_indptr,
+                     reinterpret_cast<const uint32_t*>(sorted_keys), static_cast<long long>(n), static_cast<long long>(total));
+  return check_launch("sg_bounds_from_sorted_hip");
+}
+
+// dst[p] = src[pos[p]]
+SG_API int sg_gather_i32_hip(int32_t* dst, const int32_t* src, const int32_t* pos, int64_t n, void* stream) {
+  if (n < 0) return fail(SG_ERR_INVALID, "negative size");
+  if (n == 0) return SG_OK;
+  hipLaunchKernelGGL(gather_i32_kernel, dim3(blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), dst, src, pos,
+                     static_cast<long long>(n));
+  return check_launch("sg_gather_i32_hip");
+}
+
+// inv[r] = j where ids[j] == r (ids distinct; -1 entries ignored), -1 for rows that are not listed
+SG_API int sg_inverse_index_hip(int32_t* inv, const int32_t* ids, int64_t n_ids, int64_t n_rows, void* stream) {
+  if (n_ids < 0 || n_rows < 0) return fail(SG_ERR_INVALID, "negative size");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_rows > 0) hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks(n_rows)), dim3(256), 0, st, inv, static_cast<long long>(n_rows), -1);
+  if (n_ids > 0) hipLaunchKernelGGL(inverse_index_kernel, dim3(blocks(n_ids)), dim3(256), 0, st, inv, ids, static_cast<long long>(n_ids),
+                                    static_cast<long long>(n_rows));
+  return check_launch("sg_inverse_index_hip");
+}
+
+// Masked-reconstruction sampler of one node type (reference iterators.py:309-370): recon[0..k) = k distinct uniform node
+// indices, noise[i] = i for every other node, noise[recon[j]] = -1 with probability p_zero else recon[j].
+SG_API int sg_recon_mask_hip(int32_t* noise, int32_t* recon, int64_t n, int64_t k, float p_zero, uint64_t seed, uint64_t counter,
+                             void* stream) {
+  if (n < 0 || k < 0 || k > n || n >= (1ll << 31)) return fail(SG_ERR_INVALID, "need 0 <= k <= n < 2^31");
+  if (n == 0) return SG_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(iota_kernel, dim3(blocks(n)), dim3(256), 0, st, noise, static_cast<long long>(n));
+  int rc = sg_sample_distinct_hip(recon, n, k, seed, counter, stream);
+  if (rc != SG_OK) return rc;
+  if (k > 0) {
+    uint32_t k0, k1;
+    sampler_keys(seed ^ 0xa5a5a5a5ULL, counter, &k0, &k1);
+    hipLaunchKernelGGL(recon_noise_kernel, dim3(blocks(k)), dim3(256), 0, st, noise, recon, static_cast<long long>(k),
+                       static_cast<long long>(n), p_zero, k0, k1);
+  }
+  return check_launch("sg_recon_mask_hip");
+}

@@ -1,0 +1,58 @@
+"""Per-iteration samplers of the training loop ON THE DEVICE (second half).
+
+Reference loop (experiments/STAR-GCN.py:583-600): `next(rating_sampler)` and `next(recon_sampler)` draw on the host with
+numpy's Mersenne Twister (mxgraph/iterators.py:264-370); the batch's pairs, noise arrays and reconstruction ids are then
+uploaded with the freshly built plan.  With the resident plan (resident.py) those draws were the last per-iteration host
+work.  Here they are native device kernels (csrc/plan_build.hip, section 12 of include/stargcn.h):
+
+  rating batch   B distinct edge ids of the training graph, sorted (sg_sample_distinct_hip + sg_sort_i32_hip); the pairs
+                 are the CSR coordinates of those edges, the pair plan of the rating head is built from them on the device
+  recon nodes    ceil(P_mask n) distinct nodes per node type and the embedding-noise array (sg_recon_mask_hip)
+
+The generators are counter-based (element i of a draw depends on (seed, iteration, i) only): the same distributions as
+the reference samplers, deliberately NOT the reference's random stream (a sequential Mersenne Twister cannot be run in
+parallel).  Nothing here touches the host after construction.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+
+
+class DeviceBatchSampler(object):
+    def __init__(self, resident, batch_size, embed_P_mask=0.1, embed_p_zero=0.0, seed=0):
+        self.res, self.batch_size, self.seed = resident, int(min(batch_size, resident.nnz)), int(seed)
+        self.P_mask, self.p_zero = float(embed_P_mask), float(embed_p_zero)
+        self.iteration = 0
+        dev = resident.device
+        self._values = torch.from_numpy(resident.csr.values.astype("float32")).to(dev)
+        self._n = {resident.U: resident.n_user, resident.I: resident.n_item}
+
+    def _i32(self, n):
+        return torch.empty(max(int(n), 1), dtype=torch.int32, device=self.res.device)
+
+    def next_batch(self):
+        """-> dict(edge_ids (B,) sorted, users, items, ratings (B,), noise {key: (n,)}, recon {key: (k,)}) -- all device
+        tensors, nothing synchronises."""
+        lib, st, res = L.lib(), L.stream_ptr(), self.res
+        it = self.iteration
+        self.iteration += 1
+        B = self.batch_size
+        raw, ids = self._i32(B), self._i32(B)
+        L.check(lib.sg_sample_distinct_hip(L.ptr(raw), res.nnz, B, self.seed, 3 * it, st), "sg_sample_distinct_hip")
+        ws, wsn = L.workspace(lib.sg_sort_i32_workspace_bytes(B), res.device)
+        L.check(lib.sg_sort_i32_hip(L.ptr(ids), None, L.ptr(raw), None, B, max(res.nnz - 1, 0), L.ptr(ws), wsn, st),
+                "sg_sort_i32_hip")
+        users, items = self._i32(B), self._i32(B)
+        L.check(lib.sg_gather_i32_hip(L.ptr(users), L.ptr(res._edge_row), L.ptr(ids), B, st), "sg_gather_i32_hip")
+        L.check(lib.sg_gather_i32_hip(L.ptr(items), L.ptr(res._edge_col), L.ptr(ids), B, st), "sg_gather_i32_hip")
+        ratings = self._values[ids[:B].long()]
+        noise, recon = dict(), dict()
+        for j, (key, n) in enumerate(self._n.items()):
+            k = int(math.ceil(self.P_mask * n))
+            nz, rc = self._i32(n), self._i32(k)
+            L.check(lib.sg_recon_mask_hip(L.ptr(nz), L.ptr(rc), n, k, self.p_zero, self.seed, 3 * it + 1 + j, st),
+                    "sg_recon_mask_hip")
+            noise[key], recon[key] = nz[:n], rc[:k]
+        return dict(edge_ids=ids[:B], users=users[:B], items=items[:B], ratings=ratings, noise=noise, recon=recon)

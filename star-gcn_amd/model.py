@@ -82,6 +82,29 @@ def _pair_plan_from_device_csr(cls, indptr, end_points, n_item):
 PairPlan.from_device_csr = classmethod(_pair_plan_from_device_csr)
 
 
+def _pair_plan_from_sorted_pairs(cls, user_idx, item_idx, n_user, n_item):
+    """PairPlan of a rating batch that is already ordered by (user, item) -- e.g. batch edge ids of the user->item CSR in
+    ascending order -- from DEVICE index tensors: the grouping by user is a row pointer over the sorted users
+    (sg_bounds_from_sorted_hip), the transpose comes from sg_build_transpose_hip.  Scores come back in this order."""
+    self = cls.__new__(cls)
+    user_idx, item_idx = L.i32c(user_idx), L.i32c(item_idx)
+    self.n_user, self.n_item, self.n_pairs = int(n_user), int(n_item), int(user_idx.shape[0])
+    self.identity, self.inv_order, self.order = True, None, None
+    self.indptr = torch.empty(self.n_user + 1, dtype=torch.int32, device=user_idx.device)
+    L.check(L.lib().sg_bounds_from_sorted_hip(L.ptr(self.indptr), L.ptr(user_idx), self.n_pairs, self.n_user, L.stream_ptr()),
+            "sg_bounds_from_sorted_hip")
+    self.items = item_idx if self.n_pairs else torch.zeros(1, dtype=torch.int32, device=user_idx.device)
+    t = TransposePlan(self.items, self.indptr, self.n_item, user_idx.device)
+    tp = _PairTranspose()
+    tp.t_indptr, tp.t_pos, tp.t_seg = t.t_indptr, t.t_pos, t.t_seg
+    tp.seg_num, tp.nnz, tp.total_ind_num, tp.covered = self.n_user, max(self.n_pairs, 1), self.n_item, self.n_pairs
+    self.tplan = tp
+    return self
+
+
+PairPlan.from_sorted_device_pairs = classmethod(_pair_plan_from_sorted_pairs)
+
+
 class _PairDot(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pu, pi, pp):

@@ -257,6 +257,22 @@ class TakePlan(object):
         self.ids = self.inv_ids = self.t_indptr = self.t_pos = None
         return self
 
+    @classmethod
+    def from_device_unique(cls, ids, n_rows):
+        """ids: int32 DEVICE tensor whose non-negative entries are distinct (-1 = zero row): the gradient is a row copy
+        through the inverse index, built on the device (sg_inverse_index_hip) -- no host round trip."""
+        self = cls.__new__(cls)
+        ids = L.i32c(ids).reshape(-1)
+        self.n, self.n_rows, self.covered = int(ids.shape[0]), int(n_rows), None
+        self.identity = False
+        self.ids = ids
+        self.inv_ids = torch.empty(max(self.n_rows, 1), dtype=torch.int32, device=ids.device)
+        L.check(L.lib().sg_inverse_index_hip(L.ptr(self.inv_ids), L.ptr(ids), self.n, self.n_rows, L.stream_ptr()),
+                "sg_inverse_index_hip")
+        self.inv_ids = self.inv_ids[:self.n_rows]
+        self.t_indptr = self.t_pos = None
+        return self
+
     def __init__(self, ids, n_rows, device):
         ids = _np_i32(ids).reshape(-1)
         n = ids.shape[0]

@@ -147,3 +147,28 @@ class ResidentPlan(object):
                                         embed_noise_dict is not None, dev)
         plan["gt"] = (net._embed_plan(recon_node_ids_dict, None, False, dev) if recon_node_ids_dict is not None else None)
         return plan
+
+    # ---- the same, from DEVICE tensors only (device_sampler.DeviceBatchSampler) --------------------------------------
+    def set_batch_device(self, batch, remove_batch_edges=True):
+        """`batch` as produced by DeviceBatchSampler.next_batch(): sorted batch edge ids, their (user, item) row indices,
+        noise arrays and reconstruction node indices -- all device tensors.  Masks the batch's edges, builds the pair plan
+        of the rating head and the take plans of the masked input / reconstruction rows ON THE DEVICE; no host round
+        trip, no synchronisation."""
+        net, plan = self.net, self.plan
+        if remove_batch_edges:
+            self.mask_edges(batch["edge_ids"])
+        elif self.masked:
+            self.mask_edges(np.zeros(0, np.int32))
+        n_out = {self.U: self.n_user, self.I: self.n_item}
+        pair = PairPlan.from_sorted_device_pairs(batch["users"], batch["items"], self.n_user, self.n_item)
+        recon_take = {k: TakePlan.from_device_unique(v, n_out[k]) for k, v in batch["recon"].items()}
+        for b in range(net._nblocks):
+            idx = plan["idx"][b]
+            for k in ("pair", "recon_take", "rating", "recon"):
+                idx.pop(k, None)
+            idx["pair"] = pair
+            idx["recon_take"] = recon_take
+        # masked input: row i of the input is embedding noise[i] (= i) or zero (-1): every row taken at most once
+        plan["input"] = {k: TakePlan.from_device_unique(v, n_out[k]) for k, v in batch["noise"].items()}
+        plan["gt"] = {k: TakePlan.from_device_unique(v, n_out[k]) for k, v in batch["recon"].items()}
+        return plan

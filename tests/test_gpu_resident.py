@@ -129,3 +129,78 @@ def test_training_step_on_resident_plan_matches_replanned_step(accum, order):
         p_host, _, _ = net(graph.remove_edges_by_id(U, I, pairs), rating_node_pairs=pairs, device="cuda")
         p_res, _, _ = net.run(res.set_batch(rating_node_pairs=pairs, edge_ids=graph[U, I].edge_positions(pairs)))
     close(p_res[1], p_host[1], "second batch")
+
+
+def test_device_sampler_draws_are_distinct_uniform_and_reproducible():
+    from star_gcn_amd import _lib as L
+    lib = L.lib()
+    n, k = 1_000_003, 200_000
+    out = torch.empty(k, dtype=torch.int32, device="cuda")
+    L.check(lib.sg_sample_distinct_hip(L.ptr(out), n, k, 7, 0, None), "sample")
+    a = out.cpu().numpy()
+    assert a.min() >= 0 and a.max() < n and np.unique(a).size == k              # distinct, in range
+    L.check(lib.sg_sample_distinct_hip(L.ptr(out), n, k, 7, 0, None), "sample")
+    assert np.array_equal(a, out.cpu().numpy())                                 # (seed, counter) -> same draw
+    L.check(lib.sg_sample_distinct_hip(L.ptr(out), n, k, 7, 1, None), "sample")
+    b = out.cpu().numpy()
+    assert np.intersect1d(a, b).size < 0.25 * k                                 # next counter: an independent draw (E = 0.2 k)
+    # uniformity: 50 equal bins of [0, n), chi-square with 49 dof (99.9 % quantile = 85.4)
+    hist = np.bincount(a // (n // 50 + 1), minlength=50)[:50].astype(np.float64)
+    exp = k * np.diff(np.minimum(np.arange(51) * (n // 50 + 1), n)) / n
+    assert ((hist - exp) ** 2 / exp).sum() < 86.0
+    # a full permutation: k = n
+    m = 12345
+    perm = torch.empty(m, dtype=torch.int32, device="cuda")
+    L.check(lib.sg_sample_distinct_hip(L.ptr(perm), m, m, 1, 5, None), "sample")
+    assert np.array_equal(np.sort(perm.cpu().numpy()), np.arange(m))
+    # recon mask: k distinct nodes; noise = identity except (with probability p_zero) -1 on the picked nodes
+    nz, rc = torch.empty(m, dtype=torch.int32, device="cuda"), torch.empty(1235, dtype=torch.int32, device="cuda")
+    L.check(lib.sg_recon_mask_hip(L.ptr(nz), L.ptr(rc), m, 1235, 0.3, 3, 9, None), "recon")
+    nzh, rch = nz.cpu().numpy(), rc.cpu().numpy()
+    assert np.unique(rch).size == 1235
+    rest = np.setdiff1d(np.arange(m), rch)
+    assert np.array_equal(nzh[rest], rest) and set(np.unique(nzh[rch] - rch * (nzh[rch] >= 0))) <= {0, -1}
+    frac = float((nzh[rch] == -1).mean())
+    assert 0.22 < frac < 0.38
+
+
+def test_device_batch_equals_host_batch():
+    """DeviceBatchSampler + ResidentPlan.set_batch_device (samplers, pair plan, take plans, edge masking all on the
+    device) give bit-identical network outputs to the host-planned batch (set_batch) of the SAME edges / noise / nodes."""
+    import star_gcn_amd.model as M
+    from star_gcn_amd.device_sampler import DeviceBatchSampler
+    from star_gcn_amd.resident import ResidentPlan
+    net, graph, eu, ei, vals = make()
+    res = ResidentPlan(net, graph)
+    smp = DeviceBatchSampler(res, 300, embed_P_mask=0.2, embed_p_zero=0.5, seed=11)
+    for _ in range(2):
+        batch = smp.next_batch()
+        ids = batch["edge_ids"].cpu().numpy()
+        assert np.all(np.diff(ids) > 0) and ids.size == 300
+        np.testing.assert_array_equal(batch["users"].cpu().numpy(), eu[ids])
+        np.testing.assert_array_equal(batch["items"].cpu().numpy(), ei[ids])
+        np.testing.assert_array_equal(batch["ratings"].cpu().numpy(), vals[ids])
+        y = batch["ratings"]
+        outs = []
+        for mode in ("device", "host"):
+            if mode == "device":
+                plan = res.set_batch_device(batch)
+            else:
+                plan = res.set_batch(rating_node_pairs=np.stack([eu[ids], ei[ids]]), edge_ids=ids,
+                                     embed_noise_dict={k: v.cpu().numpy() for k, v in batch["noise"].items()},
+                                     recon_node_ids_dict={k: v.cpu().numpy() for k, v in batch["recon"].items()})
+            net.zero_grad(set_to_none=True)
+            preds, recons, gt = net.run(plan)
+            loss = M.star_gcn_loss(preds, recons, gt, (y - y.mean()) / y.std(), recon_lambda=0.1)
+            loss.backward()
+            outs.append((preds, recons, gt, loss.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+        d, h = outs
+        for b in range(2):
+            assert torch.equal(d[0][b], h[0][b])
+            for key in (U, I):
+                assert torch.equal(d[1][b][key], h[1][b][key])
+        for key in (U, I):
+            assert torch.equal(d[2][key], h[2][key])
+        assert torch.equal(d[3], h[3])
+        for k in d[4]:
+            assert torch.equal(d[4][k], h[4][k]), k
