@@ -38,6 +38,58 @@ def evaluate(net, data_iter, graph, segment, mean, std, dev, lo, hi):
     return (se / max(n, 1)) ** 0.5
 
 
+def run_graph(args, net, it, resident, dsampler, mean, std, lo, hi, dev):
+    """The iteration has no host work left, so it is captured once and replayed: one hipGraphLaunch per training step.
+    The batch changes between replays because the sampler's draw counter lives in device memory."""
+    state = dict()
+
+    def iteration(advance):
+        dbatch = dsampler.next_batch(advance_on_device=advance)
+        preds, recons, gt = net.run(resident.set_batch_device(dbatch))
+        y = (dbatch["ratings"] - mean) / std
+        loss = M.star_gcn_loss(preds, recons, gt, y, recon_lambda=0.1)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0, foreach=True)
+        state["opt"].step()
+        state["opt"].zero_grad(set_to_none=True)
+        return loss.detach()
+
+    # eager warm-up on a side stream (lazy parameter shapes, workspaces, allocator pools), as graph capture requires
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dbatch = dsampler.next_batch(advance_on_device=True)
+        net.run(resident.set_batch_device(dbatch))                       # materialises the parameters
+        state["opt"] = torch.optim.Adam(net.parameters(), lr=args.lr, capturable=True)
+        for _ in range(3):
+            iteration(True)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        state["loss"] = iteration(True)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    t_train, n_timed = 0.0, 0
+    for step in range(1, args.iters + 1):
+        t_it = time.perf_counter()
+        graph.replay()
+        if step % args.eval_every == 0 or step == 1:
+            torch.cuda.synchronize()
+            net.eval()
+            rmse = evaluate(net, it, it.val_graph, "valid", mean, std, dev, lo, hi)
+            net.train()
+            print("iter %4d  loss %.4f  valid RMSE %.4f  (%.1f s)" % (step, float(state["loss"]), rmse, time.time() - t0))
+        else:
+            torch.cuda.synchronize()
+            t_train += time.perf_counter() - t_it
+            n_timed += 1
+    print("training iterations: %.2f ms/iter (one hipGraph replay per iteration: resident plan + device samplers, batch %d)" %
+          (1e3 * t_train / max(n_timed, 1), args.batch))
+    net.eval()
+    print("test RMSE %.4f" % evaluate(net, it, it.test_graph, "test", mean, std, dev, lo, hi))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="ml-100k")
@@ -50,6 +102,9 @@ def main():
     ap.add_argument("--device-sampler", action="store_true",
                     help="with --resident: draw the rating batch / reconstruction nodes and build the batch plans on the "
                          "device as well (star_gcn_amd/device_sampler.py): no per-iteration host work besides launches")
+    ap.add_argument("--graph", action="store_true",
+                    help="with --resident --device-sampler: capture the whole host-free iteration (sampling, edge masking, "
+                         "batch plans, forward, backward, clipping, Adam) in ONE hipGraph and replay it")
     ap.add_argument("--eval-every", type=int, default=20)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -81,6 +136,10 @@ def main():
             dsampler = DeviceBatchSampler(resident, args.batch, embed_P_mask=0.1, embed_p_zero=0.0, seed=args.seed)
     t0 = time.time()
     t_train = 0.0
+    if args.graph:
+        assert dsampler is not None, "--graph needs --resident --device-sampler"
+        run_graph(args, net, it, resident, dsampler, mean, std, lo, hi, dev)
+        return
     for step in range(1, args.iters + 1):
         torch.cuda.synchronize()
         t_it = time.perf_counter()

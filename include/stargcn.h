@@ -410,6 +410,13 @@ int sg_level_index_hip(int32_t* level, const float* values, const float* multi_l
 int sg_sample_distinct_hip(int32_t* out, int64_t n, int64_t k, uint64_t seed, uint64_t counter, void* stream);
 int sg_recon_mask_hip(int32_t* noise, int32_t* recon, int64_t n, int64_t k, float p_zero, uint64_t seed, uint64_t counter,
                       void* stream);
+/* the same draws with the counter taken as counter + *dev_counter (device pointer or NULL): a captured hipGraph freezes its
+ * kernel arguments, so a replayed training iteration advances its draw through device memory (sg_counter_add_hip) */
+int sg_sample_distinct_dev_hip(int32_t* out, int64_t n, int64_t k, uint64_t seed, uint64_t counter,
+                               const uint64_t* dev_counter, void* stream);
+int sg_recon_mask_dev_hip(int32_t* noise, int32_t* recon, int64_t n, int64_t k, float p_zero, uint64_t seed,
+                          uint64_t counter, const uint64_t* dev_counter, void* stream);
+int sg_counter_add_hip(uint64_t* counter, uint64_t v, void* stream);
 size_t sg_sort_i32_workspace_bytes(int64_t n);
 int sg_sort_i32_hip(int32_t* keys_out, int32_t* vals_out, const int32_t* keys, const int32_t* vals, int64_t n,
                     int64_t max_key, void* workspace, size_t workspace_bytes, void* stream);

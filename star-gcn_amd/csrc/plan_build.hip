@@ -744,9 +744,20 @@ __device__ __forceinline__ uint64_t feistel(uint64_t x, int half_bits, uint32_t 
   }
   return (static_cast<uint64_t>(l) << half_bits) | r;
 }
-__global__ void sample_kernel(int32_t* __restrict__ out, long long n, long long k, int half_bits, uint32_t k0, uint32_t k1) {
+// keys of a draw from (seed, counter [+ *dev_counter]): the optional device-resident counter lets a captured hipGraph draw
+// a fresh batch at every replay (kernel arguments are frozen at capture time, device memory is not)
+__host__ __device__ __forceinline__ void sampler_keys(uint64_t seed, uint64_t counter, uint32_t* k0, uint32_t* k1) {
+  const uint64_t a = seed * 0x9e3779b97f4a7c15ULL + counter;
+  const uint64_t b = (a ^ (a >> 31)) * 0xbf58476d1ce4e5b9ULL + (counter << 1 | 1);
+  *k0 = static_cast<uint32_t>(a ^ (a >> 32));
+  *k1 = static_cast<uint32_t>(b ^ (b >> 29)) | 1U;
+}
+__global__ void sample_kernel(int32_t* __restrict__ out, long long n, long long k, int half_bits, uint64_t seed,
+                              uint64_t counter, const uint64_t* __restrict__ dev_counter) {
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= k) return;
+  uint32_t k0, k1;
+  sampler_keys(seed, counter + (dev_counter ? *dev_counter : 0ull), &k0, &k1);
   uint64_t x = static_cast<uint64_t>(i);
   do { x = feistel(x, half_bits, k0, k1); } while (x >= static_cast<uint64_t>(n));   // cycle walking: expected < 4 rounds
   out[i] = static_cast<int32_t>(x);
@@ -767,35 +778,46 @@ __global__ void inverse_index_kernel(int32_t* __restrict__ inv, const int32_t* _
 }
 // noise[node] of the nodes picked for reconstruction: -1 (zero-mask) with probability p_zero, the node itself otherwise
 __global__ void recon_noise_kernel(int32_t* __restrict__ noise, const int32_t* __restrict__ recon, long long k, long long n,
-                                   float p_zero, uint32_t k0, uint32_t k1) {
+                                   float p_zero, uint64_t seed, uint64_t counter, const uint64_t* __restrict__ dev_counter) {
   const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (j >= k) return;
+  uint32_t k0, k1;
+  sampler_keys(seed, counter + (dev_counter ? *dev_counter : 0ull), &k0, &k1);
   const long long node = recon[j];
   if (node < 0 || node >= n) return;
   const float u = (mix32(static_cast<uint32_t>(j) ^ mix32(k0 ^ 0x5bd1e995U) ^ (k1 * 0x27d4eb2fU)) >> 8) * (1.0f / 16777216.0f);
   noise[node] = (u < p_zero) ? -1 : static_cast<int32_t>(node);
 }
-inline void sampler_keys(uint64_t seed, uint64_t counter, uint32_t* k0, uint32_t* k1) {
-  const uint64_t a = seed * 0x9e3779b97f4a7c15ULL + counter;
-  const uint64_t b = (a ^ (a >> 31)) * 0xbf58476d1ce4e5b9ULL + (counter << 1 | 1);
-  *k0 = static_cast<uint32_t>(a ^ (a >> 32));
-  *k1 = static_cast<uint32_t>(b ^ (b >> 29)) | 1U;
+__global__ void add_u64_kernel(uint64_t* __restrict__ c, uint64_t v) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *c += v;
 }
 }  // namespace
 }  // namespace sg
 
+SG_API int sg_sample_distinct_dev_hip(int32_t* out, int64_t n, int64_t k, uint64_t seed, uint64_t counter,
+                                      const uint64_t* dev_counter, void* stream);
 // out[i] = pi_{seed,counter}(i) for i < k: k distinct uniform elements of [0, n)  (k <= n < 2^31)
 SG_API int sg_sample_distinct_hip(int32_t* out, int64_t n, int64_t k, uint64_t seed, uint64_t counter, void* stream) {
+  return sg_sample_distinct_dev_hip(out, n, k, seed, counter, nullptr, stream);
+}
+// same with counter + *dev_counter (dev_counter: device pointer or null), for draws inside a captured graph
+SG_API int sg_sample_distinct_dev_hip(int32_t* out, int64_t n, int64_t k, uint64_t seed, uint64_t counter,
+                                      const uint64_t* dev_counter, void* stream) {
   if (n < 0 || k < 0 || k > n || n >= (1ll << 31)) return fail(SG_ERR_INVALID, "need 0 <= k <= n < 2^31 (k=%lld n=%lld)", (long long)k, (long long)n);
   if (k == 0) return SG_OK;
   if (!out) return fail(SG_ERR_INVALID, "null pointer argument");
   int bits = 2;
   while ((1ll << bits) < n) bits += 2;       // even width: two equal halves
-  uint32_t k0, k1;
-  sampler_keys(seed, counter, &k0, &k1);
   hipLaunchKernelGGL(sample_kernel, dim3(blocks(k)), dim3(256), 0, static_cast<hipStream_t>(stream), out,
-                     static_cast<long long>(n), static_cast<long long>(k), bits / 2, k0, k1);
+                     static_cast<long long>(n), static_cast<long long>(k), bits / 2, seed, counter, dev_counter);
   return check_launch("sg_sample_distinct_hip");
+}
+
+// *counter += v on the stream (advances the device-resident draw counter once per captured iteration)
+SG_API int sg_counter_add_hip(uint64_t* counter, uint64_t v, void* stream) {
+  if (!counter) return fail(SG_ERR_INVALID, "null pointer argument");
+  hipLaunchKernelGGL(add_u64_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter, v);
+  return check_launch("sg_counter_add_hip");
 }
 
 // stable ascending sort of non-negative int32 keys (<= max_key) with an int32 payload (vals == null: payload = position)
@@ -853,19 +875,22 @@ SG_API int sg_inverse_index_hip(int32_t* inv, const int32_t* ids, int64_t n_ids,
 
 // Masked-reconstruction sampler of one node type (reference iterators.py:309-370): recon[0..k) = k distinct uniform node
 // indices, noise[i] = i for every other node, noise[recon[j]] = -1 with probability p_zero else recon[j].
+SG_API int sg_recon_mask_dev_hip(int32_t* noise, int32_t* recon, int64_t n, int64_t k, float p_zero, uint64_t seed,
+                                 uint64_t counter, const uint64_t* dev_counter, void* stream);
 SG_API int sg_recon_mask_hip(int32_t* noise, int32_t* recon, int64_t n, int64_t k, float p_zero, uint64_t seed, uint64_t counter,
                              void* stream) {
+  return sg_recon_mask_dev_hip(noise, recon, n, k, p_zero, seed, counter, nullptr, stream);
+}
+SG_API int sg_recon_mask_dev_hip(int32_t* noise, int32_t* recon, int64_t n, int64_t k, float p_zero, uint64_t seed,
+                                 uint64_t counter, const uint64_t* dev_counter, void* stream) {
   if (n < 0 || k < 0 || k > n || n >= (1ll << 31)) return fail(SG_ERR_INVALID, "need 0 <= k <= n < 2^31");
   if (n == 0) return SG_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(iota_kernel, dim3(blocks(n)), dim3(256), 0, st, noise, static_cast<long long>(n));
-  int rc = sg_sample_distinct_hip(recon, n, k, seed, counter, stream);
+  int rc = sg_sample_distinct_dev_hip(recon, n, k, seed, counter, dev_counter, stream);
   if (rc != SG_OK) return rc;
-  if (k > 0) {
-    uint32_t k0, k1;
-    sampler_keys(seed ^ 0xa5a5a5a5ULL, counter, &k0, &k1);
+  if (k > 0)
     hipLaunchKernelGGL(recon_noise_kernel, dim3(blocks(k)), dim3(256), 0, st, noise, recon, static_cast<long long>(k),
-                       static_cast<long long>(n), p_zero, k0, k1);
-  }
+                       static_cast<long long>(n), p_zero, seed ^ 0xa5a5a5a5ULL, counter, dev_counter);
   return check_launch("sg_recon_mask_hip");
 }

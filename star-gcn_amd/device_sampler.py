@@ -26,21 +26,27 @@ class DeviceBatchSampler(object):
         self.P_mask, self.p_zero = float(embed_P_mask), float(embed_p_zero)
         self.iteration = 0
         dev = resident.device
+        # draw counter in device memory: lets a captured hipGraph of the whole iteration draw a new batch at every replay
+        self.dev_counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self._values = torch.from_numpy(resident.csr.values.astype("float32")).to(dev)
         self._n = {resident.U: resident.n_user, resident.I: resident.n_item}
 
     def _i32(self, n):
         return torch.empty(max(int(n), 1), dtype=torch.int32, device=self.res.device)
 
-    def next_batch(self):
+    def next_batch(self, advance_on_device=False):
         """-> dict(edge_ids (B,) sorted, users, items, ratings (B,), noise {key: (n,)}, recon {key: (k,)}) -- all device
-        tensors, nothing synchronises."""
+        tensors, nothing synchronises.  advance_on_device=True: the draw index lives in device memory and is advanced by a
+        kernel at the end of this call (for a captured hipGraph: every replay draws the next batch)."""
         lib, st, res = L.lib(), L.stream_ptr(), self.res
-        it = self.iteration
-        self.iteration += 1
+        if advance_on_device:
+            it, dc = 0, L.ptr(self.dev_counter)
+        else:
+            it, dc = self.iteration, None
+            self.iteration += 1
         B = self.batch_size
         raw, ids = self._i32(B), self._i32(B)
-        L.check(lib.sg_sample_distinct_hip(L.ptr(raw), res.nnz, B, self.seed, 3 * it, st), "sg_sample_distinct_hip")
+        L.check(lib.sg_sample_distinct_dev_hip(L.ptr(raw), res.nnz, B, self.seed, 3 * it, dc, st), "sg_sample_distinct_hip")
         ws, wsn = L.workspace(lib.sg_sort_i32_workspace_bytes(B), res.device)
         L.check(lib.sg_sort_i32_hip(L.ptr(ids), None, L.ptr(raw), None, B, max(res.nnz - 1, 0), L.ptr(ws), wsn, st),
                 "sg_sort_i32_hip")
@@ -52,7 +58,9 @@ class DeviceBatchSampler(object):
         for j, (key, n) in enumerate(self._n.items()):
             k = int(math.ceil(self.P_mask * n))
             nz, rc = self._i32(n), self._i32(k)
-            L.check(lib.sg_recon_mask_hip(L.ptr(nz), L.ptr(rc), n, k, self.p_zero, self.seed, 3 * it + 1 + j, st),
+            L.check(lib.sg_recon_mask_dev_hip(L.ptr(nz), L.ptr(rc), n, k, self.p_zero, self.seed, 3 * it + 1 + j, dc, st),
                     "sg_recon_mask_hip")
             noise[key], recon[key] = nz[:n], rc[:k]
+        if advance_on_device:
+            L.check(lib.sg_counter_add_hip(L.ptr(self.dev_counter), 3, st), "sg_counter_add_hip")
         return dict(edge_ids=ids[:B], users=users[:B], items=items[:B], ratings=ratings, noise=noise, recon=recon)
