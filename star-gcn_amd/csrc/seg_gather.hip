@@ -80,6 +80,24 @@ template <int V> __device__ __forceinline__ void ld_vec(float (&r)[V], const flo
 #pragma unroll
   for (int v = 0; v < V; ++v) r[v] = f[v];
 }
+// gathered source rows.  PMC (tools/pmc_gather.sh): the per-CU L1 waits for L2 returns 47-65 % of its busy cycles
+// (TCP_PENDING_STALL) at 0.18-0.25 line requests per clock, request latency 119 (L2-resident) .. 414 cycles (bench shape),
+// no TLB misses: the kernel is bound by the L1's outstanding-miss capacity over the L2 / Infinity-Cache latency.
+// SG_GATHER_NT=1 issues the row loads non-temporal to keep them out of the L1 -- measured 1.6-1.7 ms instead of
+// 0.86-0.92 ms per launch: the hint also keeps the rows out of L2, and the L2 hits are what the kernel lives on.  Off.
+#ifndef SG_GATHER_NT
+#define SG_GATHER_NT 0
+#endif
+template <int V> __device__ __forceinline__ void ld_row(float (&r)[V], const float* p) {
+#if SG_GATHER_NT
+  typedef float vec_t __attribute__((ext_vector_type(V)));
+  const vec_t t = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(p));
+#pragma unroll
+  for (int v = 0; v < V; ++v) r[v] = t[v];
+#else
+  ld_vec<V>(r, p);
+#endif
+}
 template <int V> __device__ __forceinline__ void st_vec(float* p, const float (&r)[V]) {
   typename VecT<V>::T t;
   float* f = reinterpret_cast<float*>(&t);
@@ -151,7 +169,7 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
         off = uniform_ll(off);
         wv[u] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wv[u])));
       }
-      if (chan_ok) ld_vec<VEC>(x[u], src + off + c);
+      if (chan_ok) ld_row<VEC>(x[u], src + off + c);
     }
     if (chan_ok) {
 #pragma unroll
@@ -169,7 +187,7 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
     }
     if (chan_ok) {
       float x[VEC];
-      ld_vec<VEC>(x, src + off + c);
+      ld_row<VEC>(x, src + off + c);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[v] = fmaf(wv, x[v], acc[v]);
     }
