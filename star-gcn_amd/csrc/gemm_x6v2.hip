@@ -208,13 +208,18 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
     // time).  With the consumer at a higher static priority an MFMA takes its slot as soon as the pipe frees up and the
     // VALU work fills the 32-cycle shadows in between.
     __builtin_amdgcn_s_setprio(3);
-    f32x16 acc[2][2];
+    // Two accumulator sets: `acc` takes the leading product a1 b1 of every K step, `accs` the five correction terms
+    // (2^-8 .. 2^-16 of it).  Adding the corrections straight into the large running sum would round each of them at the
+    // ulp of the LARGE value -- six roundings per K step instead of one, which showed as 3x the exact-fp32 kernel's error
+    // on a cancelling bias gradient; in their own accumulator their roundings are 2^-8 smaller and the leading sum is
+    // rounded once per step, like a plain fp32-accumulating MFMA.  The two are added once, in the epilogue.
+    f32x16 acc[2][2], accs[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accs[i][j][e] = 0.f; }
     Cursor c;
     cursor_set(c, g, blockIdx.x, n_items, ktiles);
     while (c.valid && c.kt >= c.kt_end) cursor_set(c, g, c.item + stride, n_items, ktiles);
@@ -243,18 +248,23 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
         // depend on each other
 #if SG_X6V2_ABLATE != 2
 #pragma unroll
-        for (int term = 0; term < 6; ++term) {
+        for (int term = 0; term < 5; ++term) {     // corrections, smallest first
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kPA[term]], b[j][kPB[term]], acc[i][j], 0, 0, 0);
+              accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kPA[term]], b[j][kPB[term]], accs[i][j], 0, 0, 0);
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
 #else
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) acc[i][0][p] += static_cast<float>(a[i][p][0]) + static_cast<float>(b[i][p][0]);
+          for (int p = 0; p < 3; ++p) accs[i][0][p] += static_cast<float>(a[i][p][0]) + static_cast<float>(b[i][p][0]);
 #endif
       }
       if (c.kt + 1 >= c.kt_end) {
@@ -281,8 +291,9 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-              cst[((e & 3) + 8 * (e >> 2) + 4 * kh) * CPITCH + j * 32 + l31] = acc[i][j][e];
+              cst[((e & 3) + 8 * (e >> 2) + 4 * kh) * CPITCH + j * 32 + l31] = acc[i][j][e] + accs[i][j][e];
               acc[i][j][e] = 0.f;
+              accs[i][j][e] = 0.f;
             }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
