@@ -41,6 +41,9 @@ struct GemmArgs {   // must match gemm_f32.hip
   int vecA, vecB;
 };
 
+#ifndef SG_X6V2_NT_STORE
+#define SG_X6V2_NT_STORE 1    // C tiles are written once and never re-read by this kernel: stream them past the caches
+#endif
 #ifndef SG_X6V2_ABLATE
 #define SG_X6V2_ABLATE 0      // development: 1 producers skip split + LDS stores, 2 consumers skip MFMAs, 3 consumers skip LDS reads
 #endif
@@ -321,7 +324,12 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
                 for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q] + bv[q], g.act, g.slope);
               }
               if (full) {
-                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const f4 t = {v[0], v[1], v[2], v[3]};
+                // a finished C tile is not re-read by this kernel: streamed past the caches (K = 256, 262 144 x 4 096:
+                // 106 -> 122 TFLOP/s); split-K partials ARE re-read at once by the reduce kernel and stay cacheable
+                if (SG_X6V2_NT_STORE && !partial) __builtin_nontemporal_store(t, reinterpret_cast<f4*>(o));
+                else *reinterpret_cast<f4*>(o) = t;
               } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) if (col + q < g.N) o[q] = v[q];
