@@ -3,9 +3,11 @@
 experiments/STAR-GCN.py:583-632 reduced to what exercises the path: rating + masked-reconstruction mini-batches,
 per-batch removal of the batch's rating edges from the aggregation graph (both directions, reference
 graph.py:952-974), 2-block network with decoder, the two losses, Adam + global-norm clipping, RMSE on held-out
-ratings.  Data: a MovieLens-shaped synthetic graph (no dataset files in this environment).
+ratings.  Data: a MovieLens-shaped synthetic graph (no dataset files in this environment), or an extracted MovieLens
+directory through star_gcn_amd.datasets.LoadData (reference mxgraph/datasets.py) with the reference's splits.
 
   python examples/train_star_gcn.py --shape ml-100k --iters 200 [--resident]
+  python examples/train_star_gcn.py --data-root /data --dataset ml-1m --iters 2000 --resident --device-sampler
 
 --resident keeps the plan of the whole training graph in HBM and removes each batch's edges ON THE DEVICE
 (star_gcn_amd/resident.py, sg_mask_edges_hip) instead of rebuilding CSRs + plan on the host every iteration.
@@ -93,6 +95,8 @@ def run_graph(args, net, it, resident, dsampler, mean, std, lo, hi, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="ml-100k")
+    ap.add_argument("--data-root", default=None, help="directory holding the extracted ml-100k / ml-1m / ml-10M100K folder")
+    ap.add_argument("--dataset", default="ml-100k", choices=["ml-100k", "ml-1m", "ml-10m"])
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--batch", type=int, default=10000)
     ap.add_argument("--embed", type=int, default=32)
@@ -110,12 +114,18 @@ def main():
     dev = torch.device("cuda", 0)
     torch.manual_seed(args.seed)
     rng = np.random.default_rng(args.seed)
-    graph, eu, ei, vals = S.make_graph(args.shape, signal=True)
-    n = eu.size
-    perm = rng.permutation(n)
-    n_test, n_valid = int(0.2 * n), int(0.08 * n)
-    test_pairs = np.stack([eu[perm[:n_test]], ei[perm[:n_test]]])
-    valid_pairs = np.stack([eu[perm[n_test:n_test + n_valid]], ei[perm[n_test:n_test + n_valid]]])
+    if args.data_root is not None:
+        from star_gcn_amd.datasets import LoadData
+        data = LoadData(args.dataset, args.data_root, seed=args.seed)
+        print(data)
+        graph, test_pairs, valid_pairs = data.graph, data.test_data[0], data.valid_data[0]
+    else:
+        graph, eu, ei, vals = S.make_graph(args.shape, signal=True)
+        n = eu.size
+        perm = rng.permutation(n)
+        n_test, n_valid = int(0.2 * n), int(0.08 * n)
+        test_pairs = np.stack([eu[perm[:n_test]], ei[perm[:n_test]]])
+        valid_pairs = np.stack([eu[perm[n_test:n_test + n_valid]], ei[perm[n_test:n_test + n_valid]]])
     it = DataIterator(graph, U, I, test_pairs, valid_pairs, embed_P_mask=0.1, embed_p_zero=0.0, embed_p_self=1.0,
                       seed=args.seed)
     train_vals = it.train_graph[U, I].values

@@ -374,26 +374,55 @@ class HeterGraph(object):
             np.testing.assert_array_equal(ids, np.arange(ids.size, dtype=np.int32))
 
     def save(self, dir_name):
-        """npz/json layout of reference graph.py:898-915 (meta_graph.json + one CSR npz per direction)."""
+        """The reference's directory layout (graph.py:898-915, CSR keys :465-481), so either side reads the other's files:
+        `meta_graph.json` = {key: {neighbour key: 1}}; `<key>.npz` = node_ids + features (float32; a zero-width matrix
+        when the graph carries none); ONE `<k1>_<k2>_csr.npz` per node-type pair with row_ids, col_ids, values,
+        end_points, ind_ptr and -- only when the matrix is multi-link -- multi_link."""
         os.makedirs(dir_name, exist_ok=True)
         with open(os.path.join(dir_name, 'meta_graph.json'), 'w') as f:
-            json.dump({k: sorted(v) for k, v in self.meta_graph.items()}, f)
+            json.dump({k: {n: 1 for n in v} for k, v in self.meta_graph.items()}, f)
         for key, ids in self.node_ids_dict.items():
-            np.savez_compressed(os.path.join(dir_name, '{}.npz'.format(key)), node_ids=ids)
+            fea = self.features.get(key)
+            fea = np.zeros((ids.size, 0), np.float32) if fea is None else np.asarray(fea, np.float32)
+            np.savez_compressed(os.path.join(dir_name, '{}.npz'.format(key)), node_ids=ids, features=fea)
+        written = set()
         for (a, b), m in self.csr_mat_dict.items():
-            np.savez_compressed(os.path.join(dir_name, '{}_{}_csr.npz'.format(a, b)), end_points=m.end_points,
-                                ind_ptr=m.ind_ptr, values=m.values, row_ids=m.row_ids, col_ids=m.col_ids,
-                                multi_link=m.multi_link if m.multi_link is not None else np.zeros(0, np.float32))
+            if (a, b) in written:
+                continue
+            written.update([(a, b), (b, a)])
+            arrays = dict(row_ids=m.row_ids, col_ids=m.col_ids, values=m.values, end_points=m.end_points,
+                          ind_ptr=m.ind_ptr)
+            if m.multi_link is not None:
+                arrays['multi_link'] = m.multi_link
+            np.savez_compressed(os.path.join(dir_name, '{}_{}_csr.npz'.format(a, b)), **arrays)
 
     @classmethod
-    def load(cls, dir_name):
+    def load(cls, dir_name, fea_normalize=False):
+        """reference graph.py:1066-1100.  `fea_normalize` standardises every feature column (zero mean, unit variance;
+        constant columns are only centred -- what sklearn's StandardScaler, which the reference calls, does)."""
         with open(os.path.join(dir_name, 'meta_graph.json')) as f:
             meta = json.load(f)
-        node_ids = {k: np.load(os.path.join(dir_name, '{}.npz'.format(k)))['node_ids'] for k in meta}
-        mats = dict()
+        node_ids, features, mats = dict(), dict(), dict()
         for a in meta:
+            dat = np.load(os.path.join(dir_name, '{}.npz'.format(a)))
+            node_ids[a] = dat['node_ids']
+            fea = dat['features'] if 'features' in dat else None
+            if fea is not None and fea.ndim == 2 and fea.shape[1] > 0:
+                if fea_normalize:
+                    fea = fea.astype(np.float64)
+                    std = fea.std(axis=0)
+                    fea = (fea - fea.mean(axis=0)) / np.where(std == 0, 1.0, std)
+                features[a] = fea
             for b in meta[a]:
-                d = np.load(os.path.join(dir_name, '{}_{}_csr.npz'.format(a, b)))
-                ml = d['multi_link'] if d['multi_link'].size else None
-                mats[(a, b)] = CSRMat(d['end_points'], d['ind_ptr'], d['row_ids'], d['col_ids'], d['values'], ml)
-        return cls(node_ids, mats)
+                if (a, b) in mats or (b, a) in mats:
+                    continue
+                found = [(x, y) for x, y in ((a, b), (b, a))
+                         if os.path.exists(os.path.join(dir_name, '{}_{}_csr.npz'.format(x, y)))]
+                if a == b:
+                    found = found[:1]
+                if len(found) != 1:
+                    raise IOError("expected exactly one of {0}_{1}_csr.npz / {1}_{0}_csr.npz in {2}".format(a, b, dir_name))
+                d = np.load(os.path.join(dir_name, '{}_{}_csr.npz'.format(*found[0])))
+                ml = d['multi_link'] if 'multi_link' in d and d['multi_link'].size else None
+                mats[found[0]] = CSRMat(d['end_points'], d['ind_ptr'], d['row_ids'], d['col_ids'], d['values'], ml)
+        return cls(node_ids, mats, features)

@@ -49,45 +49,3 @@ def test_recon_sampler_noise_convention():
     noise0, _, rec0 = next(it0.recon_nodes_sampler(1000))
     assert all(np.array_equal(noise0[k][rec0[k]], rec0[k]) for k in rec0)       # shipped transductive setting
     assert all(np.array_equal(v, np.arange(v.size)) for v in it0.evaluate_embed_noise_dict.values())
-
-
-def test_movielens_file_loader(tmp_path):
-    """star_gcn_amd.datasets.LoadData on files written in the two MovieLens layouts (tab-separated u1.base/u1.test,
-    '::'-separated ratings.dat): id maps, CSR, rating levels, splits feed the DataIterator."""
-    from star_gcn_amd.datasets import LoadData
-    from star_gcn_amd.mxgraph.iterators import DataIterator
-    rng = np.random.default_rng(0)
-    users = rng.choice(np.arange(1, 400), 40, replace=False)           # raw ids with gaps
-    movies = rng.choice(np.arange(1, 900), 30, replace=False)
-    cells = rng.choice(users.size * movies.size, 500, replace=False)
-    u, m = users[cells // movies.size], movies[cells % movies.size]
-    r = rng.choice([1, 2, 3, 4, 5], 500)
-    d = tmp_path / "ml-100k"
-    d.mkdir()
-    with open(d / "u1.base", "w") as f:
-        f.writelines("%d\t%d\t%d\t88%d\n" % (a, b, c, k) for k, (a, b, c) in enumerate(zip(u[:400], m[:400], r[:400])))
-    with open(d / "u1.test", "w") as f:
-        f.writelines("%d\t%d\t%d\t99\n" % (a, b, c) for a, b, c in zip(u[400:], m[400:], r[400:]))
-    data = LoadData("ml-100k", str(tmp_path), val_ratio=0.1, seed=1)
-    g = data.graph
-    csr = g["user", "movie"]
-    assert csr.nnz == 500 and data.num_user == np.unique(u).size and data.num_item == np.unique(m).size
-    assert np.array_equal(data.num_links, np.arange(1, 6, dtype=np.float32))
-    tp, tv = data.test_data
-    assert tp.shape == (2, 100) and np.array_equal(tv, r[400:].astype(np.float32))
-    assert np.array_equal(data.raw_user_ids[tp[0]], u[400:]) and np.array_equal(data.raw_movie_ids[tp[1]], m[400:])
-    assert np.array_equal(g.fetch_edges_by_id("user", "movie", tp), tv)
-    vp, vv = data.valid_data
-    assert vp.shape == (2, 40) and np.array_equal(g.fetch_edges_by_id("user", "movie", vp), vv)
-    it = DataIterator(g, "user", "movie", tp, vp, seed=0)
-    assert it.train_graph["user", "movie"].nnz == 500 - 100 - 40
-    # ml-1m layout: one '::' file, random split
-    d2 = tmp_path / "ml-1m"
-    d2.mkdir()
-    with open(d2 / "ratings.dat", "w") as f:
-        f.writelines("%d::%d::%.1f::7\n" % (a, b, c / 2.0) for a, b, c in zip(u, m, r))
-    data2 = LoadData("ml-1m", str(tmp_path), test_ratio=0.2, val_ratio=0.1, seed=3)
-    assert data2.test_data[0].shape == (2, 100) and data2.valid_data[0].shape == (2, 40)
-    assert np.array_equal(data2.num_links, np.array([0.5, 1, 1.5, 2, 2.5], np.float32))
-    both = np.concatenate([data2.test_data[0], data2.valid_data[0]], axis=1)
-    assert np.unique(both[0].astype(np.int64) * 10 ** 6 + both[1]).size == 140     # test and validation are disjoint
