@@ -173,6 +173,10 @@ int sg_act_bwd_hip(float* dpre, const float* dout, const float* out, int64_t n, 
 size_t sg_colsum_workspace_bytes(int64_t M, int64_t N);
 int sg_colsum_hip(float* dst, const float* X, int64_t ldx, int64_t M, int64_t N, int req, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* Both at once for a Dense layer's backward (dpre = dout * act'(out) AND dbias = column sums of dpre, one pass over
+ * dout / out; all three matrices dense M x N).  Same partial-sum order as sg_colsum_hip(dpre): identical results. */
+int sg_act_bwd_colsum_hip(float* dpre, float* dbias, const float* dout, const float* out, int64_t M, int64_t N, int act,
+                          float slope, int req, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (6) masked embedding gather (reference STAR-GCN.py:264-300 Net.get_embed) and row take / its grad

@@ -63,6 +63,7 @@ _SIGS = {
     "sg_act_bwd_hip": (_INT, [_P, _P, _P, _I64, _INT, _F32, _P]),
     "sg_colsum_workspace_bytes": (_SZ, [_I64, _I64]),
     "sg_colsum_hip": (_INT, [_P, _P, _I64, _I64, _I64, _INT, _P, _SZ, _P]),
+    "sg_act_bwd_colsum_hip": (_INT, [_P, _P, _P, _P, _I64, _I64, _INT, _F32, _INT, _P, _SZ, _P]),
     "sg_masked_embed_hip": (_INT, [_P] * 4 + [_I64] * 3 + [_P]),
     "sg_resolve_ids_hip": (_INT, [_P] * 3 + [_I64, _P]),
     "sg_get_support_cpu": (_INT, [_P] * 5 + [_I64, _INT]),

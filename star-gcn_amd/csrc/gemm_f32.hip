@@ -337,8 +337,20 @@ __global__ void splitk_reduce_kernel(const GemmArgs g) {
   const long long total = static_cast<long long>(g.M) * g.N;
   if (i >= total) return;
   const int row = static_cast<int>(i / g.N), col = static_cast<int>(i - static_cast<long long>(row) * g.N);
+  // The slices are summed in increasing z (the order is part of the result), but read 16 at a time: with 100-300
+  // slices of a small C (weight gradients over 70 k rows) one dependent load per slice made this kernel a 45-65 us
+  // latency chain on a near-empty chip.
   float v = 0.f;
-  for (int z = 0; z < g.splits; ++z) v += g.ws[static_cast<long long>(z) * total + i];
+  const float* p = g.ws + i;
+  int z = 0;
+  for (; z + 16 <= g.splits; z += 16) {
+    float t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = p[static_cast<long long>(z + u) * total];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v += t[u];
+  }
+  for (; z < g.splits; ++z) v += p[static_cast<long long>(z) * total];
   if (g.bias) v += g.bias[col];
   float* o = g.C + static_cast<long long>(row) * g.ldc + col;
   if (g.accumulate) v += *o;
@@ -377,22 +389,20 @@ static void plan_split(int64_t M, int64_t N, int64_t K, int* splits, int* tiles_
 }
 
 // ---- elementwise helpers used by the dense backward -------------------------------------------------
+__device__ __forceinline__ float act_slope_from_output(float y, int act, float slope) {
+  switch (act) {
+    case SG_ACT_LEAKY: return y > 0.f ? 1.f : slope;   // leaky preserves sign for slope > 0
+    case SG_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case SG_ACT_SIGMOID: return y * (1.f - y);
+    case SG_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
 __global__ void act_bwd_kernel(float* __restrict__ dpre, const float* __restrict__ dout, const float* __restrict__ out,
                                long long n, int act, float slope) {
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
-  for (long long p = i; p < n; p += stride) {
-    const float y = out[p];
-    float d;
-    switch (act) {
-      case SG_ACT_LEAKY: d = y > 0.f ? 1.f : slope; break;   // leaky preserves sign for slope > 0
-      case SG_ACT_RELU: d = y > 0.f ? 1.f : 0.f; break;
-      case SG_ACT_SIGMOID: d = y * (1.f - y); break;
-      case SG_ACT_TANH: d = 1.f - y * y; break;
-      default: d = 1.f; break;
-    }
-    dpre[p] = dout[p] * d;
-  }
+  for (long long p = i; p < n; p += stride) dpre[p] = dout[p] * act_slope_from_output(out[p], act, slope);
 }
 
 // rows per workgroup in pass 1 of colsum: 64 keeps >= 160 workgroups in flight for the 10 k-row matrices of the step,
@@ -401,9 +411,14 @@ static inline int colsum_rows(long long M) { return M > 32768 ? 256 : 64; }
 // pass 1: partial[chunk][col] = sum over the chunk's rows.  256 threads = 4 waves; a wave reads whole row
 // segments of 64*VEC consecutive floats (1 KiB with float4) so each load instruction is one coalesced burst;
 // the 4 waves take rows r, r+4, ... and are combined through LDS.
-template <int VEC>
+// FUSED: X = dout, and the kernel first forms dpre = dout * act'(out) (written to `dpre`, dense M x N like `out`), then
+// sums THAT: the Dense layer's bias gradient without a second pass over dpre.
+template <int VEC, bool FUSED>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(float* __restrict__ partial, const float* __restrict__ X,
-                                                             long long ldx, long long M, int N, int kColRows) {
+                                                             long long ldx, long long M, int N, int kColRows,
+                                                             float* __restrict__ dpre, const float* __restrict__ out,
+                                                             int act, float slope) {
+#pragma clang fp contract(off)   // the product dout * act' is rounded (it IS dpre) before it enters the column sum
   __shared__ float red[4][64 * VEC];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.y * 64 * VEC + lane * VEC;
@@ -415,10 +430,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(float* __restrict__
   if (col < N) {
     for (long long r = r0 + w; r < r1; r += 4) {
       if (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(X + r * ldx + col);
+        float4 t = *reinterpret_cast<const float4*>(X + r * ldx + col);
+        if (FUSED) {
+          const float4 y = *reinterpret_cast<const float4*>(out + r * N + col);
+          t.x *= act_slope_from_output(y.x, act, slope); t.y *= act_slope_from_output(y.y, act, slope);
+          t.z *= act_slope_from_output(y.z, act, slope); t.w *= act_slope_from_output(y.w, act, slope);
+          *reinterpret_cast<float4*>(dpre + r * N + col) = t;
+        }
         acc[0] += t.x; acc[1 % VEC] += t.y; acc[2 % VEC] += t.z; acc[3 % VEC] += t.w;
       } else {
-        acc[0] += X[r * ldx + col];
+        float t = X[r * ldx + col];
+        if (FUSED) {
+          t *= act_slope_from_output(out[r * N + col], act, slope);
+          dpre[r * N + col] = t;
+        }
+        acc[0] += t;
       }
     }
   }
@@ -555,29 +581,48 @@ SG_API size_t sg_colsum_workspace_bytes(int64_t M, int64_t N) {
   return static_cast<size_t>((M + kColRows - 1) / kColRows) * N * sizeof(float);
 }
 
-SG_API int sg_colsum_hip(float* dst, const float* X, int64_t ldx, int64_t M, int64_t N, int req, void* workspace,
-                         size_t workspace_bytes, void* stream) {
-  if (!valid_req(req)) return fail(SG_ERR_INVALID, "bad req %d", req);
-  if (req == SG_REQ_NULL || N <= 0) return SG_OK;
-  if (M < 0 || ldx < N || N >= (1ll << 31)) return fail(SG_ERR_INVALID, "bad colsum shape");
-  hipStream_t st = static_cast<hipStream_t>(stream);
+static int colsum_launch(float* dst, const float* X, int64_t ldx, int64_t M, int64_t N, int req, void* workspace,
+                         size_t workspace_bytes, hipStream_t st, float* dpre, const float* out, int act, float slope) {
+  const bool fused = dpre != nullptr;
   const int kColRows = colsum_rows(M);
   const int64_t chunks = (M + kColRows - 1) / kColRows;
   if (chunks >= (1ll << 31) || (N + 63) / 64 > 65535) return fail(SG_ERR_INVALID, "colsum: shape too large");
   if (chunks > 0) {
     if (!workspace || workspace_bytes < sg_colsum_workspace_bytes(M, N))
       return fail(SG_ERR_WORKSPACE, "colsum workspace too small");
-    if (N % 4 == 0 && ldx % 4 == 0 && aligned(X, 16))
-      hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>((N + 255) / 256)),
-                         dim3(256), 0, st, static_cast<float*>(workspace), X, static_cast<long long>(ldx),
-                         static_cast<long long>(M), static_cast<int>(N), kColRows);
-    else
-      hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(static_cast<unsigned>(chunks), static_cast<unsigned>((N + 63) / 64)),
-                         dim3(256), 0, st, static_cast<float*>(workspace), X, static_cast<long long>(ldx),
-                         static_cast<long long>(M), static_cast<int>(N), kColRows);
+    const bool v4 = N % 4 == 0 && ldx % 4 == 0 && aligned(X, 16) && (!fused || (aligned(dpre, 16) && aligned(out, 16)));
+    const dim3 grid(static_cast<unsigned>(chunks), static_cast<unsigned>(v4 ? (N + 255) / 256 : (N + 63) / 64));
+#define SG_COLSUM(V, F)                                                                                         \
+  hipLaunchKernelGGL((colsum_partial_kernel<V, F>), grid, dim3(256), 0, st, static_cast<float*>(workspace), X,   \
+                     static_cast<long long>(ldx), static_cast<long long>(M), static_cast<int>(N), kColRows, dpre, \
+                     out, act, slope)
+    if (v4) { if (fused) SG_COLSUM(4, true); else SG_COLSUM(4, false); }
+    else { if (fused) SG_COLSUM(1, true); else SG_COLSUM(1, false); }
+#undef SG_COLSUM
   }
   hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>((N + 63) / 64)), dim3(1024), 0, st, dst,
                      static_cast<const float*>(workspace), static_cast<int>(chunks), static_cast<int>(N),
                      req == SG_REQ_ADD);
   return check_launch("colsum");
+}
+
+SG_API int sg_colsum_hip(float* dst, const float* X, int64_t ldx, int64_t M, int64_t N, int req, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (!valid_req(req)) return fail(SG_ERR_INVALID, "bad req %d", req);
+  if (req == SG_REQ_NULL || N <= 0) return SG_OK;
+  if (M < 0 || ldx < N || N >= (1ll << 31)) return fail(SG_ERR_INVALID, "bad colsum shape");
+  return colsum_launch(dst, X, ldx, M, N, req, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr,
+                       nullptr, SG_ACT_NONE, 0.f);
+}
+
+SG_API int sg_act_bwd_colsum_hip(float* dpre, float* dbias, const float* dout, const float* out, int64_t M, int64_t N,
+                                 int act, float slope, int req, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!valid_req(req)) return fail(SG_ERR_INVALID, "bad req %d", req);
+  if (act < SG_ACT_NONE || act > SG_ACT_TANH) return fail(SG_ERR_INVALID, "bad activation %d", act);
+  if (M < 0 || N < 0 || N >= (1ll << 31)) return fail(SG_ERR_INVALID, "bad shape");
+  if (N == 0) return SG_OK;
+  if (!dpre || !dbias || (M > 0 && (!dout || !out))) return fail(SG_ERR_INVALID, "null pointer argument");
+  if (req == SG_REQ_NULL) return sg_act_bwd_hip(dpre, dout, out, M * N, act, slope, stream);
+  return colsum_launch(dbias, dout, N, M, N, req, workspace, workspace_bytes, static_cast<hipStream_t>(stream), dpre, out,
+                       act, slope);
 }

@@ -31,63 +31,131 @@ constexpr int kBlock = 256;             // 4 waves per workgroup
 constexpr int kWavesPerBlock = kBlock / kWave;
 
 // ---------------------------------------------------------------------------------------------------
-// seg_take_k_corr: edge-balanced like the gather kernel -- one wave per chunk of 256 consecutive edges,
-// walking the segments the chunk overlaps.  Each edge's dot product is taken by LPR lanes holding VEC
-// consecutive channels each (float4 -> a 64-wide row is 16 lanes, 4 edges per wave step); partial dots
-// are combined inside the lane group with __shfl_xor.
+// seg_take_k_corr: edge-balanced like the gather kernel -- one wave per chunk of 256 consecutive edges.
+//   1. the chunk's neighbour ids and the segment of every edge are staged in LDS once: segment starts inside the
+//      chunk are marked (ds_max, so runs of empty segments resolve to the one that owns the edge) and a prefix-max
+//      over the 256 slots turns the marks into a per-edge segment id;
+//   2. each edge's dot product is taken by LPR lanes holding VEC consecutive channels each (float4 -> a 64-wide row
+//      is 16 lanes, 4 edges per wave step), partial dots combined inside the lane group with __shfl_xor.  The edge
+//      loop carries no dependence on the segment walk any more, so it is unrolled 4x: 8 independent row loads in
+//      flight per lane instead of the id -> row -> reduce chain of round 1 (10 M pairs x 64: 336 -> see profiles/);
+//   3. the 256 results leave through LDS as coalesced stores; edges past indptr[node_num] are zero-filled here
+//      (kWriteTo) instead of by a separate launch.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kCorrChunk = 256;
 
-template <int VEC>
+template <int VEC, int LPR>   // LPR > 0: lanes per edge, a row fits one pass of the lane group; 0: general (run-time lpr)
 __global__ __launch_bounds__(kWave) void take_k_corr_kernel(float* __restrict__ dst, const float* __restrict__ e1,
                                                             const float* __restrict__ e2,
                                                             const int32_t* __restrict__ ids,
                                                             const int32_t* __restrict__ indptr, int node_num,
-                                                            long long nbr_num, long long nnz, int C, int lpr, int add) {
+                                                            long long nbr_num, long long nnz, int C, int lpr_rt, int add) {
+  constexpr bool ONE = LPR > 0;
+  const int lpr = ONE ? LPR : lpr_rt;
+  __shared__ int32_t s_id[kCorrChunk];
+  __shared__ int32_t s_seg[kCorrChunk];
+  __shared__ float s_out[kCorrChunk];
   const int lane = threadIdx.x;
   const int k = blockIdx.y;
-  const int E = indptr[node_num];
+  const long long E = indptr[node_num];
   const long long cb64 = static_cast<long long>(blockIdx.x) * kCorrChunk;
-  if (cb64 >= E) return;
+  float* out = dst + static_cast<long long>(k) * nnz;
+  const int n_here = static_cast<int>(min(static_cast<long long>(kCorrChunk), nnz - cb64));   // slots of this chunk
+  if (cb64 >= E) {                                   // nothing but uncovered positions
+    if (!add)
+      for (int i = lane; i < n_here; i += kWave) out[cb64 + i] = 0.f;
+    return;
+  }
   const int cb = static_cast<int>(cb64);
-  const int ce = min(cb + kCorrChunk, E);
-  const int epg = kWave / lpr;
-  const int grp = lane / lpr, slot = lane % lpr;
-  // segment containing edge cb: largest s with indptr[s] <= cb  (uniform binary search)
+  const int ce = static_cast<int>(min(cb64 + kCorrChunk, E));
+  const int n = ce - cb;
+  // segments holding the first / last edge of the chunk: largest s with indptr[s] <= edge  (uniform binary searches)
   int lo = 0, hi = node_num;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (indptr[mid] <= cb) lo = mid; else hi = mid;
   }
-  int s = lo;
+  const int s0 = lo;
+  hi = node_num;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (indptr[mid] <= ce - 1) lo = mid; else hi = mid;
+  }
+  const int s1 = lo;
+  for (int i = lane; i < kCorrChunk; i += kWave) {
+    s_seg[i] = i == 0 ? s0 : 0;
+    s_id[i] = i < n ? ids[cb + i] : 0;
+  }
+  __syncthreads();
+  for (int s = s0 + 1 + lane; s <= s1; s += kWave) atomicMax(&s_seg[indptr[s] - cb], s);   // 0 < indptr[s] - cb < n
+  __syncthreads();
+  {  // inclusive prefix-max over the 256 slots: 4 per lane, then across lanes
+    int m[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] = s_seg[lane * 4 + q];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) m[q] = max(m[q], m[q - 1]);
+    int run = m[3];
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int up = __shfl_up(run, off);
+      if (lane >= off) run = max(run, up);
+    }
+    const int before = __shfl_up(run, 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_seg[lane * 4 + q] = lane == 0 ? m[q] : max(m[q], before);
+  }
+  __syncthreads();
+
+  const int epg = kWave / lpr;
+  const int grp = lane / lpr, slot = lane % lpr;
   const float* base1 = e1 + static_cast<long long>(k) * node_num * C;
   const float* base2 = e2 + static_cast<long long>(k) * nbr_num * C;
-  float* out = dst + static_cast<long long>(k) * nnz;
-  int e = cb;
-  while (e < ce) {
-    const int pe = indptr[s + 1];
-    if (pe <= e) { ++s; continue; }   // skip exhausted / empty segments
-    const int end = min(pe, ce);
-    const float* row1 = base1 + static_cast<long long>(s) * C;
-    for (int j0 = e; j0 < end; j0 += epg) {
-      const int j = j0 + grp;
-      float acc = 0.f;
-      if (j < end) {
-        const float* row2 = base2 + static_cast<long long>(ids[j]) * C;
-        for (int c = slot * VEC; c < C; c += lpr * VEC) {
-          if (VEC == 4) {
-            const float4 a = *reinterpret_cast<const float4*>(row1 + c);
-            const float4 b = *reinterpret_cast<const float4*>(row2 + c);
-            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
-          } else {
-            acc = fmaf(row1[c], row2[c], acc);
-          }
-        }
-      }
-      for (int off = 1; off < lpr; off <<= 1) acc += __shfl_xor(acc, off);
-      if (j < end && slot == 0) out[j] = add ? (out[j] + acc) : acc;
+  auto dot = [&](const float* row1, const float* row2, int c) -> float {
+    if (VEC == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(row1 + c);
+      const float4 b = *reinterpret_cast<const float4*>(row2 + c);
+      return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
     }
-    e = end;
+    return row1[c] * row2[c];
+  };
+  if (ONE) {   // a row fits one pass of the lane group: nothing but independent loads inside the unrolled loop
+    const bool has = slot * VEC < C;
+    const int c = has ? slot * VEC : 0;
+    constexpr int kBatch = 4;                       // edges per lane group in flight: 2 * kBatch independent row loads
+    for (int i0 = 0; i0 < n; i0 += kBatch * epg) {  // 256 % (kBatch * epg) == 0, so every slot index stays < 256
+      float acc[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int i = i0 + u * epg + grp;           // slots >= n hold id 0 / a valid segment: they read real rows
+        acc[u] = dot(base1 + static_cast<long long>(s_seg[i]) * C, base2 + static_cast<long long>(s_id[i]) * C, c);
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        float v = has ? acc[u] : 0.f;
+#pragma unroll
+        for (int off = 1; off < (ONE ? LPR : 1); off <<= 1) v += __shfl_xor(v, off);
+        if (slot == 0) s_out[i0 + u * epg + grp] = v;
+      }
+    }
+  } else {
+    for (int i0 = 0; i0 < n; i0 += epg) {
+      const int i = i0 + grp;
+      const bool live = i < n;
+      const float* row1 = base1 + static_cast<long long>(live ? s_seg[i] : s0) * C;
+      const float* row2 = base2 + static_cast<long long>(s_id[i]) * C;
+      float acc = 0.f;
+      for (int c = slot * VEC; c < C; c += lpr * VEC) acc += dot(row1, row2, c);
+      for (int off = 1; off < lpr; off <<= 1) acc += __shfl_xor(acc, off);
+      if (slot == 0) s_out[i] = acc;
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < n_here; i += kWave) {
+    const float v = s_out[i];
+    float* o = out + cb64 + i;
+    if (i < n) *o = add ? (*o + v) : v;
+    else if (!add) *o = 0.f;
   }
 }
 
@@ -276,7 +344,7 @@ SG_API int sg_seg_take_k_corr_hip(float* dst, const float* embed1, const float* 
   if (int rc = common_checks(req, K, node_num, nnz)) return rc;
   if (req == SG_REQ_NULL || K == 0 || nnz == 0) return SG_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (req == SG_REQ_WRITE)
+  if (req == SG_REQ_WRITE && (node_num == 0 || feat_dim == 0))     // otherwise the main kernel zero-fills
     hipLaunchKernelGGL(zero_uncovered_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256), static_cast<unsigned>(K)),
                        dim3(256), 0, st, dst, neighbor_indptr, static_cast<int>(node_num), static_cast<long long>(nnz));
   if (node_num > 0 && feat_dim > 0) {
@@ -285,14 +353,26 @@ SG_API int sg_seg_take_k_corr_hip(float* dst, const float* embed1, const float* 
     int lpr = 1;
     while (lpr < kWave && lpr < per_row) lpr <<= 1;
     dim3 grid(static_cast<unsigned>((nnz + kCorrChunk - 1) / kCorrChunk), static_cast<unsigned>(K));
-    if (v4)
-      hipLaunchKernelGGL(take_k_corr_kernel<4>, grid, dim3(kWave), 0, st, dst, embed1, embed2, neighbor_ids,
-                         neighbor_indptr, static_cast<int>(node_num), static_cast<long long>(neighbor_node_num),
-                         static_cast<long long>(nnz), static_cast<int>(feat_dim), lpr, req == SG_REQ_ADD);
-    else
-      hipLaunchKernelGGL(take_k_corr_kernel<1>, grid, dim3(kWave), 0, st, dst, embed1, embed2, neighbor_ids,
-                         neighbor_indptr, static_cast<int>(node_num), static_cast<long long>(neighbor_node_num),
-                         static_cast<long long>(nnz), static_cast<int>(feat_dim), lpr, req == SG_REQ_ADD);
+#define SG_CORR(V, L)                                                                                                 \
+  hipLaunchKernelGGL((take_k_corr_kernel<V, L>), grid, dim3(kWave), 0, st, dst, embed1, embed2, neighbor_ids,         \
+                     neighbor_indptr, static_cast<int>(node_num), static_cast<long long>(neighbor_node_num),          \
+                     static_cast<long long>(nnz), static_cast<int>(feat_dim), lpr, req == SG_REQ_ADD)
+#define SG_CORR_V(V)                                                                                                  \
+  do {                                                                                                                \
+    if (per_row > kWave) SG_CORR(V, 0);                                                                               \
+    else switch (lpr) {                                                                                               \
+      case 1: SG_CORR(V, 1); break;                                                                                   \
+      case 2: SG_CORR(V, 2); break;                                                                                   \
+      case 4: SG_CORR(V, 4); break;                                                                                   \
+      case 8: SG_CORR(V, 8); break;                                                                                   \
+      case 16: SG_CORR(V, 16); break;                                                                                 \
+      case 32: SG_CORR(V, 32); break;                                                                                 \
+      default: SG_CORR(V, 64); break;                                                                                 \
+    }                                                                                                                 \
+  } while (0)
+    if (v4) SG_CORR_V(4); else SG_CORR_V(1);
+#undef SG_CORR_V
+#undef SG_CORR
   }
   return check_launch("seg_take_k_corr");
 }

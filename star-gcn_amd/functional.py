@@ -33,13 +33,16 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
-        dpre = ops.act_bwd(L.f32c(dy), y, ctx.act, ctx.slope)
         dx = dw = db = None
+        if ctx.has_bias and ctx.needs_input_grad[2] and dy.dim() == 2:
+            dpre, db = ops.act_bwd_colsum(L.f32c(dy), y, ctx.act, ctx.slope)      # one pass for both
+        else:
+            dpre = ops.act_bwd(L.f32c(dy), y, ctx.act, ctx.slope)
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dpre, weight)                     # (N,U) @ (U,K)
         if ctx.needs_input_grad[1]:
             dw = ops.gemm(dpre, x, trans_a=True)            # (U,N) @ (N,K), split-K over N
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
             db = ops.colsum(dpre)
         return dx, dw, db, None, None
 

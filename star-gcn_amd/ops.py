@@ -202,6 +202,23 @@ def act_bwd(dout, out_act, act, slope=0.1):
     return dpre
 
 
+def act_bwd_colsum(dout, out_act, act, slope=0.1):
+    """(dpre, column sums of dpre) in one pass -- the Dense backward's activation gradient + bias gradient."""
+    if _act_id(act) == 0:
+        return dout, colsum(dout)
+    L.require_gpu(dout, out_act)
+    dout = L.f32c(dout)
+    assert dout.dim() == 2 and out_act.is_contiguous()
+    M, N = dout.shape
+    dpre = torch.empty_like(dout)
+    db = torch.empty((N,), dtype=torch.float32, device=dout.device)
+    lib = L.lib()
+    ws, wsn = L.workspace(lib.sg_colsum_workspace_bytes(M, N), dout.device)
+    L.check(lib.sg_act_bwd_colsum_hip(L.ptr(dpre), L.ptr(db), L.ptr(dout), L.ptr(out_act), M, N, _act_id(act),
+                                      float(slope), REQ_WRITE, L.ptr(ws), wsn, L.stream_ptr()), "sg_act_bwd_colsum_hip")
+    return dpre, db
+
+
 def colsum(x):
     L.require_gpu(x)
     assert x.dim() == 2 and x.stride(1) == 1

@@ -152,6 +152,21 @@ def test_linear_autograd(act):
     rel_close(bd.grad, br.grad, 2e-5, "db")
 
 
+@pytest.mark.parametrize("M,N", [(777, 250), (40000, 256), (5, 3), (300, 1030)])
+@pytest.mark.parametrize("act", ["leaky", "tanh", "relu", "sigmoid"])
+def test_fused_activation_and_bias_gradient(M, N, act):
+    """sg_act_bwd_colsum_hip == sg_act_bwd_hip followed by sg_colsum_hip, bit for bit (same partial-sum order)."""
+    from star_gcn_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    dy = torch.randn(M, N, generator=g).cuda()
+    y = torch.tanh(torch.randn(M, N, generator=g)).cuda()
+    dpre = ops.act_bwd(dy, y, act, 0.1)
+    db = ops.colsum(dpre)
+    dpre2, db2 = ops.act_bwd_colsum(dy, y, act, 0.1)
+    assert torch.equal(dpre, dpre2) and torch.equal(db, db2)
+    rel_close(db, dpre.double().sum(0), 1e-5, "db")
+
+
 CASES = [  # n_dst, n_src, nnz, R, D, U
     (60, 45, 900, 5, 64, 250),
     (45, 60, 900, 5, 32, 250),

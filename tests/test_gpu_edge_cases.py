@@ -144,3 +144,32 @@ def test_column_sliced_gather_matches_unsliced(slices):
                 scale = float(want.abs().max())
                 assert float((sliced.double().cpu() - want).abs().max()) <= 2e-6 * scale
                 assert float((sliced - plain).abs().max()) <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("C", [4, 12, 64, 100, 256, 260, 1024])
+def test_take_k_corr_chunk_staging(C):
+    """The chunked kernel's segment staging: runs of empty segments (also at chunk boundaries), segments longer than a
+    256-edge chunk, padding edges past indptr[-1] (zero-filled on write, untouched on add), K > 1; lane groups of
+    every width (C/4 = 1 ... 64) and the multi-pass path (C > 256)."""
+    from star_gcn_amd import ops
+    rng = np.random.default_rng(C)
+    K, S, T = 2, 400, 57
+    lens = rng.integers(0, 12, S)
+    lens[rng.choice(S, 150, replace=False)] = 0              # runs of empty segments
+    lens[[3, 200]] = [700, 300]                              # segments spanning several chunks
+    lens[255:262] = 0
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    E = int(indptr[-1])
+    nnz = E + 300                                            # padding edges, a whole chunk of them included
+    ids = rng.integers(0, T, nnz).astype(np.int32)
+    e1 = rng.normal(size=(K, S, C)).astype(np.float32)
+    e2 = rng.normal(size=(K, T, C)).astype(np.float32)
+    ref = O.seg_take_k_corr(e1, e2, ids, indptr)
+    got = ops.seg_take_k_corr(dev(e1), dev(e2), dev(ids), dev(indptr))
+    close(got[:, :E], ref[:, :E], 2e-5)
+    assert float(got[:, E:].abs().max()) == 0.0
+    prev = rng.normal(size=(K, nnz)).astype(np.float32)
+    acc = dev(prev)
+    ops.seg_take_k_corr(dev(e1), dev(e2), dev(ids), dev(indptr), out=acc, req=ops.REQ_ADD)
+    close(acc[:, :E], prev[:, :E] + ref[:, :E], 2e-5)
+    assert np.array_equal(acc[:, E:].cpu().numpy(), prev[:, E:])

@@ -95,6 +95,31 @@ def gather_cases():
             print("take_k_corr %-19s %7.3f ms  %7.1f GB/s (4C+8 B/edge)" % (name, t * 1e3, (4 * C + 8) * nnz / t / 1e9))
 
 
+def small_cases():
+    """The step's small kernels: rating-head inner products, long split-K weight gradients, Dense backward's
+    activation + bias gradient."""
+    g = torch.Generator().manual_seed(0)
+    S, T, nnz, C = 69878, 10677, 10_000_000, 64
+    lens = torch.distributions.Multinomial(nnz, torch.rand(S, generator=g) ** 2 + 1e-3).sample().long()
+    indptr = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)]).int().cuda()
+    idx = torch.randint(0, T, (nnz,), generator=g).int().cuda()
+    x = torch.randn(1, T, C, device="cuda")
+    e1 = torch.randn(1, S, C, device="cuda")
+    t = timeit(lambda: ops.seg_take_k_corr(e1, x, idx, indptr))
+    print("take_k_corr 10M pairs C=64        %7.3f ms  %7.1f GB/s (4C+8 B/edge)" % (t * 1e3, (4 * C + 8) * nnz / t / 1e9))
+    for M, N, K in [(256, 256, 69878), (64, 256, 69878), (256, 256, 10677), (2560, 256, 10677)]:
+        a = torch.randn(K, M, device="cuda")
+        b = torch.randn(K, N, device="cuda")
+        t = timeit(lambda: ops.gemm(a, b, trans_a=True))
+        print("gemm TN (weight gradient) M=%5d N=%4d K=%6d  %7.3f ms  %6.1f TF/s" % (M, N, K, t * 1e3, 2.0 * M * N * K / t / 1e12))
+    for M, N in [(69878, 256), (10677, 256)]:
+        dy = torch.randn(M, N, device="cuda")
+        y = torch.randn(M, N, device="cuda")
+        t1 = timeit(lambda: ops.colsum(ops.act_bwd(dy, y, "leaky", 0.1)))
+        t2 = timeit(lambda: ops.act_bwd_colsum(dy, y, "leaky", 0.1))
+        print("Dense backward %6d x %3d: act_bwd + colsum %7.3f ms, fused %7.3f ms" % (M, N, t1 * 1e3, t2 * 1e3))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "gather"]
     if "gemm" in which:
@@ -103,3 +128,5 @@ if __name__ == "__main__":
         gemm_big_cases()
     if "gather" in which:
         gather_cases()
+    if "small" in which:
+        small_cases()
