@@ -89,6 +89,19 @@ int sg_seg_gather_sum_hinted_hip(float* dst, int64_t dst_group, int64_t dst_ld, 
                                  int64_t src_ld, const float* weights, const int32_t* indices, const int32_t* indptr,
                                  int64_t seg_num, int64_t nnz, int64_t feat_dim, int req, int act, float slope,
                                  void* workspace, size_t workspace_bytes, void* stream, int64_t src_bytes);
+/* Source-partitioned form, for gathers whose OUTPUT is small next to what they read (the item-side gradient of the rating
+ * head: 10 M edges x 256 B gathered from an 18 MB matrix into 10 677 rows).  The plan's edges are ordered by source-row
+ * range first (sg_part_keys_hip + sg_sort_i32_hip + sg_bounds_from_sorted_hip): indptr_p has parts * seg_num + 1
+ * entries, indices_p the source rows, wpos the ORIGINAL slot of every edge (weights are read through it).  With
+ * parts = 8 each XCD takes one contiguous eighth of the edge list, so its private 4 MB L2 only ever sees one source
+ * range; the parts * seg_num partial rows go to the workspace and are summed in part order: dst = act(sum (+ dst)).
+ * No reference counterpart (a scheduling transformation of seg_weighted_pool / its data gradient); deterministic. */
+size_t sg_seg_gather_sum_parts_workspace_bytes(int64_t seg_num, int64_t parts, int64_t nnz, int64_t feat_dim);
+int sg_seg_gather_sum_parts_hip(float* dst, int64_t dst_group, int64_t dst_ld, const float* src, int64_t src_group,
+                                int64_t src_ld, const float* weights, const int32_t* wpos, const int32_t* indices_p,
+                                const int32_t* indptr_p, int64_t seg_num, int64_t parts, int64_t nnz, int64_t feat_dim,
+                                int req, int act, float slope, void* workspace, size_t workspace_bytes, void* stream,
+                                int64_t src_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * (2) gradient of (1) w.r.t. data == reference `_contrib__backward_seg_take_k_corr_embed2(weights,
@@ -392,6 +405,10 @@ int sg_multilink_fuse_csr_hip(int32_t* c_indptr, int32_t* c_idx, int32_t* c_q, f
                               int32_t* c_from, int32_t* t_from, const int32_t* indptr, const int32_t* end_points,
                               const int32_t* level, const float* support, int64_t num_links, int64_t n_dst,
                               int64_t n_src, int64_t nnz, void* workspace, size_t workspace_bytes, void* stream);
+/* keys[j] = part(src_ids[j]) * n_seg + segment(j) for the source-partitioned gather plan (parts <= 64; bounds[1..parts)
+ * = first source row of each part, device array); padding positions get parts * n_seg. */
+int sg_part_keys_hip(int32_t* keys, const int32_t* src_ids, const int32_t* indptr, const int32_t* bounds, int64_t parts,
+                     int64_t n_seg, int64_t n, void* stream);
 int sg_gen_row_indices_hip(int32_t* edge_row, const int32_t* ind_ptr, int64_t row_num, int64_t nnz, void* stream);
 int sg_count_indices_hip(int32_t* counts, const int32_t* idx, int64_t n, int64_t total, void* stream);
 int sg_get_support_hip(float* support, const int32_t* row_degrees, const int32_t* col_degrees, const int32_t* end_points,

@@ -93,6 +93,10 @@ _SIGS = {
     "sg_multilink_fuse_workspace_bytes": (_SZ, [_I64] * 4),
     "sg_multilink_fuse_hip": (_INT, [_P] * 13 + [_I64] * 4 + [_P, _SZ, _P]),
     "sg_multilink_fuse_csr_hip": (_INT, [_P] * 16 + [_I64] * 4 + [_P, _SZ, _P]),
+    "sg_part_keys_hip": (_INT, [_P] * 4 + [_I64] * 3 + [_P]),
+    "sg_seg_gather_sum_parts_workspace_bytes": (_SZ, [_I64] * 4),
+    "sg_seg_gather_sum_parts_hip": (_INT, [_P, _I64, _I64, _P, _I64, _I64] + [_P] * 4 + [_I64] * 4
+                                    + [_INT, _INT, _F32, _P, _SZ, _P, _I64]),
     "sg_gen_row_indices_hip": (_INT, [_P, _P, _I64, _I64, _P]),
     "sg_count_indices_hip": (_INT, [_P, _P, _I64, _I64, _P]),
     "sg_get_support_hip": (_INT, [_P] * 5 + [_I64, _INT, _P]),

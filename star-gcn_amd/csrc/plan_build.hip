@@ -894,3 +894,39 @@ SG_API int sg_recon_mask_dev_hip(int32_t* noise, int32_t* recon, int64_t n, int6
                        static_cast<long long>(n), p_zero, seed ^ 0xa5a5a5a5ULL, counter, dev_counter);
   return check_launch("sg_recon_mask_hip");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Source-partitioned view of a gather plan (sg_seg_gather_sum_parts_hip): key[j] = part(src[j]) * n_seg + seg(j), with
+// part(v) = #{p in [1, parts): bounds[p] <= v}; a stable sort by this key orders the edges [part 0: segment by segment |
+// part 1: ... ] and sg_bounds_from_sorted_hip over parts * n_seg keys gives the row pointer of the sub-segments.
+// Positions >= indptr[n_seg] (padding) get the key parts * n_seg and sort behind everything.
+// ------------------------------------------------------------------------------------------------------------------
+namespace sg {
+namespace {
+__global__ void part_keys_kernel(int32_t* __restrict__ keys, const int32_t* __restrict__ src, const int32_t* __restrict__ indptr,
+                                 const int32_t* __restrict__ bounds, int parts, long long n_seg, long long n) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  if (j >= indptr[n_seg]) { keys[j] = static_cast<int32_t>(parts * n_seg); return; }
+  long long lo = 0, hi = n_seg;                       // segment of edge j: upper_bound(indptr[1..n_seg], j)
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (indptr[mid + 1] <= j) lo = mid + 1; else hi = mid;
+  }
+  const int v = src[j];
+  int p = 0;
+  for (int q = 1; q < parts; ++q) p += bounds[q] <= v ? 1 : 0;
+  keys[j] = static_cast<int32_t>(p * n_seg + lo);
+}
+}  // namespace
+}  // namespace sg
+
+SG_API int sg_part_keys_hip(int32_t* keys, const int32_t* src_ids, const int32_t* indptr, const int32_t* bounds,
+                            int64_t parts, int64_t n_seg, int64_t n, void* stream) {
+  if (parts < 1 || parts > 64 || n_seg < 0 || n < 0 || (parts + 1) * n_seg >= (1ll << 31) - 1) return fail(SG_ERR_INVALID, "bad size");
+  if (n == 0) return SG_OK;
+  if (!keys || !src_ids || !indptr || (parts > 1 && !bounds)) return fail(SG_ERR_INVALID, "null pointer argument");
+  hipLaunchKernelGGL(part_keys_kernel, dim3(blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), keys, src_ids, indptr,
+                     bounds, static_cast<int>(parts), static_cast<long long>(n_seg), static_cast<long long>(n));
+  return check_launch("sg_part_keys_hip");
+}

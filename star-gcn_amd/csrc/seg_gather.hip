@@ -54,6 +54,9 @@ struct GatherArgs {
   int32_t src_shift;
   int32_t seg_num, C, n_chunks, lpr;
   int32_t n_slices, Cs;  // column slicing across XCDs: slice i covers channels [i*Cs, (i+1)*Cs); 1 / C = off
+  int32_t xcd_ranges;    // 1: XCD x takes the CONTIGUOUS chunk range [x * span, (x + 1) * span) instead of every 8th chunk --
+                         // for source-partitioned plans (edges ordered by source-row range first): each private L2 then
+                         // only ever sees one range of the gathered matrix
   int32_t req, mean;
   int32_t act;
   float slope;
@@ -211,7 +214,11 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
   // touches the 4*Cs-byte column slice (i % n_slices) of every source row, so its private 4 MB L2 faces a working set
   // n_slices times smaller than the source matrix.  The 8 / n_slices XCDs that share a slice split the chunks.
   int k = blockIdx.x, slice = 0;
-  if (a.n_slices > 1) {
+  if (a.xcd_ranges) {
+    const int span = (a.n_chunks + 7) >> 3;
+    k = (blockIdx.x & 7) * span + (blockIdx.x >> 3);
+    if (k >= a.n_chunks) return;
+  } else if (a.n_slices > 1) {
     const int xcd = blockIdx.x & 7;
     slice = xcd % a.n_slices;
     k = (blockIdx.x >> 3) * (8 / a.n_slices) + xcd / a.n_slices;
@@ -375,7 +382,9 @@ size_t gather_workspace_bytes(int64_t batch, int64_t nnz, int64_t C) {
 template <int VEC>
 static void launch_variants(const GatherArgs& a, dim3 fix_grid, hipStream_t st, bool grouped, bool uni) {
   dim3 grid = fix_grid;   // sliced: 8 workgroups (one per XCD) per group of 8 / n_slices chunks
-  if (a.n_slices > 1) {
+  if (a.xcd_ranges) {
+    grid.x = ((static_cast<unsigned>(a.n_chunks) + 7u) / 8u) * 8u;
+  } else if (a.n_slices > 1) {
     const unsigned per = 8u / static_cast<unsigned>(a.n_slices);
     grid.x = (static_cast<unsigned>(a.n_chunks) + per - 1) / per * 8u;
   }
@@ -436,11 +445,26 @@ static int env_slices_force() {
   return v;
 }
 
+int launch_gather_ex(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs, const float* src, int64_t src_group,
+                     int64_t src_ld, int64_t src_bs, const float* w, int64_t w_bs, const int32_t* wpos,
+                     const int32_t* idx, const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t nnz, int64_t C,
+                     int req, int mean, int act, float slope, void* workspace, size_t workspace_bytes, hipStream_t st,
+                     int64_t src_bytes, int xcd_ranges);
+
 int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs, const float* src, int64_t src_group,
                   int64_t src_ld, int64_t src_bs, const float* w, int64_t w_bs, const int32_t* wpos,
                   const int32_t* idx, const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t nnz, int64_t C,
                   int req, int mean, int act, float slope, void* workspace, size_t workspace_bytes, hipStream_t st,
                   int64_t src_bytes) {
+  return launch_gather_ex(dst, dst_group, dst_ld, dst_bs, src, src_group, src_ld, src_bs, w, w_bs, wpos, idx, indptr, batch,
+                          seg_num, nnz, C, req, mean, act, slope, workspace, workspace_bytes, st, src_bytes, 0);
+}
+
+int launch_gather_ex(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs, const float* src, int64_t src_group,
+                     int64_t src_ld, int64_t src_bs, const float* w, int64_t w_bs, const int32_t* wpos,
+                     const int32_t* idx, const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t nnz, int64_t C,
+                     int req, int mean, int act, float slope, void* workspace, size_t workspace_bytes, hipStream_t st,
+                     int64_t src_bytes, int xcd_ranges) {
   if (!valid_req(req)) return fail(SG_ERR_INVALID, "req must be 0 (null), 1 (write) or 3 (add), got %d", req);
   if (req == SG_REQ_NULL) return SG_OK;
   if (batch < 0 || seg_num < 0 || nnz < 0 || C < 0) return fail(SG_ERR_INVALID, "negative dimension");
@@ -499,6 +523,8 @@ int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs,
     if (!valid(slices)) slices = 1;
   }
   if (env_slices_force() > 0 && valid(env_slices_force())) slices = env_slices_force();   // tests: slice every launch
+  if (xcd_ranges) slices = 1;     // the source-row partition replaces the column slices
+  a.xcd_ranges = xcd_ranges ? 1 : 0;
   a.n_slices = slices;
   a.Cs = static_cast<int32_t>(C / slices);
   int lpr = 1;
@@ -514,6 +540,40 @@ int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs,
   else launch_variants<1>(a, grid, st, grouped, uni);
   prof_end(rec, st);
   return check_launch("seg_gather");
+}
+
+// dst[s, :] (+)= act( sum_p part[p * seg_num + s, :] ), p ascending: joins the partial results of a source-partitioned
+// gather.  One float4 (or float) per thread.
+template <int VEC>
+__global__ void sum_parts_kernel(float* __restrict__ dst, long long dst_group, long long dst_ld,
+                                 const float* __restrict__ part, long long seg_num, int parts, int C, int req, int act,
+                                 float slope) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int cv = C / VEC;
+  if (i >= seg_num * cv) return;
+  const long long s = i / cv;
+  const int c = static_cast<int>(i - s * cv) * VEC;
+  float acc[VEC];
+  ld_vec<VEC>(acc, part + s * C + c);
+  for (int p = 1; p < parts; ++p) {
+    float t[VEC];
+    ld_vec<VEC>(t, part + (static_cast<long long>(p) * seg_num + s) * C + c);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] += t[v];
+  }
+  const long long g = s / dst_group;
+  float* o = dst + g * dst_ld + (s - g * dst_group) * C + c;
+  if (req == SG_REQ_ADD) {
+    float old[VEC];
+    ld_vec<VEC>(old, o);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] += old[v];
+  }
+  if (act) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = gather_act(acc[v], act, slope);
+  }
+  st_vec<VEC>(o, acc);
 }
 
 }  // namespace sg
@@ -545,6 +605,47 @@ SG_API int sg_seg_gather_sum_hinted_hip(float* dst, int64_t dst_group, int64_t d
   return sg::launch_gather(dst, dst_group, dst_ld, 0, src, src_group, src_ld, 0, weights, 0, nullptr, indices, indptr,
                            1, seg_num, nnz, feat_dim, req, 0, act, slope, workspace, workspace_bytes,
                            static_cast<hipStream_t>(stream), src_bytes);
+}
+
+SG_API size_t sg_seg_gather_sum_parts_workspace_bytes(int64_t seg_num, int64_t parts, int64_t nnz, int64_t feat_dim) {
+  if (seg_num < 0 || parts < 1 || nnz < 0 || feat_dim < 0) return 0;
+  return ((static_cast<size_t>(parts) * seg_num * feat_dim * sizeof(float) + 255) & ~static_cast<size_t>(255)) + 256 +
+         sg::gather_workspace_bytes(1, nnz, feat_dim);
+}
+
+SG_API int sg_seg_gather_sum_parts_hip(float* dst, int64_t dst_group, int64_t dst_ld, const float* src,
+                                       int64_t src_group, int64_t src_ld, const float* weights, const int32_t* wpos,
+                                       const int32_t* indices_p, const int32_t* indptr_p, int64_t seg_num, int64_t parts,
+                                       int64_t nnz, int64_t feat_dim, int req, int act, float slope, void* workspace,
+                                       size_t workspace_bytes, void* stream, int64_t src_bytes) {
+  if (!sg::valid_req(req)) return sg::fail(SG_ERR_INVALID, "req must be 0, 1 or 3, got %d", req);
+  if (req == SG_REQ_NULL || seg_num == 0 || feat_dim == 0) return SG_OK;
+  if (seg_num < 0 || nnz < 0 || feat_dim < 0 || parts < 1 || parts * seg_num >= (1ll << 31) - 1)
+    return sg::fail(SG_ERR_INVALID, "bad size");
+  if (dst_group < 1 || !dst) return sg::fail(SG_ERR_INVALID, "bad destination");
+  if (!workspace || workspace_bytes < sg_seg_gather_sum_parts_workspace_bytes(seg_num, parts, nnz, feat_dim))
+    return sg::fail(SG_ERR_WORKSPACE, "partitioned gather workspace too small");
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  const size_t pbytes = (static_cast<size_t>(parts) * seg_num * feat_dim * sizeof(float) + 255) & ~static_cast<size_t>(255);
+  float* part = reinterpret_cast<float*>(base);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t used = static_cast<size_t>(base - static_cast<char*>(workspace)) + pbytes;
+  int rc = sg::launch_gather_ex(part, 1, feat_dim, 0, src, src_group, src_ld, 0, weights, 0, wpos, indices_p, indptr_p, 1,
+                                parts * seg_num, nnz, feat_dim, SG_REQ_WRITE, 0, SG_ACT_NONE, 0.f, base + pbytes,
+                                workspace_bytes - used, st, src_bytes, parts == 8 ? 1 : 0);
+  if (rc != SG_OK) return rc;
+  const bool v4 = feat_dim % 4 == 0 && dst_ld % 4 == 0 && sg::aligned(dst, 16);
+  const long long n = seg_num * (v4 ? feat_dim / 4 : feat_dim);
+  const dim3 grid(static_cast<unsigned>((n + 255) / 256));
+  if (v4)
+    hipLaunchKernelGGL(sg::sum_parts_kernel<4>, grid, dim3(256), 0, st, dst, static_cast<long long>(dst_group),
+                       static_cast<long long>(dst_ld), part, static_cast<long long>(seg_num), static_cast<int>(parts),
+                       static_cast<int>(feat_dim), req, act, slope);
+  else
+    hipLaunchKernelGGL(sg::sum_parts_kernel<1>, grid, dim3(256), 0, st, dst, static_cast<long long>(dst_group),
+                       static_cast<long long>(dst_ld), part, static_cast<long long>(seg_num), static_cast<int>(parts),
+                       static_cast<int>(feat_dim), req, act, slope);
+  return sg::check_launch("sg_seg_gather_sum_parts_hip");
 }
 
 SG_API int sg_seg_gather_sum_hip(float* dst, int64_t dst_group, int64_t dst_ld, const float* src, int64_t src_group,

@@ -20,7 +20,7 @@ from . import ops
 from .mxgraph import graph as G
 from .mxgraph.layers import (Dense, HeterGCNLayer, InnerProductLayer, LayerDictionary, StackedHeterGCNLayers,
                              get_activation)
-from .plan import TakePlan, TransposePlan
+from .plan import SourcePartition, TakePlan, TransposePlan
 
 
 class _PairTranspose(object):
@@ -60,6 +60,24 @@ class PairPlan(object):
         tp.t_indptr, tp.t_pos, tp.t_seg = d_tip, d_tpos, d_tseg
         tp.seg_num, tp.nnz, tp.total_ind_num, tp.covered = self.n_user, m, self.n_item, n
         self.tplan = tp
+
+
+def _item_side_partition(self, width):
+    """SourcePartition of the transposed pair plan, or None when the plain gather is the better launch: it pays when the
+    gathered table (n_user x width) is well beyond one XCD's 4 MB L2, the output (n_item x width, x8 partial copies) is
+    small next to the gathered bytes, and there are enough pairs to fill the chip.  Built once, on first use."""
+    sp = getattr(self, "_tparts", False)
+    if sp is False:
+        sp = None
+        table, out = self.n_user * width * 4, self.n_item * width * 4
+        if self.n_pairs >= (1 << 20) and table >= (6 << 20) and 8 * out * 8 <= self.n_pairs * width * 4:
+            tp = self.tplan
+            sp = SourcePartition(tp.t_indptr, tp.t_seg, self.n_user, pos=tp.t_pos, parts=8)
+        self._tparts = sp
+    return sp
+
+
+PairPlan.item_side_partition = _item_side_partition
 
 
 def _pair_plan_from_device_csr(cls, indptr, end_points, n_item):
@@ -121,8 +139,14 @@ class _PairDot(torch.autograd.Function):
         if g.shape[1] < pp.items.numel():
             g = torch.nn.functional.pad(g, (0, pp.items.numel() - g.shape[1]))
         d_u = ops.seg_weighted_pool(pi.unsqueeze(0), g, pp.items, pp.indptr)[0] if ctx.needs_input_grad[0] else None
-        d_i = (ops.seg_weighted_pool_bwd_data(g, pu.unsqueeze(0), pp.tplan, pp.n_item)[0]
-               if ctx.needs_input_grad[1] else None)
+        d_i = None
+        if ctx.needs_input_grad[1]:
+            sp = pp.item_side_partition(pu.shape[1])
+            if sp is not None:      # 10 M pairs read from an 18 MB table into 10 k rows: gather from L2-sized ranges
+                d_i = torch.empty((pp.n_item, pu.shape[1]), dtype=torch.float32, device=pu.device)
+                ops.gather_sum_parts(d_i, pu, sp, g, pu.shape[1])
+            else:
+                d_i = ops.seg_weighted_pool_bwd_data(g, pu.unsqueeze(0), pp.tplan, pp.n_item)[0]
         return d_u, d_i, None
 
 

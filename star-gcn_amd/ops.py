@@ -53,6 +53,21 @@ def gather_sum(dst, src, indices, indptr, weights, seg_num, feat_dim, dst_group=
     return dst
 
 
+def gather_sum_parts(dst, src, sp, weights, feat_dim, dst_group=1, dst_ld=None, src_group=1, src_ld=None, req=REQ_WRITE,
+                     act=None, slope=0.1):
+    """gather_sum over a plan.SourcePartition (sg_seg_gather_sum_parts_hip): dst[s] (+)= act(sum_j w[pos[j]] src[row(j)])."""
+    L.require_gpu(dst, src, weights)
+    dst_ld = feat_dim * dst_group if dst_ld is None else dst_ld
+    src_ld = feat_dim * src_group if src_ld is None else src_ld
+    lib = L.lib()
+    ws, wsn = L.workspace(lib.sg_seg_gather_sum_parts_workspace_bytes(sp.n_seg, sp.parts, sp.nnz, feat_dim), dst.device)
+    L.check(lib.sg_seg_gather_sum_parts_hip(L.ptr(dst), dst_group, dst_ld, L.ptr(src), src_group, src_ld, L.ptr(weights),
+                                            L.ptr(sp.pos), L.ptr(sp.src), L.ptr(sp.indptr), sp.n_seg, sp.parts, sp.nnz,
+                                            feat_dim, req, _act_id(act), float(slope), L.ptr(ws), wsn, L.stream_ptr(),
+                                            src.numel() * 4), "sg_seg_gather_sum_parts_hip")
+    return dst
+
+
 def seg_weighted_pool(data, weights, indices, indptr, out=None, req=REQ_WRITE):
     """reference `_contrib_seg_weighted_pool` forward (seg_op.cc:665-716)."""
     L.require_gpu(data, weights, indices, indptr)

@@ -226,6 +226,46 @@ class MultiLinkPlan(object):
         return self._rowsum
 
 
+class SourcePartition(object):
+    """Edges of a gather plan (`indptr` over n_seg segments, `src_ids` = gathered row of every edge, `pos` = slot of the
+    edge's weight, None = its own position) re-ordered by source-row range first: `parts` ranges holding about the same
+    number of edges each.  Consumed by ops.gather_sum_parts (sg_seg_gather_sum_parts_hip): with 8 parts every XCD gathers
+    from ONE range, which fits its private L2.  Built on the device: degree histogram + running sum + searchsorted for the
+    range bounds, sg_part_keys_hip, one stable radix sort, sg_bounds_from_sorted_hip, two index gathers."""
+
+    def __init__(self, indptr, src_ids, n_src_rows, pos=None, parts=8):
+        indptr, src_ids = L.i32c(indptr), L.i32c(src_ids)
+        L.require_gpu(indptr, src_ids)
+        dev = indptr.device
+        lib = L.lib()
+        n, n_seg = int(src_ids.numel()), int(indptr.numel() - 1)
+        self.parts, self.n_seg, self.nnz = int(parts), n_seg, n
+        counts = torch.zeros(int(n_src_rows), dtype=torch.int32, device=dev)
+        L.check(lib.sg_count_indices_hip(L.ptr(counts), L.ptr(src_ids), n, int(n_src_rows), L.stream_ptr()),
+                "sg_count_indices_hip")
+        run = torch.cumsum(counts, 0)
+        want = (torch.arange(parts + 1, device=dev, dtype=torch.int64) * n) // parts
+        self.bounds = torch.searchsorted(run, want.to(run.dtype), right=False).to(torch.int32).contiguous()
+        keys = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        L.check(lib.sg_part_keys_hip(L.ptr(keys), L.ptr(src_ids), L.ptr(indptr), L.ptr(self.bounds), parts, n_seg, n,
+                                     L.stream_ptr()), "sg_part_keys_hip")
+        skeys, order = torch.empty_like(keys), torch.empty_like(keys)
+        ws, wsn = L.workspace(lib.sg_sort_i32_workspace_bytes(n), dev)
+        L.check(lib.sg_sort_i32_hip(L.ptr(skeys), L.ptr(order), L.ptr(keys), None, n, parts * n_seg, L.ptr(ws), wsn,
+                                    L.stream_ptr()), "sg_sort_i32_hip")
+        self.indptr = torch.empty(parts * n_seg + 1, dtype=torch.int32, device=dev)
+        L.check(lib.sg_bounds_from_sorted_hip(L.ptr(self.indptr), L.ptr(skeys), n, parts * n_seg, L.stream_ptr()),
+                "sg_bounds_from_sorted_hip")
+        self.src = torch.empty_like(keys)
+        L.check(lib.sg_gather_i32_hip(L.ptr(self.src), L.ptr(src_ids), L.ptr(order), n, L.stream_ptr()), "sg_gather_i32_hip")
+        if pos is None:
+            self.pos = order
+        else:
+            self.pos = torch.empty_like(keys)
+            L.check(lib.sg_gather_i32_hip(L.ptr(self.pos), L.ptr(L.i32c(pos)), L.ptr(order), n, L.stream_ptr()),
+                    "sg_gather_i32_hip")
+
+
 def upload_packed(arrays, device):
     """ONE host->device copy for several int32 arrays (each padded to a 16-byte multiple); returns device views.
     A per-batch plan used to cost one ~0.2 ms pageable copy per array."""

@@ -178,3 +178,74 @@ def test_synthetic_device_graph_is_a_valid_rating_graph():
     assert lv.min() >= 0 and lv.max() == 15
     p = dg.plan(U)
     assert int(p.c_indptr[-1]) == dg.nnz and int(p.t_indptr[-1]) == dg.nnz
+
+
+@pytest.mark.parametrize("parts", [8, 3, 1])
+@pytest.mark.parametrize("C", [64, 50])
+def test_source_partitioned_gather_equals_the_plain_data_gradient(parts, C):
+    """plan.SourcePartition + sg_seg_gather_sum_parts_hip against sg_seg_weighted_pool_bwd_data_hip and the oracle: the
+    sub-segments partition every segment's edges by source range (bit-exact bookkeeping), the sums agree to fp32
+    reordering; padding edges, empty segments and sources nobody references included."""
+    from star_gcn_amd import ops
+    from star_gcn_amd.plan import SourcePartition, TransposePlan
+    rng = np.random.default_rng(parts * 100 + C)
+    S, T, nnz, pad = 700, 90, 9000, 37
+    lens = rng.multinomial(nnz, rng.dirichlet(np.ones(S) * 0.3))          # many empty user rows
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    items = rng.integers(0, T - 5, nnz + pad).astype(np.int32)            # items T-5.. never referenced
+    d_ip, d_items = torch.from_numpy(indptr).cuda(), torch.from_numpy(items).cuda()
+    tp = TransposePlan(d_items, d_ip, T, d_items.device)
+    sp = SourcePartition(tp.t_indptr, tp.t_seg, S, pos=tp.t_pos, parts=parts)
+    # bookkeeping: same multiset of (segment, source, slot) triples, sub-segment p only holds sources of range p
+    ip = sp.indptr.cpu().numpy()
+    src, pos, b = sp.src.cpu().numpy(), sp.pos.cpu().numpy(), sp.bounds.cpu().numpy()
+    assert ip[0] == 0 and ip[-1] == nnz and np.all(np.diff(ip) >= 0) and b[0] == 0
+    t_ip, t_seg, t_pos = tp.t_indptr.cpu().numpy(), tp.t_seg.cpu().numpy(), tp.t_pos.cpu().numpy()
+    for p in range(parts):
+        for s in rng.choice(T, 12, replace=False):
+            lo, hi = ip[p * T + s], ip[p * T + s + 1]
+            whole = slice(t_ip[s], t_ip[s + 1])
+            hi_b = b[p + 1] if p + 1 < parts else S
+            sel = (t_seg[whole] >= b[p]) & (t_seg[whole] < hi_b) if p else (t_seg[whole] < (b[1] if parts > 1 else S))
+            assert np.array_equal(src[lo:hi], t_seg[whole][sel]) and np.array_equal(pos[lo:hi], t_pos[whole][sel])
+    g = rng.normal(size=(1, nnz + pad)).astype(np.float32)
+    g[:, nnz:] = 0                       # padding carries weight 0 wherever the model pads (reference graph.py:221-222)
+    pu = rng.normal(size=(S, C)).astype(np.float32)
+    d_g, d_pu = torch.from_numpy(g).cuda(), torch.from_numpy(pu).cuda()
+    ref = ops.seg_weighted_pool_bwd_data(d_g, d_pu.unsqueeze(0), tp, T)[0]
+    got = torch.full((T, C), 7.0, device="cuda")
+    ops.gather_sum_parts(got, d_pu, sp, d_g, C)
+    want = O.seg_weighted_pool_bwd_data(g, pu[None], items, indptr, T)[0]
+    scale = float(np.abs(want).max())
+    assert float((got.cpu() - torch.from_numpy(want)).abs().max()) <= 1e-5 * scale
+    assert float((got - ref).abs().max()) <= 1e-5 * scale
+    acc = torch.from_numpy(want).cuda().clone()
+    ops.gather_sum_parts(acc, d_pu, sp, d_g, C, req=ops.REQ_ADD)
+    assert float((acc.cpu() - 2 * torch.from_numpy(want)).abs().max()) <= 2e-5 * scale
+
+
+def test_pair_plan_uses_the_partitioned_gather_when_it_pays(monkeypatch):
+    """_PairDot.backward: with the eligibility forced, the item-side gradient through the source partition equals the
+    plain transposed gather."""
+    import star_gcn_amd.model as M
+    rng = np.random.default_rng(4)
+    nu, ni, n = 500, 80, 6000
+    cells = rng.choice(nu * ni, n, replace=False)
+    cells.sort()
+    u, i = (cells // ni).astype(np.int32), (cells % ni).astype(np.int32)
+    pu = torch.randn(nu, 64, device="cuda")
+    pi = torch.randn(ni, 64, device="cuda")
+    gy = torch.randn(n, device="cuda")
+    grads = []
+    for forced in (False, True):
+        pp = M.PairPlan.from_sorted_device_pairs(torch.from_numpy(u).cuda(), torch.from_numpy(i).cuda(), nu, ni)
+        if forced:
+            from star_gcn_amd.plan import SourcePartition
+            pp._tparts = SourcePartition(pp.tplan.t_indptr, pp.tplan.t_seg, nu, pos=pp.tplan.t_pos, parts=8)
+        else:
+            assert pp.item_side_partition(64) is None                  # far too small to pay
+        a, b = pu.clone().requires_grad_(True), pi.clone().requires_grad_(True)
+        M.pair_inner_product(a, b, pp).backward(gy)
+        grads.append((a.grad, b.grad))
+    assert torch.equal(grads[0][0], grads[1][0])
+    assert float((grads[0][1] - grads[1][1]).abs().max()) <= 1e-5 * float(grads[0][1].abs().max())

@@ -107,6 +107,15 @@ def small_cases():
     e1 = torch.randn(1, S, C, device="cuda")
     t = timeit(lambda: ops.seg_take_k_corr(e1, x, idx, indptr))
     print("take_k_corr 10M pairs C=64        %7.3f ms  %7.1f GB/s (4C+8 B/edge)" % (t * 1e3, (4 * C + 8) * nnz / t / 1e9))
+    from star_gcn_amd.plan import SourcePartition, TransposePlan
+    tp = TransposePlan(idx, indptr, T, idx.device)
+    gw = torch.randn(1, nnz, device="cuda")
+    t1 = timeit(lambda: ops.seg_weighted_pool_bwd_data(gw, e1, tp, T))
+    sp = SourcePartition(tp.t_indptr, tp.t_seg, S, pos=tp.t_pos, parts=8)
+    out = torch.empty(T, C, device="cuda")
+    t2 = timeit(lambda: ops.gather_sum_parts(out, e1[0], sp, gw, C))
+    print("rating head item-side gradient (10M x 256 B from 17.9 MB): plain %7.3f ms, source-partitioned %7.3f ms" %
+          (t1 * 1e3, t2 * 1e3))
     for M, N, K in [(256, 256, 69878), (64, 256, 69878), (256, 256, 10677), (2560, 256, 10677)]:
         a = torch.randn(K, M, device="cuda")
         b = torch.randn(K, N, device="cuda")
