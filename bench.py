@@ -304,6 +304,105 @@ def hbm_leg(args, dev):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def run_config5(args, dev, dist_on, world, rank, backend):
+    """`--shape config5`: BASELINE config 5 as it is meant to run -- N ranks, each holding ONE user block of --hbm-shape
+    (default: 1.25 M users x all 1 M items, 125 M ratings, 16 levels; 8 ranks = the 10 M x 1 M / 1 B-edge graph), the
+    item side replicated, item-side partials all-reduced over RCCL.  Weak scaling: per-GPU work is fixed.  Every rank
+    generates and plans its block on its own device; the item degrees of the support are summed over the ranks."""
+    import torch.distributed as dist
+    import star_gcn_amd.dist as SD
+    import star_gcn_amd.functional as SF
+    import star_gcn_amd.model as M
+    from star_gcn_amd.device_graph import synthetic_device_graph
+    nu, ni, ne, R = (int(x) for x in args.hbm_shape.split(","))
+    D = args.dim
+    t0 = time.perf_counter()
+    dg = synthetic_device_graph(nu, ni, ne, R, dev, seed=5 + rank, item_seed=5)
+    E_local = dg.nnz
+    vals = dg.values()
+    stats = torch.stack([vals.double().sum(), (vals.double() ** 2).sum(),
+                         torch.tensor(float(E_local), dtype=torch.float64, device=dev)])
+    if dist_on:
+        deg = dg.item_degrees.clone()
+        if backend == "gloo":
+            deg_h, stats_h = deg.cpu(), stats.cpu()
+            dist.all_reduce(deg_h)
+            dist.all_reduce(stats_h)
+            deg, stats = deg_h.to(dev), stats_h.to(dev)
+        else:
+            dist.all_reduce(deg)
+            dist.all_reduce(stats)
+        dg = dg.with_item_degrees(deg)
+    s1, s2, n = (float(x) for x in stats.tolist())
+    E_total = int(round(n))
+    mean = s1 / n
+    std = max((s2 / n - mean * mean) * n / max(n - 1, 1), 1e-12) ** 0.5
+    y = ((vals - mean) / std).contiguous()
+    del vals
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    part = SD.NodePartition([U], [I]) if dist_on else None
+    torch.manual_seed(1234)
+    net = build_net(dg, D, args.order, dev, part)
+    plan = net.make_plan_device(dg)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter() - t0
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        preds, _, _ = net.run(plan)
+        loss = SF.l2_loss(preds[0].view(-1), y, 1.0 / E_total)
+        loss.backward()
+        if dist_on:
+            SD.allreduce_grads(net.local_region_parameters())
+        return loss
+
+    step()
+    # replicated parameters (and, for simplicity, the user tables) drawn by parameter NAME: identical on every rank
+    M.deterministic_init(net, 1234, {U: (0, nu, nu), I: (0, ni, ni)})
+    elapsed, loss, timeline = timed_steps(step, args.steps, args.warmup, dev, dist_on)
+    comm = SD.STATS.read() if dist_on else None
+    loss_total = loss.detach().clone()
+    edges_per_rank = [E_local]
+    if dist_on:
+        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        loss_total = SD.all_reduce_sum(loss_total.view(1))[0]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, E_local)
+        edges_per_rank = [int(e) for e in gathered]
+    roof = gather_roofline(timeline, E_local, D, args.steps)
+    if roof:
+        roof.update(bound="hbm", peak=HBM_PEAK / 1e9, frac=roof["achieved"] * 1e9 / HBM_PEAK, traffic=None)
+        roof.pop("_classes", None)
+    value = E_total / (elapsed / args.steps)
+    out = {"metric": METRIC, "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE config 5, %d user block(s) of %d users x %d items, %d ratings per block, %d "
+                                  "rating levels, dim %d; same 2-layer network, fwd+bwd; every block generated and planned "
+                                  "on its rank's device" % (world, nu, ni, ne, R, D),
+                      "partition": "single GPU (one block)" if world == 1 else
+                                   "1-D user-block node partition, items replicated, RCCL all-reduce of item-side "
+                                   "partials on a side stream",
+                      "order": args.order, "graph_gen_s": round(t_gen, 2), "plan_build_s": round(t_plan, 2),
+                      "loss": float(loss_total), "edges_per_rank": edges_per_rank,
+                      "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
+           "roofline": roof, "step_roofline_frac": value * 8 * (8 + 4 * D) / (world * HBM_PEAK),
+           "cpu_baseline": None}
+    if dist_on:
+        out["collectives"] = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
+                              "calls_per_step": comm["calls"] / args.steps,
+                              "allreduce_bytes_per_step": comm["bytes"] / args.steps,
+                              "collective_ms_per_step": comm["device_ms"] / args.steps}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.destroy_process_group()
+
+
 def run_rank(args):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -342,6 +441,9 @@ def run_rank(args):
     if args.hbm_only:
         out = {"metric": METRIC, "hbm_bound": hbm_leg(args, dev)}
         print(json.dumps(out))
+        return
+    if args.shape == "config5":
+        run_config5(args, dev, dist_on, world, rank, backend)
         return
 
     graph, eu, ei, vals = S.make_graph(args.shape)

@@ -56,6 +56,12 @@ class DeviceBipartite(object):
         self.node_ids_dict = {self.U: np.arange(self.n_user, dtype=np.int32), self.I: np.arange(self.n_item, dtype=np.int32)}
         self.meta_graph = {self.U: {self.I: 1}, self.I: {self.U: 1}}
 
+    def with_item_degrees(self, item_degrees):
+        """The same user block normalised with other (= the GLOBAL) item degrees: what a rank of a node-partitioned run
+        uses once the per-rank degree counts have been summed over the ranks."""
+        return DeviceBipartite(self.ind_ptr, self.end_points, self.level, self.n_item, self.multi_link, self.U, self.I,
+                               item_degrees=item_degrees)
+
     @classmethod
     def from_host(cls, graph, name_user, name_item, device):
         """Upload the user->item CSRMat of a host HeterGraph (one copy of ind_ptr / end_points / values); the level
@@ -122,16 +128,23 @@ class DeviceBipartite(object):
         return self._plans[key]
 
 
-def synthetic_device_graph(n_user, n_item, n_edges, n_levels, device, seed=0, name_user="user", name_item="movie"):
+def synthetic_device_graph(n_user, n_item, n_edges, n_levels, device, seed=0, name_user="user", name_item="movie",
+                           item_seed=None):
     """MovieLens-SHAPED synthetic graph generated ON the device (SURVEY 8(d) recipe of star_gcn_amd.synthetic at sizes
     the host cannot plan in bench time): log-normal user / item propensities (sigma 1.0 / 1.5), no duplicate (user,
-    item) pairs, every node keeps degree >= 1, ML-like level skew.  Returns a DeviceBipartite."""
+    item) pairs, every node keeps degree >= 1, ML-like level skew.  Returns a DeviceBipartite.
+    item_seed: draw the item propensities from their own generator -- the ranks of a node-partitioned run generate
+    their user blocks with different `seed`s against the SAME item popularity."""
     from .synthetic import level_probs, level_values
     dev = torch.device(device)
     g = torch.Generator(device=dev)
     g.manual_seed(20240917 + int(seed))
     pu = torch.exp(torch.randn(n_user, generator=g, device=dev, dtype=torch.float64))
-    pi = torch.exp(1.5 * torch.randn(n_item, generator=g, device=dev, dtype=torch.float64))
+    gi = g
+    if item_seed is not None:
+        gi = torch.Generator(device=dev)
+        gi.manual_seed(77001 + int(item_seed))
+    pi = torch.exp(1.5 * torch.randn(n_item, generator=gi, device=dev, dtype=torch.float64))
     cu, ci = torch.cumsum(pu, 0), torch.cumsum(pi, 0)
     cu, ci = cu / cu[-1], ci / ci[-1]
     n_edges = int(min(n_edges, n_user * n_item // 2))

@@ -45,3 +45,30 @@ def test_bench_rccl_code_path_with_one_rank():
     assert forced["collectives"]["backend"] == "nccl" and forced["collectives"]["rccl_ranks"] == 1
     assert forced["collectives"]["calls_per_step"] >= 5
     assert abs(one["config"]["loss"] - forced["config"]["loss"]) <= 1e-6 * max(1.0, abs(one["config"]["loss"]))
+
+
+def test_config5_mode_runs_as_user_blocks_over_two_ranks():
+    """`--shape config5`: every rank generates and plans ONE user block on the device, item degrees are summed over the
+    ranks, item-side partials are all-reduced; weak scaling (per-rank work fixed).  Small blocks here; the default
+    block is the 1.25 M x 1 M x 125 M shard."""
+    flags = ["--shape", "config5", "--hbm-shape", "3000,2000,60000,4", "--dim", "64", "--steps", "2", "--warmup", "1"]
+
+    def run(extra, env_extra):
+        env = dict(os.environ, **env_extra)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + flags + extra, env=env, cwd=ROOT,
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        return json.loads(lines[0])
+
+    one = run([], {})
+    two = run(["--gpus", "2"], {"SG_BENCH_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and one["scaling"] == two["scaling"] == "weak"
+    assert len(two["config"]["edges_per_rank"]) == 2 and all(e >= 60000 for e in two["config"]["edges_per_rank"])
+    assert two["config"]["edges_per_rank"][0] == one["config"]["edges_per_rank"][0]      # rank 0's block is the N = 1 block
+    assert two["collectives"]["rccl_ranks"] == 2 and two["collectives"]["allreduce_bytes_per_step"] > 0
+    for r in (one, two):
+        assert r["roofline"]["bound"] == "hbm" and 0 < r["config"]["loss"] < 10 and r["value"] > 0
