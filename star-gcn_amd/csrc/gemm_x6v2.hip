@@ -48,7 +48,20 @@ struct GemmArgs {   // must match gemm_f32.hip
 #define SG_X6V2_ABLATE 0      // development: 1 producers skip split + LDS stores, 2 consumers skip MFMAs, 3 consumers skip LDS reads
 #endif
 
+#ifndef SG_X6V2_TIMING
+#define SG_X6V2_TIMING 0      // development: per-phase cycle counters of consumer wave 0 / producer wave 4 (sg_x6v2_timing_read)
+#endif
+
 namespace x6v2 {
+
+#if SG_X6V2_TIMING
+// [0] consumer barrier wait  [1] consumer LDS reads + MFMA  [2] consumer epilogue  [3] consumer steps
+// [4] producer split + LDS stores  [5] producer global-load issue  [6] producer barrier wait  [7] producer steps
+__device__ unsigned long long g_timing[8];
+#define SG_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define SG_T(var)
+#endif
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int kThreads = 512;
@@ -228,9 +241,14 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
     while (c.valid && c.kt >= c.kt_end) cursor_set(c, g, c.item + stride, n_items, ktiles);
     const int a_off = (wm * 64 + l31) * ROWB + kh * 16;
     const int b_off = OPER + (wn * 64 + l31) * ROWB + kh * 16;
+#if SG_X6V2_TIMING
+    unsigned long long tc_wait = 0, tc_work = 0, tc_epi = 0, tc_steps = 0;
+#endif
     for (long long s = 0; s < total2; ++s) {
+      SG_T(t_a);
       __syncthreads();               // stage (s & 1) holds step s; the producers go on to fill the other stage
       if (s >= total) break;         // odd number of steps: the pairing barrier only
+      SG_T(t_b);
       const char* st = smem + (s & 1) * STAGE;
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
@@ -270,6 +288,11 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
           for (int p = 0; p < 3; ++p) accs[i][0][p] += static_cast<float>(a[i][p][0]) + static_cast<float>(b[i][p][0]);
 #endif
       }
+#if SG_X6V2_TIMING
+      // the last MFMA result is needed before the clock is read: make the MFMA section's time its execution time
+      asm volatile("s_nop 0" :: "v"(accs[1][1][0]), "v"(acc[1][1][0]));
+#endif
+      SG_T(t_c);
       if (c.kt + 1 >= c.kt_end) {
         // ---- epilogue of this item.  The MFMA result layout (col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 kh) gives a
         // lane ONE column: stored directly, every wave instruction writes 128-byte pieces of 64 different rows, and at
@@ -342,7 +365,16 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
         }
       }
       cursor_next(c, g, n_items, ktiles, stride);
+#if SG_X6V2_TIMING
+      { SG_T(t_d); tc_wait += t_b - t_a; tc_work += t_c - t_b; tc_epi += t_d - t_c; ++tc_steps; }
+#endif
     }
+#if SG_X6V2_TIMING
+    if (t == 0) {
+      atomicAdd(&g_timing[0], tc_wait); atomicAdd(&g_timing[1], tc_work); atomicAdd(&g_timing[2], tc_epi);
+      atomicAdd(&g_timing[3], tc_steps);
+    }
+#endif
   } else {
     // ---------------------------------------------------------------------------------------------- producers ----
     float va[NSETS][16], vb[NSETS][16];           // staging sets: the tile of step s lives in set (s % NSETS)
@@ -380,20 +412,46 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
     //  then waits for ALL sets at the top of every iteration -- total2 keeps the body branch-free)
 #pragma unroll
     for (int u = 0; u < NSETS; ++u) gload(va[u], vb[u], k0s[u]);      // steps 0 .. NSETS-1
+#if SG_X6V2_TIMING
+    unsigned long long tp_store = 0, tp_load = 0, tp_wait = 0, tp_steps = 0;
+#endif
     for (long long s = 0; s < total2; s += kUnroll) {
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
+        SG_T(p_a);
         sstore(u & 1, va[u % NSETS], vb[u % NSETS], k0s[u % NSETS]);  // step s + u
+        SG_T(p_b);
         gload(va[u % NSETS], vb[u % NSETS], k0s[u % NSETS]);          // step s + u + NSETS
+        SG_T(p_c);
         __syncthreads();
+#if SG_X6V2_TIMING
+        { SG_T(p_d); tp_store += p_b - p_a; tp_load += p_c - p_b; tp_wait += p_d - p_c; ++tp_steps; }
+#endif
       }
     }
+#if SG_X6V2_TIMING
+    if (t == kRole) {
+      atomicAdd(&g_timing[4], tp_store); atomicAdd(&g_timing[5], tp_load); atomicAdd(&g_timing[6], tp_wait);
+      atomicAdd(&g_timing[7], tp_steps);
+    }
+#endif
   }
 }
 
 }  // namespace x6v2
 
 int x6v2_items(const GemmArgs& g) { return g.tiles_m * g.tiles_n * g.splits; }
+
+#if SG_X6V2_TIMING
+// development build only (not declared in include/stargcn.h): read and reset the phase counters
+extern "C" __attribute__((visibility("default"))) int sg_x6v2_timing_read(unsigned long long* out8) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(x6v2::g_timing), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(x6v2::g_timing), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 // x6v2 handles 16-byte aligned operands whose K-contiguous dimension is a multiple of 4 (everything the step produces);
 // sg_gemm_f32_hip falls back to the exact-fp32 kernel otherwise
