@@ -72,3 +72,21 @@ def test_config5_mode_runs_as_user_blocks_over_two_ranks():
     assert two["collectives"]["rccl_ranks"] == 2 and two["collectives"]["allreduce_bytes_per_step"] > 0
     for r in (one, two):
         assert r["roofline"]["bound"] == "hbm" and 0 < r["config"]["loss"] < 10 and r["value"] > 0
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's N > 1 launch line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` (ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env)."""
+    env = dict(os.environ, SG_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29713", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + COMMON
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                 # rank 0 only
+    two = json.loads(lines[0])
+    one = _bench([], {})
+    assert two["n_gpus"] == 2 and two["collectives"]["rccl_ranks"] == 2
+    assert abs(one["config"]["loss"] - two["config"]["loss"]) <= 1e-5 * max(1.0, abs(one["config"]["loss"]))
