@@ -65,12 +65,16 @@ class PairPlan(object):
 def _item_side_partition(self, width):
     """SourcePartition of the transposed pair plan, or None when the plain gather is the better launch: it pays when the
     gathered table (n_user x width) is well beyond one XCD's 4 MB L2, the output (n_item x width, x8 partial copies) is
-    small next to the gathered bytes, and there are enough pairs to fill the chip.  Built once, on first use."""
+    small next to the gathered bytes, there are enough pairs to fill the chip, and the plan is one that is kept across
+    steps.  Built once, on first use."""
     sp = getattr(self, "_tparts", False)
     if sp is False:
         sp = None
         table, out = self.n_user * width * 4, self.n_item * width * 4
-        if self.n_pairs >= (1 << 20) and table >= (6 << 20) and 8 * out * 8 <= self.n_pairs * width * 4:
+        # `reused`: only plans that live across steps (the full-batch head over a resident CSR) amortise the extra radix
+        # sort; a per-iteration batch plan would pay it every time
+        if (getattr(self, "reused", False) and self.n_pairs >= (1 << 20) and table >= (6 << 20)
+                and 8 * out * 8 <= self.n_pairs * width * 4):
             tp = self.tplan
             sp = SourcePartition(tp.t_indptr, tp.t_seg, self.n_user, pos=tp.t_pos, parts=8)
         self._tparts = sp
@@ -88,6 +92,7 @@ def _pair_plan_from_device_csr(cls, indptr, end_points, n_item):
     indptr, end_points = L.i32c(indptr), L.i32c(end_points)
     self.n_user, self.n_item, self.n_pairs = int(indptr.shape[0] - 1), int(n_item), int(end_points.shape[0])
     self.identity, self.inv_order, self.order = True, None, None
+    self.reused = True               # built once per graph, used by every step
     self.indptr, self.items = indptr, end_points
     t = TransposePlan(end_points, indptr, self.n_item, end_points.device)
     tp = _PairTranspose()
