@@ -168,101 +168,188 @@ __global__ void zero_uncovered_kernel(float* __restrict__ dst, const int32_t* __
 }
 
 // ---------------------------------------------------------------------------------------------------
-// seg_sum: one wave per (segment, batch)
+// seg_sum / seg_softmax: G lanes per (segment, batch) with G in {4, 8, 16, 32, 64} chosen from the average segment
+// length (a (user, level) segment of the rating graph holds 14 edges: a whole wave per segment leaves 3/4 of the lanes
+// idle and needs 4x the waves); reductions stay inside the lane group (__shfl_xor with offsets < G).
 // ---------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+static inline int lanes_per_segment(int64_t nnz, int64_t seg_num) {
+  const int64_t avg = seg_num > 0 ? nnz / seg_num : 0;
+  int g = 4;
+  while (g < kWave && g < avg) g <<= 1;
+  return g;
+}
+static inline dim3 group_grid(int64_t segs, int g, int64_t batch) {
+  const int64_t per_block = kBlock / g;
+  return dim3(static_cast<unsigned>((segs + per_block - 1) / per_block), static_cast<unsigned>(batch));
+}
+
+template <int G>
 __global__ __launch_bounds__(kBlock) void seg_sum_kernel(float* __restrict__ dst, const float* __restrict__ data,
                                                          const int32_t* __restrict__ indptr, int seg_num, long long nnz,
                                                          int add) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const long long seg = static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
-  if (seg >= seg_num) return;
+  const int slot = threadIdx.x & (G - 1);
+  const long long seg = static_cast<long long>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
+  const bool live = seg < seg_num;                       // dead groups run the shuffles with empty ranges
   const int k = blockIdx.y;
   const float* d = data + static_cast<long long>(k) * nnz;
+  const int pb = live ? indptr[seg] : 0, pe = live ? indptr[seg + 1] : 0;
   float acc = 0.f;
-  for (int j = indptr[seg] + lane; j < indptr[seg + 1]; j += kWave) acc += d[j];
-  acc = wave_sum(acc);
-  if (lane == 0) {
+  for (int j = pb + slot; j < pe; j += G) acc += d[j];
+  acc = group_sum<G>(acc);
+  if (live && slot == 0) {
     float* o = dst + static_cast<long long>(k) * seg_num + seg;
     *o = add ? (*o + acc) : acc;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// seg_broadcast_{add,mul,to}: one thread per (edge position, batch); segment by binary search
+// seg_broadcast_{add,mul,to}: one wave per chunk of 256 edge positions; the segment of every position comes from the
+// chunk-level staging seg_take_k_corr uses (segment starts marked with ds_max, prefix-max over the 256 slots) instead
+// of a 17-step binary search per element.
 // ---------------------------------------------------------------------------------------------------
-__global__ void seg_broadcast_kernel(float* __restrict__ dst, const float* __restrict__ lhs,
-                                     const float* __restrict__ rhs, const int32_t* __restrict__ indptr, int seg_num,
-                                     long long nnz, int op, int add) {
-  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (j >= nnz) return;
+__global__ __launch_bounds__(kWave) void seg_broadcast_kernel(float* __restrict__ dst, const float* __restrict__ lhs,
+                                                              const float* __restrict__ rhs,
+                                                              const int32_t* __restrict__ indptr, int seg_num,
+                                                              long long nnz, int op, int add) {
+  __shared__ int32_t s_seg[kCorrChunk];
+  const int lane = threadIdx.x;
   const int k = blockIdx.y;
-  float* o = dst + static_cast<long long>(k) * nnz + j;
-  if (j >= indptr[seg_num]) {
-    if (!add) *o = 0.f;
+  const long long E = indptr[seg_num];
+  const long long cb64 = static_cast<long long>(blockIdx.x) * kCorrChunk;
+  const int n_here = static_cast<int>(min(static_cast<long long>(kCorrChunk), nnz - cb64));
+  float* out = dst + static_cast<long long>(k) * nnz + cb64;
+  if (cb64 >= E) {
+    if (!add)
+      for (int i = lane; i < n_here; i += kWave) out[i] = 0.f;
     return;
   }
-  int lo = 0, hi = seg_num;  // largest s with indptr[s] <= j  (then indptr[s+1] > j after skipping empties)
+  const int cb = static_cast<int>(cb64);
+  const int ce = static_cast<int>(min(cb64 + kCorrChunk, E));
+  const int n = ce - cb;
+  int lo = 0, hi = seg_num;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (indptr[mid] <= j) lo = mid; else hi = mid;
+    if (indptr[mid] <= cb) lo = mid; else hi = mid;
   }
-  const float r = rhs[static_cast<long long>(k) * seg_num + lo];
-  float v;
-  if (op == 0) v = lhs[static_cast<long long>(k) * nnz + j] + r;
-  else if (op == 1) v = lhs[static_cast<long long>(k) * nnz + j] * r;
-  else v = r;
-  *o = add ? (*o + v) : v;
+  const int s0 = lo;
+  hi = seg_num;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (indptr[mid] <= ce - 1) lo = mid; else hi = mid;
+  }
+  const int s1 = lo;
+  for (int i = lane; i < kCorrChunk; i += kWave) s_seg[i] = i == 0 ? s0 : 0;
+  __syncthreads();
+  for (int s = s0 + 1 + lane; s <= s1; s += kWave) atomicMax(&s_seg[indptr[s] - cb], s);
+  __syncthreads();
+  int m[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) m[q] = s_seg[lane * 4 + q];
+#pragma unroll
+  for (int q = 1; q < 4; ++q) m[q] = max(m[q], m[q - 1]);
+  int run = m[3];
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int up = __shfl_up(run, off);
+    if (lane >= off) run = max(run, up);
+  }
+  const int before = __shfl_up(run, 1);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s_seg[lane * 4 + q] = lane == 0 ? m[q] : max(m[q], before);
+  __syncthreads();
+  const float* l = lhs ? lhs + static_cast<long long>(k) * nnz + cb64 : nullptr;
+  const float* r = rhs + static_cast<long long>(k) * seg_num;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {          // position i = 64 q + lane: every wave instruction is one 256-byte burst
+    const int i = q * kWave + lane;
+    if (i < n) {
+      const float rv = r[s_seg[i]];
+      float v;
+      if (op == 0) v = l[i] + rv;
+      else if (op == 1) v = l[i] * rv;
+      else v = rv;
+      out[i] = add ? (out[i] + v) : v;
+    } else if (i < n_here && !add) {
+      out[i] = 0.f;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// seg_softmax forward / backward: one wave per (segment, batch)
+// seg_softmax forward / backward: G lanes per (segment, batch)
 // ---------------------------------------------------------------------------------------------------
+template <int G>
 __global__ __launch_bounds__(kBlock) void seg_softmax_kernel(float* __restrict__ dst, const float* __restrict__ data,
                                                              const int32_t* __restrict__ indptr, int seg_num,
                                                              long long nnz) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const long long seg = static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
-  if (seg >= seg_num) return;
+  const int slot = threadIdx.x & (G - 1);
+  const long long seg = static_cast<long long>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
+  const bool live = seg < seg_num;
   const int k = blockIdx.y;
   const float* d = data + static_cast<long long>(k) * nnz;
   float* o = dst + static_cast<long long>(k) * nnz;
-  const int pb = indptr[seg], pe = indptr[seg + 1];
+  const int pb = live ? indptr[seg] : 0, pe = live ? indptr[seg + 1] : 0;
   float m = -3.402823466e+38f;
-  for (int j = pb + lane; j < pe; j += kWave) m = fmaxf(m, d[j]);
-  m = wave_max(m);
+  for (int j = pb + slot; j < pe; j += G) m = fmaxf(m, d[j]);
+  m = group_max<G>(m);
   float s = 0.f;
-  for (int j = pb + lane; j < pe; j += kWave) {
+  for (int j = pb + slot; j < pe; j += G) {
     const float e = expf(d[j] - m);
     o[j] = e;
     s += e;
   }
-  s = wave_sum(s);
-  for (int j = pb + lane; j < pe; j += kWave) o[j] = o[j] / s;
+  s = group_sum<G>(s);
+  for (int j = pb + slot; j < pe; j += G) o[j] = o[j] / s;
 }
 
+template <int G>
 __global__ __launch_bounds__(kBlock) void seg_softmax_bwd_kernel(float* __restrict__ dst,
                                                                  const float* __restrict__ ograd,
                                                                  const float* __restrict__ val,
                                                                  const int32_t* __restrict__ indptr, int seg_num,
                                                                  long long nnz, int add) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const long long seg = static_cast<long long>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
-  if (seg >= seg_num) return;
+  const int slot = threadIdx.x & (G - 1);
+  const long long seg = static_cast<long long>(blockIdx.x) * (kBlock / G) + threadIdx.x / G;
+  const bool live = seg < seg_num;
   const long long off = static_cast<long long>(blockIdx.y) * nnz;
-  const int pb = indptr[seg], pe = indptr[seg + 1];
+  const int pb = live ? indptr[seg] : 0, pe = live ? indptr[seg + 1] : 0;
   float s = 0.f;
-  for (int j = pb + lane; j < pe; j += kWave) s = fmaf(ograd[off + j], val[off + j], s);
-  s = wave_sum(s);
-  for (int j = pb + lane; j < pe; j += kWave) {
+  for (int j = pb + slot; j < pe; j += G) s = fmaf(ograd[off + j], val[off + j], s);
+  s = group_sum<G>(s);
+  for (int j = pb + slot; j < pe; j += G) {
     const float g = val[off + j] * (ograd[off + j] - s);
     dst[off + j] = add ? (dst[off + j] + g) : g;
   }
 }
 
+#define SG_BY_GROUP(G_, CALL)  \
+  switch (G_) {                \
+    case 4: { constexpr int G = 4; CALL; } break;    \
+    case 8: { constexpr int G = 8; CALL; } break;    \
+    case 16: { constexpr int G = 16; CALL; } break;  \
+    case 32: { constexpr int G = 32; CALL; } break;  \
+    default: { constexpr int G = 64; CALL; } break;  \
+  }
+
 // ---------------------------------------------------------------------------------------------------
-// seg_pool max forward: one wave per (segment, batch); lanes over channels; edges in CSR order with a
-// strict '>' so the first maximum wins; empty segment -> 0 / -1 (reference seg_op.cc:264-283).
+// seg_pool max forward: one wave per (segment, batch); a lane owns VEC consecutive channels; the edges of the segment
+// are taken four at a time (four independent id -> row loads in flight; the first version's one-edge loop was a
+// dependent id -> row -> compare chain: 4.1 ms for 10 M edges x 256 channels against 0.55 ms for the sum).  Candidates
+// are compared in CSR order with a strict '>' so the first maximum wins; empty segment -> 0 / -1 (seg_op.cc:264-283).
 // ---------------------------------------------------------------------------------------------------
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void seg_pool_max_kernel(float* __restrict__ dst, int32_t* __restrict__ arg,
                                                               const float* __restrict__ data,
                                                               const int32_t* __restrict__ indices,
@@ -275,19 +362,46 @@ __global__ __launch_bounds__(kBlock) void seg_pool_max_kernel(float* __restrict_
   const int pb = indptr[seg], pe = indptr[seg + 1];
   const float* base = data + static_cast<long long>(k) * total * C;
   const long long orow = (static_cast<long long>(k) * seg_num + seg) * C;
-  for (int c = lane; c < C; c += kWave) {
-    float best = (pe == pb) ? 0.f : -3.402823466e+38f;
-    int bi = -1;
-    for (int j = pb; j < pe; ++j) {
-      const float v = base[static_cast<long long>(indices[j]) * C + c];
-      if (v > best) { best = v; bi = j; }
+  for (int c = lane * VEC; c < C; c += kWave * VEC) {
+    float best[VEC];
+    int bi[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { best[v] = (pe == pb) ? 0.f : -3.402823466e+38f; bi[v] = -1; }
+    int j = pb;
+    for (; j + 4 <= pe; j += 4) {
+      float x[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* row = base + static_cast<long long>(indices[j + u]) * C + c;
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(row);
+          x[u][0] = t.x; x[u][1 % VEC] = t.y; x[u][2 % VEC] = t.z; x[u][3 % VEC] = t.w;
+        } else {
+          x[u][0] = row[0];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          if (x[u][v] > best[v]) { best[v] = x[u][v]; bi[v] = j + u; }
     }
-    dst[orow + c] = best;
-    arg[orow + c] = bi;
+    for (; j < pe; ++j) {
+      const float* row = base + static_cast<long long>(indices[j]) * C + c;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float xv = row[v];
+        if (xv > best[v]) { best[v] = xv; bi[v] = j; }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { dst[orow + c + v] = best[v]; arg[orow + c + v] = bi[v]; }
   }
 }
 
-// seg_pool max backward over the transposed plan: ddata[n,c] (+)= sum_p ograd[t_seg[p],c] * (arg[t_seg[p],c]==t_pos[p])
+// seg_pool max backward over the transposed plan: ddata[n,c] (+)= sum_p ograd[t_seg[p],c] * (arg[t_seg[p],c]==t_pos[p]).
+// A lane owns VEC consecutive channels; four transposed edges in flight (the terms are still added in plan order).
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void seg_pool_max_bwd_kernel(float* __restrict__ ddata,
                                                                   const float* __restrict__ ograd,
                                                                   const int32_t* __restrict__ arg,
@@ -302,13 +416,41 @@ __global__ __launch_bounds__(kBlock) void seg_pool_max_bwd_kernel(float* __restr
   const int pb = t_indptr[n], pe = t_indptr[n + 1];
   const long long gbase = static_cast<long long>(k) * seg_num * C;
   float* o = ddata + (static_cast<long long>(k) * total + n) * C;
-  for (int c = lane; c < C; c += kWave) {
-    float acc = 0.f;
-    for (int p = pb; p < pe; ++p) {
-      const long long r = gbase + static_cast<long long>(t_seg[p]) * C + c;
-      acc += (arg[r] == t_pos[p]) ? ograd[r] : 0.f;
+  for (int c = lane * VEC; c < C; c += kWave * VEC) {
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    int p = pb;
+    for (; p + 4 <= pe; p += 4) {
+      float g[4][VEC];
+      int a[4][VEC], pos[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long r = gbase + static_cast<long long>(t_seg[p + u]) * C + c;
+        pos[u] = t_pos[p + u];
+        if (VEC == 4) {
+          const float4 tg = *reinterpret_cast<const float4*>(ograd + r);
+          const int4 ta = *reinterpret_cast<const int4*>(arg + r);
+          g[u][0] = tg.x; g[u][1 % VEC] = tg.y; g[u][2 % VEC] = tg.z; g[u][3 % VEC] = tg.w;
+          a[u][0] = ta.x; a[u][1 % VEC] = ta.y; a[u][2 % VEC] = ta.z; a[u][3 % VEC] = ta.w;
+        } else {
+          g[u][0] = ograd[r];
+          a[u][0] = arg[r];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += (a[u][v] == pos[u]) ? g[u][v] : 0.f;
     }
-    o[c] = add ? (o[c] + acc) : acc;
+    for (; p < pe; ++p) {
+      const long long r = gbase + static_cast<long long>(t_seg[p]) * C + c;
+      const int pos = t_pos[p];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += (arg[r + v] == pos) ? ograd[r + v] : 0.f;
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[c + v] = add ? (o[c + v] + acc[v]) : acc[v];
   }
 }
 
@@ -381,8 +523,10 @@ SG_API int sg_seg_sum_hip(float* dst, const float* data, const int32_t* indptr, 
                           int64_t nnz, int req, void* stream) {
   if (int rc = common_checks(req, batch, seg_num, nnz)) return rc;
   if (req == SG_REQ_NULL || batch == 0 || seg_num == 0) return SG_OK;
-  hipLaunchKernelGGL(seg_sum_kernel, seg_grid(seg_num, batch), dim3(kBlock), 0, static_cast<hipStream_t>(stream), dst,
-                     data, indptr, static_cast<int>(seg_num), static_cast<long long>(nnz), req == SG_REQ_ADD);
+  const int lanes = lanes_per_segment(nnz, seg_num);
+  SG_BY_GROUP(lanes, hipLaunchKernelGGL(seg_sum_kernel<G>, group_grid(seg_num, G, batch), dim3(kBlock), 0,
+                                        static_cast<hipStream_t>(stream), dst, data, indptr, static_cast<int>(seg_num),
+                                        static_cast<long long>(nnz), req == SG_REQ_ADD));
   return check_launch("seg_sum");
 }
 
@@ -392,8 +536,9 @@ SG_API int sg_seg_broadcast_hip(float* dst, const float* lhs, const float* rhs, 
   if (op < 0 || op > 2) return fail(SG_ERR_INVALID, "op must be 0 (add), 1 (mul) or 2 (to)");
   if (op != 2 && lhs == nullptr && nnz > 0) return fail(SG_ERR_INVALID, "lhs is null");
   if (req == SG_REQ_NULL || batch == 0 || nnz == 0) return SG_OK;
-  hipLaunchKernelGGL(seg_broadcast_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256), static_cast<unsigned>(batch)),
-                     dim3(256), 0, static_cast<hipStream_t>(stream), dst, lhs, rhs, indptr, static_cast<int>(seg_num),
+  hipLaunchKernelGGL(seg_broadcast_kernel,
+                     dim3(static_cast<unsigned>((nnz + kCorrChunk - 1) / kCorrChunk), static_cast<unsigned>(batch)),
+                     dim3(kWave), 0, static_cast<hipStream_t>(stream), dst, lhs, rhs, indptr, static_cast<int>(seg_num),
                      static_cast<long long>(nnz), op, req == SG_REQ_ADD);
   return check_launch("seg_broadcast");
 }
@@ -406,9 +551,11 @@ SG_API int sg_seg_softmax_hip(float* dst, const float* data, const int32_t* indp
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(zero_uncovered_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256), static_cast<unsigned>(batch)),
                      dim3(256), 0, st, dst, indptr, static_cast<int>(seg_num), static_cast<long long>(nnz));
-  if (seg_num > 0)
-    hipLaunchKernelGGL(seg_softmax_kernel, seg_grid(seg_num, batch), dim3(kBlock), 0, st, dst, data, indptr,
-                       static_cast<int>(seg_num), static_cast<long long>(nnz));
+  if (seg_num > 0) {
+    const int lanes = lanes_per_segment(nnz, seg_num);
+    SG_BY_GROUP(lanes, hipLaunchKernelGGL(seg_softmax_kernel<G>, group_grid(seg_num, G, batch), dim3(kBlock), 0, st, dst,
+                                          data, indptr, static_cast<int>(seg_num), static_cast<long long>(nnz)));
+  }
   return check_launch("seg_softmax");
 }
 
@@ -420,9 +567,12 @@ SG_API int sg_seg_softmax_bwd_hip(float* dst, const float* ograd, const float* v
   if (req == SG_REQ_WRITE)
     hipLaunchKernelGGL(zero_uncovered_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256), static_cast<unsigned>(batch)),
                        dim3(256), 0, st, dst, indptr, static_cast<int>(seg_num), static_cast<long long>(nnz));
-  if (seg_num > 0)
-    hipLaunchKernelGGL(seg_softmax_bwd_kernel, seg_grid(seg_num, batch), dim3(kBlock), 0, st, dst, ograd, val, indptr,
-                       static_cast<int>(seg_num), static_cast<long long>(nnz), req == SG_REQ_ADD);
+  if (seg_num > 0) {
+    const int lanes = lanes_per_segment(nnz, seg_num);
+    SG_BY_GROUP(lanes, hipLaunchKernelGGL(seg_softmax_bwd_kernel<G>, group_grid(seg_num, G, batch), dim3(kBlock), 0, st,
+                                          dst, ograd, val, indptr, static_cast<int>(seg_num),
+                                          static_cast<long long>(nnz), req == SG_REQ_ADD));
+  }
   return check_launch("seg_softmax_bwd");
 }
 
@@ -442,9 +592,14 @@ SG_API int sg_seg_pool_hip(float* dst, int32_t* pool_indices, const float* data,
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (pool_type == SG_POOL_MAX) {
     if (!pool_indices) return fail(SG_ERR_INVALID, "pool_indices is required for max pooling");
-    hipLaunchKernelGGL(seg_pool_max_kernel, seg_grid(seg_num, batch), dim3(kBlock), 0, st, dst, pool_indices, data,
-                       indices, indptr, static_cast<int>(seg_num), static_cast<long long>(total_ind_num),
-                       static_cast<int>(feat_dim));
+    if (feat_dim % 4 == 0 && aligned(data, 16))
+      hipLaunchKernelGGL(seg_pool_max_kernel<4>, seg_grid(seg_num, batch), dim3(kBlock), 0, st, dst, pool_indices, data,
+                         indices, indptr, static_cast<int>(seg_num), static_cast<long long>(total_ind_num),
+                         static_cast<int>(feat_dim));
+    else
+      hipLaunchKernelGGL(seg_pool_max_kernel<1>, seg_grid(seg_num, batch), dim3(kBlock), 0, st, dst, pool_indices, data,
+                         indices, indptr, static_cast<int>(seg_num), static_cast<long long>(total_ind_num),
+                         static_cast<int>(feat_dim));
     return check_launch("seg_pool_max");
   }
   return launch_gather(dst, 1, feat_dim, seg_num * feat_dim, data, 1, feat_dim, total_ind_num * feat_dim, nullptr, 0,
@@ -468,9 +623,14 @@ SG_API int sg_seg_pool_bwd_hip(float* ddata, const float* ograd, const int32_t* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (pool_type == SG_POOL_MAX) {
     if (!pool_indices) return fail(SG_ERR_INVALID, "pool_indices is required for max pooling");
-    hipLaunchKernelGGL(seg_pool_max_bwd_kernel, seg_grid(total_ind_num, batch), dim3(kBlock), 0, st, ddata, ograd,
-                       pool_indices, t_indptr, t_pos, t_seg, static_cast<int>(seg_num),
-                       static_cast<long long>(total_ind_num), static_cast<int>(feat_dim), req == SG_REQ_ADD);
+    if (feat_dim % 4 == 0 && aligned(ograd, 16) && aligned(pool_indices, 16))
+      hipLaunchKernelGGL(seg_pool_max_bwd_kernel<4>, seg_grid(total_ind_num, batch), dim3(kBlock), 0, st, ddata, ograd,
+                         pool_indices, t_indptr, t_pos, t_seg, static_cast<int>(seg_num),
+                         static_cast<long long>(total_ind_num), static_cast<int>(feat_dim), req == SG_REQ_ADD);
+    else
+      hipLaunchKernelGGL(seg_pool_max_bwd_kernel<1>, seg_grid(total_ind_num, batch), dim3(kBlock), 0, st, ddata, ograd,
+                         pool_indices, t_indptr, t_pos, t_seg, static_cast<int>(seg_num),
+                         static_cast<long long>(total_ind_num), static_cast<int>(feat_dim), req == SG_REQ_ADD);
     return check_launch("seg_pool_max_bwd");
   }
   const size_t gbytes = gather_workspace_bytes(batch, nnz, feat_dim);

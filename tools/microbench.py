@@ -129,6 +129,40 @@ def small_cases():
         print("Dense backward %6d x %3d: act_bwd + colsum %7.3f ms, fused %7.3f ms" % (M, N, t1 * 1e3, t2 * 1e3))
 
 
+def segop_cases():
+    """The rest of the seg-op surface (API parity ops, not executed by STAR-GCN training) at ML-10M-like sizes, for both
+    segment granularities of the step: 69 878 user segments (143 edges on average) and 698 780 (user, level) segments (14)."""
+    g = torch.Generator().manual_seed(0)
+    nnz, T, C = 10_000_000, 10677, 256
+    for S in (69878, 698780):
+        lens = torch.distributions.Multinomial(nnz, torch.rand(S, generator=g) ** 2 + 1e-3).sample().long()
+        indptr = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)]).int().cuda()
+        idx = torch.randint(0, T, (nnz,), generator=g).int().cuda()
+        d = torch.randn(1, nnz, device="cuda")
+        t = timeit(lambda: ops.seg_sum(d, indptr))
+        print("S=%6d seg_sum            %7.3f ms  %7.1f GB/s" % (S, t * 1e3, 4 * nnz / t / 1e9))
+        t = timeit(lambda: ops.seg_softmax(d, indptr))
+        print("S=%6d seg_softmax        %7.3f ms  %7.1f GB/s (read + write)" % (S, t * 1e3, 8 * nnz / t / 1e9))
+        sm = ops.seg_softmax(d, indptr)
+        t = timeit(lambda: ops.seg_softmax_bwd(d, sm, indptr))
+        print("S=%6d seg_softmax_bwd    %7.3f ms  %7.1f GB/s (2 reads + write)" % (S, t * 1e3, 12 * nnz / t / 1e9))
+        lhs = torch.randn(1, nnz, device="cuda")
+        rhs = torch.randn(1, S, device="cuda")
+        t = timeit(lambda: ops.seg_broadcast(lhs, rhs, indptr, 0))
+        print("S=%6d seg_broadcast_add  %7.3f ms  %7.1f GB/s (read + write)" % (S, t * 1e3, 8 * nnz / t / 1e9))
+        x = torch.randn(1, T, C, device="cuda")
+        from star_gcn_amd.plan import TransposePlan
+        tp = TransposePlan(idx, indptr, T, idx.device)
+        og = torch.randn(1, S, C, device="cuda")
+        for pt in ("sum", "max"):
+            t = timeit(lambda: ops.seg_pool(x, idx, indptr, pt), n=5, warm=2)
+            print("S=%6d seg_pool %-3s C=256   %7.3f ms  %7.1f GB/s algorithmic (4C + 4 B per edge)" %
+                  (S, pt, t * 1e3, (4 * C + 4) * nnz / t / 1e9))
+            _, arg = ops.seg_pool(x, idx, indptr, pt)
+            t = timeit(lambda: ops.seg_pool_bwd(og, arg, indptr, tp, T, pt), n=5, warm=2)
+            print("S=%6d seg_pool %-3s bwd     %7.3f ms" % (S, pt, t * 1e3))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "gather"]
     if "gemm" in which:
@@ -139,3 +173,5 @@ if __name__ == "__main__":
         gather_cases()
     if "small" in which:
         small_cases()
+    if "segops" in which:
+        segop_cases()
