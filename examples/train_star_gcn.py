@@ -97,6 +97,10 @@ def main():
     ap.add_argument("--shape", default="ml-100k")
     ap.add_argument("--data-root", default=None, help="directory holding the extracted ml-100k / ml-1m / ml-10M100K folder")
     ap.add_argument("--dataset", default="ml-100k", choices=["ml-100k", "ml-1m", "ml-10m"])
+    ap.add_argument("--inductive", default=None, choices=["item", "user"],
+                    help="with --data-root: the reference's inductive setting (datasets.py:153-171, iterators.py:171-176): "
+                         "10 %% of the items / users are held out as test nodes, 10 %% of the rest as validation nodes; the "
+                         "network trains on the graph of the training nodes and sees held-out nodes with a zero embedding")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--batch", type=int, default=10000)
     ap.add_argument("--embed", type=int, default=32)
@@ -114,11 +118,17 @@ def main():
     dev = torch.device("cuda", 0)
     torch.manual_seed(args.seed)
     rng = np.random.default_rng(args.seed)
+    ind_kwargs = dict()
     if args.data_root is not None:
         from star_gcn_amd.datasets import LoadData
-        data = LoadData(args.dataset, args.data_root, seed=args.seed)
+        data = LoadData(args.dataset, args.data_root, seed=args.seed, use_inductive=args.inductive is not None,
+                        inductive_key=args.inductive or "item")
         print(data)
         graph, test_pairs, valid_pairs = data.graph, data.test_data[0], data.valid_data[0]
+        if args.inductive is not None:
+            assert not args.resident, "the resident plan needs contiguous node ids; the inductive graphs are node subsets"
+            ind_kwargs = dict(is_inductive=True, inductive_key=I if args.inductive == "item" else U,
+                              inductive_valid_ids=data.inductive_valid_ids, inductive_train_ids=data.inductive_train_ids)
     else:
         graph, eu, ei, vals = S.make_graph(args.shape, signal=True)
         n = eu.size
@@ -126,8 +136,11 @@ def main():
         n_test, n_valid = int(0.2 * n), int(0.08 * n)
         test_pairs = np.stack([eu[perm[:n_test]], ei[perm[:n_test]]])
         valid_pairs = np.stack([eu[perm[n_test:n_test + n_valid]], ei[perm[n_test:n_test + n_valid]]])
-    it = DataIterator(graph, U, I, test_pairs, valid_pairs, embed_P_mask=0.1, embed_p_zero=0.0, embed_p_self=1.0,
-                      seed=args.seed)
+    # inductive: masked nodes are zeroed (P_ZERO = 1, the reference's inductive yamls), so that a held-out node -- whose
+    # embedding was never trained -- looks to the network like a masked training node
+    p_zero = 1.0 if ind_kwargs else 0.0
+    it = DataIterator(graph, U, I, test_pairs, valid_pairs, embed_P_mask=0.1, embed_p_zero=p_zero, embed_p_self=1.0 - p_zero,
+                      seed=args.seed, **ind_kwargs)
     train_vals = it.train_graph[U, I].values
     mean, std = float(train_vals.mean()), float(train_vals.std())
     lo, hi = float(it.possible_rating_values.min()), float(it.possible_rating_values.max())

@@ -239,6 +239,12 @@ int sg_unique_inverse_cpu(int32_t* uniq, int32_t* inverse, int32_t* counts, int6
 int sg_remove_edges_cpu(int32_t* out_end_points, float* out_values, int32_t* out_ind_ptr, int64_t* new_nnz,
                         const int32_t* end_points, const float* values, const int32_t* ind_ptr, int64_t row_num,
                         const int32_t* rm_rows, const int32_t* rm_cols, int64_t rm_num);
+/* csr_submat / slice_csr_mat  graph_sampler.cpp:31-152 (py_ext.cpp:129-200): rows sel_rows (given order; NULL = all) and
+ * columns with col_map[c] >= 0 (= new column index; NULL = all); surviving entries keep their order inside the row.
+ * Outputs sized for the total length of the selected rows; out_ind_ptr has (sel_num | row_num) + 1 entries. */
+int sg_csr_submat_cpu(int32_t* out_end_points, float* out_values, int32_t* out_ind_ptr, int64_t* out_nnz,
+                      const int32_t* end_points, const float* values, const int32_t* ind_ptr, int64_t row_num,
+                      const int32_t* sel_rows, int64_t sel_num, const int32_t* col_map);
 /* random_sample_fix_neighbor  graph_sampler.cpp:742-779: per selected row all edges (<= neighbor_num of them, or
  * neighbor_num < 0) or neighbor_num positions drawn without replacement; row i's draw depends only on (seed, i)
  * and positions come back in increasing order.  sampled == NULL: only dst_ind_ptr (sel_num+1) is filled. */

@@ -71,6 +71,7 @@ _SIGS = {
     "sg_multilink_fuse_cpu": (_INT, [_P] * 11 + [_I64] * 3),
     "sg_unique_inverse_cpu": (_INT, [_P] * 5 + [_I64, _I64]),
     "sg_remove_edges_cpu": (_INT, [_P] * 7 + [_I64, _P, _P, _I64]),
+    "sg_csr_submat_cpu": (_INT, [_P] * 7 + [_I64, _P, _I64, _P]),
     "sg_sample_fix_neighbor_cpu": (_INT, [_P] * 4 + [_I64, _I64, _c.c_uint64]),
     "sg_gen_row_indices_cpu": (_INT, [_P, _P, _I64, _I64]),
     "sg_edge_positions_cpu": (_INT, [_P] * 3 + [_I64, _P, _P, _I64]),

@@ -224,6 +224,48 @@ SG_API int sg_remove_edges_cpu(int32_t* out_end_points, float* out_values, int32
   return SG_OK;
 }
 
+// slice_csr_mat of the reference (graph_sampler.cpp:31-152): rows `sel_rows` (in the given order; NULL = all rows) and
+// the columns with col_map[c] >= 0 (col_map[c] = new column index; NULL = all columns, unchanged).  Entries of
+// unselected columns are dropped, the remaining ones keep their order inside the row -- so rows are NOT column-sorted
+// any more when col_map is not monotone (the reference has the same property).  The caller sizes the outputs for the
+// total length of the selected rows; *out_nnz entries are used.  Two passes (count, fill), rows in parallel.
+SG_API int sg_csr_submat_cpu(int32_t* out_end_points, float* out_values, int32_t* out_ind_ptr, int64_t* out_nnz,
+                             const int32_t* end_points, const float* values, const int32_t* ind_ptr, int64_t row_num,
+                             const int32_t* sel_rows, int64_t sel_num, const int32_t* col_map) {
+  if (row_num < 0 || sel_num < 0) return fail(SG_ERR_INVALID, "negative dimension");
+  if (!out_ind_ptr || !out_nnz || !ind_ptr) return fail(SG_ERR_INVALID, "null pointer argument");
+  const int64_t n = sel_rows ? sel_num : row_num;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t r = sel_rows ? sel_rows[i] : i;
+    if (r < 0 || r >= row_num) return fail(SG_ERR_VALUE, "row index %lld out of range", static_cast<long long>(r));
+  }
+  out_ind_ptr[0] = 0;
+#pragma omp parallel for schedule(static) num_threads(SG_HOST_THREADS) if (n > SG_OMP_MIN_WORK)
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t r = sel_rows ? sel_rows[i] : i;
+    int32_t cnt = 0;
+    if (!col_map) cnt = ind_ptr[r + 1] - ind_ptr[r];
+    else
+      for (int64_t j = ind_ptr[r]; j < ind_ptr[r + 1]; ++j) cnt += col_map[end_points[j]] >= 0;
+    out_ind_ptr[i + 1] = cnt;
+  }
+  for (int64_t i = 0; i < n; ++i) out_ind_ptr[i + 1] += out_ind_ptr[i];
+  *out_nnz = out_ind_ptr[n];
+#pragma omp parallel for schedule(static) num_threads(SG_HOST_THREADS) if (n > SG_OMP_MIN_WORK)
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t r = sel_rows ? sel_rows[i] : i;
+    int64_t w = out_ind_ptr[i];
+    for (int64_t j = ind_ptr[r]; j < ind_ptr[r + 1]; ++j) {
+      const int32_t c = col_map ? col_map[end_points[j]] : end_points[j];
+      if (c < 0) continue;
+      out_end_points[w] = c;
+      if (values && out_values) out_values[w] = values[j];
+      ++w;
+    }
+  }
+  return SG_OK;
+}
+
 // random_sample_fix_neighbor of the reference (graph_sampler.cpp:742-779): for every selected row keep all of its
 // edges when it has <= neighbor_num of them (or neighbor_num < 0), otherwise draw neighbor_num edge positions
 // uniformly WITHOUT replacement.  Differences by design: the draw of row i depends only on (seed, i) -- the

@@ -158,6 +158,7 @@ class CSRMat(object):
         self._row_map, self._col_map = _IdMap(self.row_ids), _IdMap(self.col_ids)
         self._support = dict()
         self._col_deg = None
+        self._rows_sorted = None
 
     @classmethod
     def from_edges(cls, row_ind, col_ind, values, n_rows, n_cols, row_ids=None, col_ids=None, multi_link=None):
@@ -200,23 +201,84 @@ class CSRMat(object):
         """(2, nnz): row id and column id of every stored edge, in CSR order."""
         return np.stack([self.row_ids[self.edge_row_indices], self.col_ids[self.end_points]], axis=0)
 
+    @property
+    def rows_sorted(self):
+        """True when every row lists its columns in increasing order (what `from_edges`, `.T`, row selection and edge
+        removal give).  `submat` with a non-monotone column selection does not -- the reference's slice_csr_mat keeps
+        the original order inside a row and so does this -- and the binary-search helpers then take the sort-based path."""
+        if self._rows_sorted is None:
+            if self.nnz < 2:
+                self._rows_sorted = True
+            else:
+                inc = self.end_points[1:] > self.end_points[:-1]
+                inc[self.ind_ptr[1:-1][(self.ind_ptr[1:-1] > 0) & (self.ind_ptr[1:-1] < self.nnz)] - 1] = True   # row starts
+                self._rows_sorted = bool(inc.all())
+        return self._rows_sorted
+
+    def _positions(self, r, c):
+        """CSR position of every (row index, col index) pair, -1 where it is not an edge; any order inside the rows."""
+        r, c = _i32(r), _i32(c)
+        pos = np.empty(r.size, np.int32)
+        if self.rows_sorted:
+            L.check(L.lib().sg_edge_positions_cpu(_vp(pos), _vp(self.end_points), _vp(self.ind_ptr), self.shape[0],
+                                                  _vp(r), _vp(c), r.size), "sg_edge_positions_cpu")
+            return pos
+        ncol = max(self.shape[1], 1)
+        key = self.edge_row_indices.astype(np.int64) * ncol + self.end_points
+        order = np.argsort(key, kind="stable")
+        want = r.astype(np.int64) * ncol + c
+        at = np.searchsorted(key[order], want)
+        ok = (r >= 0) & (c >= 0) & (at < key.size)
+        ok[ok] = key[order[at[ok]]] == want[ok]
+        pos[:] = -1
+        pos[ok] = order[at[ok]]
+        return pos
+
     def fetch_edges_by_id(self, node_pair_ids):
         """Edge values of the given (row id, col id) pairs (every pair must exist)."""
-        r = self.row_id_to_ind(node_pair_ids[0]).astype(np.int64)
-        c = self.col_id_to_ind(node_pair_ids[1]).astype(np.int64)
-        key = self.edge_row_indices.astype(np.int64) * self.shape[1] + self.end_points   # sorted: CSR rows are sorted
-        pos = np.searchsorted(key, r * self.shape[1] + c)
-        if np.any(pos >= key.size) or np.any(key[np.minimum(pos, key.size - 1)] != r * self.shape[1] + c):
+        pos = self._positions(self.row_id_to_ind(node_pair_ids[0]), self.col_id_to_ind(node_pair_ids[1]))
+        if np.any(pos < 0):
             raise ValueError("fetch_edges_by_id: some node pairs are not edges of this matrix")
         return self.values[pos]
 
     def edge_positions(self, node_pair_ids):
         """Position in CSR order (= edge id) of every (row id, col id) pair; -1 where the pair is not an edge."""
-        r, c = _i32(self.row_id_to_ind(node_pair_ids[0])), _i32(self.col_id_to_ind(node_pair_ids[1]))
-        pos = np.empty(r.size, np.int32)
-        L.check(L.lib().sg_edge_positions_cpu(_vp(pos), _vp(self.end_points), _vp(self.ind_ptr), self.shape[0], _vp(r),
-                                              _vp(c), r.size), "sg_edge_positions_cpu")
-        return pos
+        return self._positions(self.row_id_to_ind(node_pair_ids[0]), self.col_id_to_ind(node_pair_ids[1]))
+
+    def submat(self, row_indices=None, col_indices=None):
+        """reference graph.py:493-531 -> slice_csr_mat (graph_sampler.cpp:31-152; native: sg_csr_submat_cpu): the rows
+        `row_indices` in the given order and the columns `col_indices`, re-indexed by their position in that list;
+        entries keep their order inside a row.  None = everything."""
+        rows = None if row_indices is None else _i32(np.atleast_1d(row_indices))
+        cols = None if col_indices is None else _i32(np.atleast_1d(col_indices))
+        if rows is None and cols is None:
+            return CSRMat(self.end_points.copy(), self.ind_ptr.copy(), self.row_ids.copy(), self.col_ids.copy(),
+                          self.values.copy(), self.multi_link)
+        col_map = None
+        if cols is not None:
+            if np.unique(cols).size != cols.size:
+                raise ValueError("submat: duplicate column indices")
+            col_map = -np.ones(self.shape[1], np.int32)
+            col_map[cols] = np.arange(cols.size, dtype=np.int32)
+        n = self.shape[0] if rows is None else rows.size
+        bound = self.nnz if rows is None else int((self.ind_ptr[rows + 1] - self.ind_ptr[rows]).sum())
+        ep, vals = np.empty(max(bound, 1), np.int32), np.empty(max(bound, 1), np.float32)
+        ind_ptr = np.empty(n + 1, np.int32)
+        m = ctypes.c_int64(0)
+        L.check(L.lib().sg_csr_submat_cpu(_vp(ep), _vp(vals), _vp(ind_ptr), ctypes.byref(m), _vp(self.end_points),
+                                          _vp(self.values), _vp(self.ind_ptr), self.shape[0],
+                                          None if rows is None else _vp(rows), n, None if col_map is None else _vp(col_map)),
+                "sg_csr_submat_cpu")
+        return CSRMat(ep[:m.value], ind_ptr, self.row_ids if rows is None else self.row_ids[rows],
+                      self.col_ids if cols is None else self.col_ids[cols], vals[:m.value], self.multi_link)
+
+    def submat_by_id(self, row_ids=None, col_ids=None):
+        """reference graph.py:535-538"""
+        r = None if row_ids is None else self.row_id_to_ind(np.atleast_1d(row_ids))
+        c = None if col_ids is None else self.col_id_to_ind(np.atleast_1d(col_ids))
+        if (r is not None and np.any(r < 0)) or (c is not None and np.any(c < 0)):
+            raise ValueError("submat_by_id: unknown row / column id")
+        return self.submat(r, c)
 
     def row_id_to_ind(self, ids):
         return self._row_map[ids]
@@ -304,9 +366,18 @@ class CSRMat(object):
         vals = np.empty(max(self.nnz, 1), np.float32)
         ind_ptr = np.empty(self.shape[0] + 1, np.int32)
         m = ctypes.c_int64(0)
-        L.check(L.lib().sg_remove_edges_cpu(_vp(ep), _vp(vals), _vp(ind_ptr), ctypes.byref(m), _vp(self.end_points),
-                                            _vp(self.values), _vp(self.ind_ptr), self.shape[0], _vp(r), _vp(c), r.size),
-                "sg_remove_edges_cpu")
+        if self.rows_sorted:
+            L.check(L.lib().sg_remove_edges_cpu(_vp(ep), _vp(vals), _vp(ind_ptr), ctypes.byref(m), _vp(self.end_points),
+                                                _vp(self.values), _vp(self.ind_ptr), self.shape[0], _vp(r), _vp(c),
+                                                r.size), "sg_remove_edges_cpu")
+        else:       # rows in slice order (after a column-permuting `submat`): positions by the sort-based lookup
+            hit = self._positions(r, c)
+            keep = np.ones(self.nnz, bool)
+            keep[hit[hit >= 0]] = False
+            m.value = int(keep.sum())
+            ep[:m.value], vals[:m.value] = self.end_points[keep], self.values[keep]
+            ind_ptr[0] = 0
+            np.cumsum(np.bincount(self.edge_row_indices[keep], minlength=self.shape[0]), out=ind_ptr[1:])
         sup_rd, sup_cd = self._sup_rd, self._sup_cd
         if sup_rd is not None or sup_cd is not None:
             if degree_reducer is None:
@@ -368,6 +439,29 @@ class HeterGraph(object):
 
     def fetch_edges_by_id(self, src_key, dst_key, node_pair_ids):
         return self.csr_mat_dict[(src_key, dst_key)].fetch_edges_by_id(np.asarray(node_pair_ids))
+
+    def node_id_to_ind(self, key, node_ids):
+        return _IdMap(self.node_ids_dict[key])[node_ids]
+
+    def sel_subgraph_by_id(self, key, node_ids):
+        """reference graph.py:1001-1030: the graph restricted to the nodes `node_ids` of type `key` (the inductive
+        setting trains on the graph of the training nodes only): rows of every (key, other) matrix and columns of every
+        (other, key) matrix are selected, in the order of `node_ids`; the other node types keep all their nodes."""
+        node_ids = _i32(node_ids)
+        new = dict(self.csr_mat_dict)
+        for (a, b), m in self.csr_mat_dict.items():
+            if a == key and b == key:
+                new[(a, b)] = m.submat_by_id(row_ids=node_ids, col_ids=node_ids)
+            elif a == key:
+                new[(a, b)] = m.submat_by_id(row_ids=node_ids)
+            elif b == key:
+                new[(a, b)] = m.submat_by_id(col_ids=node_ids)
+        ids = dict(self.node_ids_dict)
+        ids[key] = node_ids
+        fea = dict(self.features)
+        if fea.get(key) is not None:
+            fea[key] = np.take(np.asarray(fea[key]), self.node_id_to_ind(key, node_ids), axis=0)
+        return HeterGraph(ids, new, fea)
 
     def check_continous_node_ids(self):
         for key, ids in self.node_ids_dict.items():

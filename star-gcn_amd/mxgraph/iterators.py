@@ -1,23 +1,34 @@
-"""Mini-batch samplers that feed the hot path: the transductive part of reference mxgraph/iterators.py
-(`DataIterator` :120-236, `rating_sampler` :264-307, `recon_nodes_sampler` :309-370).  Host-side numpy only.
+"""Mini-batch samplers that feed the hot path: reference mxgraph/iterators.py (`DataIterator` :120-236 in both the
+transductive and the inductive setting, `rating_sampler` :264-307, `recon_nodes_sampler` :309-370).  Host-side numpy only.
 
 The embedding-noise convention is the reference's (iterators.py:338-346): `embed_noise[key]` has one entry per node
 of the whole graph; -1 masks the node's input embedding to zero, i keeps (or substitutes) embedding i.  Nodes picked
 for reconstruction get -1 with probability `embed_p_zero` and their own id otherwise; nodes that are not training
-candidates stay -1.  The inductive split and the unused negative-edge generator are out of scope.
+candidates stay -1 -- in the inductive setting those are the held-out nodes, which the network therefore sees with a
+zero input embedding and has to reconstruct from their neighbourhood.  The unused negative-edge generator
+(iterators.py:8-111) is out of scope.
 """
 import numpy as np
 
 
 class DataIterator(object):
     def __init__(self, all_graph, name_user, name_item, test_node_pairs, valid_node_pairs, embed_P_mask=0.1,
-                 embed_p_zero=0.0, embed_p_self=1.0, seed=None):
+                 embed_p_zero=0.0, embed_p_self=1.0, seed=None, is_inductive=False, inductive_key=None,
+                 inductive_valid_ids=None, inductive_train_ids=None):
         self._rng = np.random.RandomState(seed=seed)
         self._all_graph, self._name_user, self._name_item = all_graph, name_user, name_item
-        # test graph: test ratings removed; val/train graph: validation ratings removed too (reference :165-170)
+        self._is_inductive = bool(is_inductive)
+        # test graph: test ratings removed (reference :165)
         self._test_graph = all_graph.remove_edges_by_id(name_user, name_item, test_node_pairs)
-        self._val_graph = self._test_graph.remove_edges_by_id(name_user, name_item, valid_node_pairs)
-        self._train_graph = self._val_graph
+        if not is_inductive:    # val/train graph: validation ratings removed too (reference :168-170)
+            self._val_graph = self._test_graph.remove_edges_by_id(name_user, name_item, valid_node_pairs)
+            self._train_graph = self._val_graph
+        else:                   # reference :171-176: graphs of the train (+ validation) NODES of `inductive_key`
+            assert inductive_key is not None and inductive_train_ids is not None and inductive_valid_ids is not None
+            train_val_ids = np.concatenate((inductive_train_ids, inductive_valid_ids)).astype(np.int32)
+            self._val_graph = all_graph.sel_subgraph_by_id(inductive_key, train_val_ids) \
+                .remove_edges_by_id(name_user, name_item, valid_node_pairs)
+            self._train_graph = all_graph.sel_subgraph_by_id(inductive_key, inductive_train_ids)
         self._test_node_pairs, self._valid_node_pairs = np.asarray(test_node_pairs), np.asarray(valid_node_pairs)
         csr = self._train_graph[name_user, name_item]
         self._train_node_pairs, self._train_ratings = csr.node_pair_ids, csr.values
@@ -36,6 +47,7 @@ class DataIterator(object):
 
     possible_rating_values = property(lambda self: self._all_graph[self._name_user, self._name_item].multi_link)
     evaluate_embed_noise_dict = property(lambda self: self._evaluate_embed_noise_dict)
+    is_inductive = property(lambda self: self._is_inductive)
     all_graph = property(lambda self: self._all_graph)
     test_graph = property(lambda self: self._test_graph)
     val_graph = property(lambda self: self._val_graph)

@@ -94,6 +94,25 @@ class Primitives(object):
     def take_1d_omp(data, sel):
         return np.take(data, sel)
 
+    @staticmethod
+    def csr_submat(end_points, values, ind_ptr, row_ids, col_ids, row_indices, col_indices):   # graph_sampler.cpp:31-152
+        rows = np.arange(ind_ptr.size - 1) if row_indices is None else np.asarray(row_indices)
+        cmap = None if col_indices is None else {int(c): k for k, c in enumerate(col_indices)}
+        ep, va, ip = [], [], [0]
+        for r in rows:
+            for j in range(ind_ptr[r], ind_ptr[r + 1]):
+                c = int(end_points[j])
+                if cmap is None:
+                    ep.append(c)
+                    va.append(values[j])
+                elif c in cmap:
+                    ep.append(cmap[c])
+                    va.append(values[j])
+            ip.append(len(ep))
+        return (np.array(ep, np.int32), np.array(va, np.float32), np.array(ip, np.int32),
+                np.asarray(row_ids)[rows].astype(np.int32),
+                (np.asarray(col_ids) if col_indices is None else np.asarray(col_ids)[np.asarray(col_indices)]).astype(np.int32))
+
 
 def load_reference():
     def keep(node):
@@ -267,6 +286,65 @@ def main():
                         "it_ns%d_all_%s" % (k, key): allr[key]})
     vs = list(it.rating_sampler(batch_size=10, segment="valid"))
     out["it_valid_batches"] = np.array([p.shape[1] for p, _ in vs], np.int32)
+
+    # ---- sub-matrices / sub-graphs and the INDUCTIVE DataIterator (graph.py:493-538, 1001-1030; iterators.py:171-176).
+    # Appended after everything else and drawn from its own generator, so the vectors above do not move. -----------
+    rng2 = np.random.default_rng(2024)
+    um = graph["user", "movie"]
+    sub_rows = rng2.permutation(n_user)[:11].astype(np.int32)
+    sub_cols = rng2.permutation(n_item)[:9].astype(np.int32)
+    out.update(sm_rows=sub_rows, sm_cols=sub_cols)
+    for tag, kw in (("sm_r_", dict(row_ids=sub_rows)), ("sm_c_", dict(col_ids=sub_cols)),
+                    ("sm_rc_", dict(row_ids=sub_rows, col_ids=sub_cols))):
+        m = um.submat_by_id(**kw)
+        out.update({tag + "ep": m.end_points, tag + "ip": m.ind_ptr, tag + "val": m.values, tag + "rid": m.row_ids,
+                    tag + "cid": m.col_ids})
+    # inductive split over the items: every item is a train, validation or test node
+    perm = rng2.permutation(n_item).astype(np.int32)
+    test_ids, valid_ids, train_ids = perm[:4], perm[4:8], perm[8:]
+    mu = graph["movie", "user"]
+
+    def held_out_pairs(ids, frac):
+        cols = []
+        for i in ids:
+            p = mu.submat_by_id(row_ids=np.array([i], np.int32)).node_pair_ids            # (movie, user) pairs
+            take = rng2.permutation(p.shape[1])[:max(1, int(p.shape[1] * frac))]
+            cols.append(np.stack([p[1, take], p[0, take]]))                                # -> (user, movie)
+        return np.hstack(cols).astype(np.int32)
+
+    ind_test_pairs, ind_valid_pairs = held_out_pairs(test_ids, 0.8), held_out_pairs(valid_ids, 0.8)
+    out.update(ind_test_ids=test_ids, ind_valid_ids=valid_ids, ind_train_ids=train_ids, ind_test_pairs=ind_test_pairs,
+               ind_valid_pairs=ind_valid_pairs)
+    sg = graph.sel_subgraph_by_id("movie", train_ids)
+    for tag, m in (("sg_um_", sg["user", "movie"]), ("sg_mu_", sg["movie", "user"])):
+        out.update({tag + "ep": m.end_points, tag + "ip": m.ind_ptr, tag + "val": m.values, tag + "rid": m.row_ids,
+                    tag + "cid": m.col_ids, tag + "sup": m.get_support(True)})
+    it2 = ref_it["DataIterator"](graph, "user", "movie", is_inductive=True, test_node_pairs=ind_test_pairs,
+                                 valid_node_pairs=ind_valid_pairs, inductive_key="movie",
+                                 inductive_valid_ids=valid_ids, inductive_train_ids=train_ids,
+                                 embed_P_mask=0.3, embed_p_zero=0.5, embed_p_self=0.5, seed=321)
+    for tag, g_ in (("ind_train_", it2.train_graph), ("ind_val_", it2.val_graph), ("ind_test_", it2.test_graph)):
+        for d, m in (("um_", g_["user", "movie"]), ("mu_", g_["movie", "user"])):
+            out.update({tag + d + "ep": m.end_points, tag + d + "ip": m.ind_ptr, tag + d + "val": m.values,
+                        tag + d + "rid": m.row_ids, tag + d + "cid": m.col_ids})
+    out.update(ind_train_pairs=it2._train_node_pairs, ind_train_ratings=it2._train_ratings,
+               ind_valid_ratings=it2._valid_ratings, ind_test_ratings=it2._test_ratings,
+               ind_eval_noise_user=it2.evaluate_embed_noise_dict["user"],
+               ind_eval_noise_movie=it2.evaluate_embed_noise_dict["movie"])
+    rs2 = it2.rating_sampler(batch_size=20, segment="train")
+    for k in range(2):
+        p, r = next(rs2)
+        out.update({"ind_rs%d_pairs" % k: p, "ind_rs%d_ratings" % k: r})
+    ns2 = it2.recon_nodes_sampler(batch_size=3)
+    for k in range(2):
+        noise, batch, allr = next(ns2)
+        for key in ("user", "movie"):
+            out.update({"ind_ns%d_noise_%s" % (k, key): noise[key], "ind_ns%d_batch_%s" % (k, key): batch[key],
+                        "ind_ns%d_all_%s" % (k, key): allr[key]})
+    # full-neighbourhood plan arrays of the inductive train graph (unsorted rows of the column-selected direction)
+    eps, vs_, ips, sps = it2.train_graph["user", "movie"].sample_neighbors(None, True, True, -1)
+    for l in range(len(levels)):
+        out.update({"ind_nb_ep%d" % l: eps[l], "ind_nb_ip%d" % l: ips[l], "ind_nb_sup%d" % l: sps[l]})
 
     np.savez_compressed(OUT, **{k: np.asarray(v) for k, v in out.items()})
     print("wrote %s: %d arrays, %d bytes" % (OUT, len(out), os.path.getsize(OUT)))

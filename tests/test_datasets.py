@@ -265,3 +265,38 @@ def test_training_from_a_movielens_directory(tmp_path):
     rmse = [float(x) for x in re.findall(r"valid RMSE ([0-9.]+)", out.stdout)]
     assert len(rmse) >= 3 and rmse[-1] < rmse[0] - 0.05, out.stdout
     assert re.search(r"test RMSE [0-9.]+", out.stdout)
+
+
+@pytest.mark.gpu
+def test_inductive_training_from_a_movielens_directory(tmp_path):
+    """The inductive setting end to end (reference datasets.py:153-171 + iterators.py:171-176): held-out ITEMS never
+    appear in the training graph, are evaluated with a zero input embedding through the graph that contains them, and the
+    model still predicts their ratings better than the rating mean (it reconstructs them from their neighbourhood)."""
+    import re
+    import subprocess
+    import sys
+    rng = np.random.default_rng(1)
+    nu, nm, n = 500, 300, 30000
+    pu, pm = rng.normal(size=(nu, 3)), rng.normal(size=(nm, 3))
+    cells = rng.choice(nu * nm, n, replace=False)
+    u, m = cells // nm, cells % nm
+    score = (pu[u] * pm[m]).sum(1)
+    r = np.clip(np.round(3 + 1.2 * score / score.std()), 1, 5).astype(int)
+    d = tmp_path / "ml-1m"
+    d.mkdir()
+    with open(d / "ratings.dat", "w") as f:
+        f.writelines("%d::%d::%d::1\n" % (a + 1, b + 1, c) for a, b, c in zip(u, m, r))
+    with open(d / "users.dat", "w") as f:
+        f.writelines("%d::%s::%d::%d::00000\n" % (i + 1, "FM"[i % 2], 25, i % 21) for i in range(nu))
+    with open(d / "movies.dat", "w") as f:
+        f.writelines("%d::Film %d (1999)::Drama\n" % (i + 1, i) for i in range(nm))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "train_star_gcn.py"), "--data-root", str(tmp_path),
+                          "--dataset", "ml-1m", "--inductive", "item", "--iters", "200", "--eval-every", "100", "--batch",
+                          "3000"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Inductive (movie)" in out.stdout
+    rmse = [float(x) for x in re.findall(r"valid RMSE ([0-9.]+)", out.stdout)]
+    test = float(re.search(r"test RMSE ([0-9.]+)", out.stdout).group(1))
+    assert len(rmse) >= 3 and rmse[-1] < rmse[0] - 0.03, out.stdout
+    assert test < float(np.std(r)) * 0.97, (test, float(np.std(r)))

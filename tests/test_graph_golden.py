@@ -160,3 +160,70 @@ def test_gen_plan_matches_reference_gen_plan():
                     eq("gp%d_%s_%s_ip%d" % (depth, key, dst_key, l), ip)
                     eq("gp%d_%s_%s_ep%d" % (depth, key, dst_key, l), c_idx[pos])
                     eq("gp%d_%s_%s_sup%d" % (depth, key, dst_key, l), c_w[pos])
+
+
+def _check_mat(prefix, m, support=False):
+    eq(prefix + "ep", m.end_points)
+    eq(prefix + "ip", m.ind_ptr)
+    eq(prefix + "val", m.values)
+    eq(prefix + "rid", m.row_ids)
+    eq(prefix + "cid", m.col_ids)
+    if support:
+        eq(prefix + "sup", m.get_support(True))
+
+
+def test_submat_and_subgraph_match_reference():
+    """CSRMat.submat_by_id (graph.py:493-538 -> slice_csr_mat, graph_sampler.cpp:31-152: rows in selection order, columns
+    re-indexed by their position in the selection, entries in their original order inside a row) and
+    HeterGraph.sel_subgraph_by_id (graph.py:1001-1030)."""
+    g = build()
+    um = g[U, I]
+    _check_mat("sm_r_", um.submat_by_id(row_ids=GOLD["sm_rows"]))
+    c = um.submat_by_id(col_ids=GOLD["sm_cols"])
+    _check_mat("sm_c_", c)
+    assert not c.rows_sorted                       # a permuted column selection leaves slice order inside the rows
+    _check_mat("sm_rc_", um.submat_by_id(row_ids=GOLD["sm_rows"], col_ids=GOLD["sm_cols"]))
+    sg = g.sel_subgraph_by_id(I, GOLD["ind_train_ids"])
+    _check_mat("sg_um_", sg[U, I], support=True)
+    _check_mat("sg_mu_", sg[I, U], support=True)
+    with pytest.raises(ValueError):
+        um.submat_by_id(col_ids=np.array([10 ** 6], np.int32))
+
+
+def test_inductive_data_iterator_matches_reference():
+    """DataIterator(is_inductive=True) (iterators.py:171-176): train / validation graphs are the sub-graphs of the train
+    (+ validation) items, held-out items get noise -1 at evaluation, samplers walk the same RNG sequence; the per-level
+    neighbour lists of the train graph (column-selected direction, unsorted rows) feed the plan unchanged."""
+    g = build()
+    it = DataIterator(g, U, I, test_node_pairs=GOLD["ind_test_pairs"], valid_node_pairs=GOLD["ind_valid_pairs"],
+                      embed_P_mask=0.3, embed_p_zero=0.5, embed_p_self=0.5, seed=321, is_inductive=True, inductive_key=I,
+                      inductive_valid_ids=GOLD["ind_valid_ids"], inductive_train_ids=GOLD["ind_train_ids"])
+    assert it.is_inductive
+    for tag, g_ in (("ind_train_", it.train_graph), ("ind_val_", it.val_graph), ("ind_test_", it.test_graph)):
+        _check_mat(tag + "um_", g_[U, I])
+        _check_mat(tag + "mu_", g_[I, U])
+    eq("ind_train_pairs", it._train_node_pairs)
+    eq("ind_train_ratings", it._train_ratings)
+    eq("ind_valid_ratings", it._valid_ratings)
+    eq("ind_test_ratings", it._test_ratings)
+    eq("ind_eval_noise_user", it.evaluate_embed_noise_dict[U])
+    eq("ind_eval_noise_movie", it.evaluate_embed_noise_dict[I])
+    held_out = np.concatenate([GOLD["ind_test_ids"], GOLD["ind_valid_ids"]])
+    assert np.all(it.evaluate_embed_noise_dict[I][held_out] == -1)
+    rs = it.rating_sampler(batch_size=20, segment="train")
+    for k in range(2):
+        p, r = next(rs)
+        eq("ind_rs%d_pairs" % k, p)
+        eq("ind_rs%d_ratings" % k, r)
+    ns = it.recon_nodes_sampler(batch_size=3)
+    for k in range(2):
+        noise, batch, allr = next(ns)
+        for key in (U, I):
+            eq("ind_ns%d_noise_%s" % (k, key), noise[key])
+            eq("ind_ns%d_batch_%s" % (k, key), batch[key])
+            eq("ind_ns%d_all_%s" % (k, key), allr[key])
+    eps, _, ips, sps = it.train_graph[U, I].sample_neighbors(None, True, True, -1)
+    for l in range(GOLD["g_levels"].size):
+        eq("ind_nb_ep%d" % l, eps[l])
+        eq("ind_nb_ip%d" % l, ips[l])
+        eq("ind_nb_sup%d" % l, sps[l])
