@@ -90,3 +90,100 @@ def test_bench_under_torch_distributed_run():
     one = _bench([], {})
     assert two["n_gpus"] == 2 and two["collectives"]["rccl_ranks"] == 2
     assert abs(one["config"]["loss"] - two["config"]["loss"]) <= 1e-5 * max(1.0, abs(one["config"]["loss"]))
+
+
+def _config5_union_worker(rank, world, port, shape, dim, result_path):
+    """Rank r: the config-5 construction of bench.run_config5 (own user block, item degrees summed over the ranks, partitioned
+    network).  Rank 0 then rebuilds the SAME problem as one graph -- the blocks stacked -- without any partition and compares."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import bench
+    import star_gcn_amd.dist as SD
+    import star_gcn_amd.functional as SF
+    import star_gcn_amd.model as M
+    from star_gcn_amd.device_graph import DeviceBipartite, synthetic_device_graph
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nu, ni, ne, R = shape
+    dg = synthetic_device_graph(nu, ni, ne, R, dev, seed=5 + rank, item_seed=5)
+    deg = dg.item_degrees.cpu()
+    dist.all_reduce(deg)
+    dgp = dg.with_item_degrees(deg.to(dev))
+    vals = dg.values()
+    blocks = [None] * world
+    dist.all_gather_object(blocks, (dg.ind_ptr.cpu().numpy(), dg.end_points.cpu().numpy(), dg.level.cpu().numpy(),
+                                    vals.cpu().numpy()))
+    allv = np.concatenate([b[3] for b in blocks])
+    mean, std, E = float(allv.mean()), float(allv.std(ddof=1)), int(allv.size)
+
+    def loss_and_grads(graph_like, y, part, rows):
+        torch.manual_seed(1234)
+        net = bench.build_net(graph_like, dim, "auto", dev, part)
+        plan = net.make_plan_device(graph_like)
+
+        def step():
+            net.zero_grad(set_to_none=True)
+            preds, _, _ = net.run(plan)
+            loss = SF.l2_loss(preds[0].view(-1), y, 1.0 / E)
+            loss.backward()
+            return loss
+        step()
+        M.deterministic_init(net, 1234, {bench.U: (0, rows, rows), bench.I: (0, ni, ni)})
+        return net, step()
+
+    y = ((vals - mean) / std).contiguous()
+    net, loss = loss_and_grads(dgp, y, SD.NodePartition([bench.U], [bench.I]), nu)
+    SD.allreduce_grads(net.local_region_parameters())
+    total = SD.all_reduce_sum(loss.detach().view(1))[0]
+    if rank == 0:
+        ip = np.concatenate([[0]] + [b[0][1:] + sum(int(c[0][-1]) for c in blocks[:k]) for k, b in enumerate(blocks)])
+        union = DeviceBipartite(torch.from_numpy(ip.astype(np.int32)).to(dev),
+                                torch.from_numpy(np.concatenate([b[1] for b in blocks])).to(dev),
+                                torch.from_numpy(np.concatenate([b[2] for b in blocks])).to(dev), ni, dg.multi_link)
+        yu = torch.from_numpy(((allv - mean) / std).astype(np.float32)).to(dev)
+        torch.manual_seed(1234)
+        ref = bench.build_net(union, dim, "auto", dev, None)
+        plan = ref.make_plan_device(union)
+
+        def rstep():
+            ref.zero_grad(set_to_none=True)
+            preds, _, _ = ref.run(plan)
+            loss = SF.l2_loss(preds[0].view(-1), yu, 1.0 / E)
+            loss.backward()
+            return loss
+        rstep()
+        M.deterministic_init(ref, 1234, {bench.I: (0, ni, ni)})
+        ukey = "embed_layers._layers.%d.weight" % ref.embed_layers._key2idx[bench.U]
+        with torch.no_grad():       # every rank holds the same user table (run_config5): the union table stacks it
+            dict(ref.named_parameters())[ukey].copy_(dict(net.named_parameters())[ukey].repeat(world, 1))
+        rl = rstep()
+        errs = dict()
+        for k, p in net.named_parameters():
+            g = dict(ref.named_parameters())[k].grad
+            g = g[:nu] if k == ukey else g
+            errs[k] = (float((p.grad - g).abs().max()), float(g.abs().max()))
+        torch.save({"loss": float(total), "ref_loss": float(rl), "errs": errs}, result_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config5_blocks_equal_the_union_graph(tmp_path):
+    """The N-rank config-5 construction (one generated block per rank, item degrees summed over the ranks, item-side
+    partials all-reduced) computes the loss and the gradients of the ONE graph that stacks the blocks."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = str(tmp_path / "r.pt")
+    mp.spawn(_config5_union_worker, args=(2, port, (2500, 1800, 50000, 4), 64, res), nprocs=2, join=True)
+    r = torch.load(res)
+    assert abs(r["loss"] - r["ref_loss"]) <= 1e-5 * max(1.0, abs(r["ref_loss"])), r
+    worst = max(e / max(sc, 1e-30) for e, sc in r["errs"].values())
+    assert worst <= 2e-4, {k: v for k, v in r["errs"].items() if v[0] > 2e-4 * v[1]}
