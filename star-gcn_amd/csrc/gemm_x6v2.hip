@@ -45,7 +45,8 @@ struct GemmArgs {   // must match gemm_f32.hip
 #define SG_X6V2_NT_STORE 1    // C tiles are written once and never re-read by this kernel: stream them past the caches
 #endif
 #ifndef SG_X6V2_ABLATE
-#define SG_X6V2_ABLATE 0      // development: 1 producers skip split + LDS stores, 2 consumers skip MFMAs, 3 consumers skip LDS reads
+#define SG_X6V2_ABLATE 0      // development: 1 producers skip split + LDS stores, 2 consumers skip MFMAs, 3 consumers skip LDS reads,
+                              // 4 two planes and three products per K step (cost model of a 3-product split scheme)
 #endif
 
 #ifndef SG_X6V2_TIMING
@@ -132,7 +133,9 @@ __device__ __forceinline__ void sstore_kc(char* __restrict__ s, float (&v)[16], 
     char* d = s + (rr + 32 * i) * ROWB + kc * 2;
     *reinterpret_cast<uint2*>(d) = make_uint2(a1, b1);
     *reinterpret_cast<uint2*>(d + PLANE) = make_uint2(a2, b2);
+#if SG_X6V2_ABLATE != 4
     *reinterpret_cast<uint2*>(d + 2 * PLANE) = make_uint2(a3, b3);
+#endif
   }
 }
 // row-contiguous operand (element (k,c) at p[k*ld + c]): thread pt holds tile row c = pt % 128, k = 16 (pt/128) + i -> v[i]
@@ -158,7 +161,9 @@ __device__ __forceinline__ void sstore_rc(char* __restrict__ s, float (&v)[16], 
     }
     *reinterpret_cast<uint4*>(d + 16 * h) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
     *reinterpret_cast<uint4*>(d + 16 * h + PLANE) = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+#if SG_X6V2_ABLATE != 4
     *reinterpret_cast<uint4*>(d + 16 * h + 2 * PLANE) = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+#endif
   }
 }
 
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
+          for (int p = 0; p < (SG_X6V2_ABLATE == 4 ? 2 : 3); ++p) {
 #if SG_X6V2_ABLATE != 3
             a[i][p] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 32 * ROWB + p * PLANE + ks * 32);
             b[i][p] = *reinterpret_cast<const bf16x8*>(st + b_off + i * 32 * ROWB + p * PLANE + ks * 32);
@@ -267,7 +272,21 @@ __global__ __launch_bounds__(kThreads) void gemm_x6v2_kernel(const GemmArgs g, i
           }
         // plane pairs ordered smallest terms first; the four accumulators interleave so that consecutive MFMAs never
         // depend on each other
-#if SG_X6V2_ABLATE != 2
+#if SG_X6V2_ABLATE == 4
+#pragma unroll
+        for (int term = 3; term < 5; ++term) {     // a1 b2, a2 b1
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kPA[term]], b[j][kPB[term]], accs[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+#elif SG_X6V2_ABLATE != 2
 #pragma unroll
         for (int term = 0; term < 5; ++term) {     // corrections, smallest first
 #pragma unroll

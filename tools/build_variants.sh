@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../star-gcn_amd/csrc"
 make -j8 > /dev/null
 OBJS="seg_gather.o seg_ops.o gemm_f32.o gemm_bf16x6.o multilink.o edge_mask.o embed.o plan_build.o graph_host.o"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fopenmp"
-for v in 1 2 3 t; do
+for v in 1 2 3 4 t; do
   mkdir -p ../../tools/ablate/$v
   if [ $v = t ]; then D="-DSG_X6V2_TIMING=1"; else D="-DSG_X6V2_ABLATE=$v"; fi
   /opt/rocm/bin/hipcc $FLAGS $D -c gemm_x6v2.hip -o /tmp/gemm_x6v2_$v.o

@@ -14,7 +14,8 @@ for (M, N, K, tb) in [(4096, 4096, 4096, True), (262144, 4096, 256, True), (2621
     print("  M=%%7d N=%%5d K=%%5d tb=%%d  %%8.3f ms  %%6.1f TF/s-equiv" %% (M, N, K, tb, t * 1e3, 2.0 * M * N * K / t / 1e12), flush=True)
 ''' % ROOT
 for name, lib in (("full kernel", None), ("1: producers load only (no split, no LDS stores)", "1"), ("2: consumers read LDS only (no MFMA)", "2"),
-                  ("3: consumers MFMA only (no LDS reads)", "3")):
+                  ("3: consumers MFMA only (no LDS reads)", "3"),
+                  ("4: two planes, three products per K step (cost model of a 3-product split scheme)", "4")):
     env = dict(os.environ)
     if lib:
         env["SG_LIB_OVERRIDE"] = os.path.join(ROOT, "tools", "ablate", lib, "libstargcn_hip.so")
