@@ -210,7 +210,8 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
   __shared__ int32_t s_ptr[kPtrTile + 1];
 
   const int lane = threadIdx.x;
-  // Column slicing (n_slices in {2,4,8}): workgroup x runs on XCD x % 8 (round-robin dispatch), and XCD i only ever
+  // Column slicing (n_slices in {2,4,8}): workgroup x runs on XCD x % 8 (round-robin dispatch of the default SPX partition
+  // mode; a locality assumption only -- results do not depend on it), and XCD i only ever
   // touches the 4*Cs-byte column slice (i % n_slices) of every source row, so its private 4 MB L2 faces a working set
   // n_slices times smaller than the source matrix.  The 8 / n_slices XCDs that share a slice split the chunks.
   int k = blockIdx.x, slice = 0;
