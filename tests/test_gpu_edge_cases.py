@@ -173,3 +173,30 @@ def test_take_k_corr_chunk_staging(C):
     ops.seg_take_k_corr(dev(e1), dev(e2), dev(ids), dev(indptr), out=acc, req=ops.REQ_ADD)
     close(acc[:, :E], prev[:, :E] + ref[:, :E], 2e-5)
     assert np.array_equal(acc[:, E:].cpu().numpy(), prev[:, E:])
+
+
+@pytest.mark.parametrize("S", [3, 40, 150, 700, 3000])          # average segment length 1000 ... 1: every lane-group width
+@pytest.mark.parametrize("B", [1, 2])
+def test_lane_group_kernels_for_every_segment_length(S, B):
+    """seg_sum / seg_softmax (fwd, bwd) / seg_broadcast pick 4 ... 64 lanes per segment from the average segment length,
+    and seg_broadcast stages segment ids per 256-position chunk: all widths, empty segments, padding past indptr[-1]."""
+    from star_gcn_amd import contrib, ops
+    rng = np.random.default_rng(S * 7 + B)
+    nnz, pad = 3000, 77
+    lens = rng.multinomial(nnz, rng.dirichlet(np.ones(S) * 0.5))
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    d = rng.normal(size=(B, nnz + pad)).astype(np.float32)
+    dd, di = dev(d), dev(indptr)
+    close(ops.seg_sum(dd, di), O.seg_sum(d, indptr), 2e-5)
+    sm = ops.seg_softmax(dd, di)
+    ref_sm = O.seg_softmax(d, indptr)
+    close(sm, ref_sm, 2e-6)
+    assert float(sm[:, nnz:].abs().max()) == 0.0
+    og = rng.normal(size=(B, nnz + pad)).astype(np.float32)
+    close(ops.seg_softmax_bwd(dev(og), sm, di), O.seg_softmax_bwd(og, ref_sm, indptr), 2e-5)
+    rhs = rng.normal(size=(B, S)).astype(np.float32)
+    for op, name in ((0, "add"), (1, "mul"), (2, "to")):
+        got = ops.seg_broadcast(dd if op < 2 else None, dev(rhs), di, op, nnz=nnz + pad)
+        want = getattr(O, "seg_broadcast_" + name)(*((d, rhs, indptr) if op < 2 else (rhs, indptr, nnz + pad)))
+        close(got[:, :nnz], want[:, :nnz], 1e-6)
+        assert float(got[:, nnz:].abs().max()) == 0.0
