@@ -121,6 +121,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-hbm-leg", action="store_true")
     p.add_argument("--no-ceiling", action="store_true")
+    p.add_argument("--graph-replay", action="store_true",
+                   help="also time the step as ONE hipGraph replay (secondary figure `graph_replay`; opt-in: stream capture of "
+                        "an autograd step depends on the torch build)")
     p.add_argument("--hbm-only", action="store_true", help="run only the HBM-bound leg (profiling)")
     p.add_argument("--hbm-steps", type=int, default=3)
     p.add_argument("--hbm-shape", default="1250000,1000000,125000000,16",
@@ -200,6 +203,31 @@ def timed_steps(step, steps, warmup, dev, dist_on):
     ops.gather_profile(False)
     SD.STATS.enabled = False
     return elapsed, loss, ops.gather_profile_read(with_src_bytes=True)
+
+
+def graph_replay(step, dev, steps):
+    """Capture one fwd+bwd step into a hipGraph and time `steps` replays: the step without launch gaps / host work."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss = step()
+    torch.cuda.synchronize()
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": ms, "loss": float(loss.detach()),
+            "note": "same step, one hipGraphLaunch per step; no HIP events inside, so not the headline"}
 
 
 def gather_roofline(timeline, E_local, D, steps):
@@ -574,6 +602,15 @@ def run_rank(args):
                               "collective_ms_per_step": comm["device_ms"] / args.steps,
                               "note": "rank-0 view; device time of the collectives on the communication stream (they "
                                       "overlap compute, so this is not exposed time)"}
+    if world == 1 and not dist_on and args.graph_replay:
+        # secondary figure: the same step as ONE hipGraph replay (the library's launches captured through
+        # torch.cuda.CUDAGraph, as examples/train_star_gcn.py --graph does for the whole training iteration).  Not the
+        # headline: the HIP events that time the gathers for `roofline` cannot live inside a captured graph.
+        try:
+            del loss                  # the last step's autograd graph (and its AccumulateGrad nodes) must be gone
+            out["graph_replay"] = graph_replay(step, dev, args.steps)
+        except Exception as e:      # capture support is a property of the torch build, not of the path
+            out["graph_replay"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     # free the main leg before the big one
     del net, plan, dgraph, y
     torch.cuda.empty_cache()

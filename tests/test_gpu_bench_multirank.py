@@ -187,3 +187,11 @@ def test_config5_blocks_equal_the_union_graph(tmp_path):
     assert abs(r["loss"] - r["ref_loss"]) <= 1e-5 * max(1.0, abs(r["ref_loss"])), r
     worst = max(e / max(sc, 1e-30) for e, sc in r["errs"].values())
     assert worst <= 2e-4, {k: v for k, v in r["errs"].items() if v[0] > 2e-4 * v[1]}
+
+
+def test_bench_step_replays_as_one_hipgraph():
+    """`--graph-replay`: the same fwd+bwd step captured once and replayed (secondary figure of the JSON line)."""
+    r = _bench(["--graph-replay"], {})
+    g = r["graph_replay"]
+    assert "error" not in g, g
+    assert g["ms_per_step"] > 0 and abs(g["loss"] - r["config"]["loss"]) <= 1e-6 * max(1.0, abs(r["config"]["loss"]))
