@@ -479,8 +479,11 @@ def run_rank(args):
     n_user, n_item, E_total, R = csr.shape[0], csr.shape[1], csr.nnz, int(csr.multi_link.size)
     mean, std = float(vals.mean()), float(vals.std())
     lo, hi = 0, n_user
+    # SG_BENCH_EMULATE_WORLD=N (development, one process): run rank 0's share of an N-rank partition through the
+    # partitioned code path -- what ONE rank of the N-GPU strong-scaling run computes per step, without the other ranks
+    emulate = int(os.environ.get("SG_BENCH_EMULATE_WORLD", "0")) if world == 1 else 0
     if dist_on:
-        lo, hi = SD.balanced_row_blocks(csr.ind_ptr, world)[rank]
+        lo, hi = SD.balanced_row_blocks(csr.ind_ptr, emulate if emulate > 1 else world)[rank]
         sub = S.user_block(graph, U, I, lo, hi)       # this rank's users x ALL items, GLOBAL item degrees for the support
         lgraph = HeterGraph({U: np.arange(hi - lo, dtype=np.int32), I: np.arange(n_item, dtype=np.int32)}, {(U, I): sub})
     else:
