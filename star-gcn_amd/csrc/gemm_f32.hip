@@ -520,6 +520,9 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
   g.vecA = (lda % 4 == 0) && aligned(A, 16);
   g.vecB = (ldb % 4 == 0) && aligned(B, 16);
   if (backend == 2 && !x6v2_supported(g, transA != 0, transB != 0)) backend = 0;   // odd K / unaligned operands: exact-fp32 kernel
+  // x6v2 has nothing to amortise its split on when K is one or two tiles (the rating projection's data gradient,
+  // K = 64) or when the whole output is half a tile high (its weight gradient, 64 x 256 x n): tools/exp_small_gemm.py
+  if (backend == 2 && g_backend_override.load(std::memory_order_relaxed) < 0 && (K <= 64 || (transA && M <= 64))) backend = 0;
   const bool use_bx6 = backend == 1, use_v2 = backend == 2;
   if (use_bx6 || use_v2) tm = 128;
   g.tiles_m = static_cast<int>((M + tm - 1) / tm);
