@@ -110,14 +110,26 @@ def dense_level_adjacency(row_ind, col_ind, values, levels, n_rows, n_cols, symm
     return out
 
 
-def dense_star_gcn(tables, noise, adj, blocks, maps, projs, rating_pairs, recon_ids, accum="sum", act="leaky"):
+def dense_star_gcn(tables, noise, adj, blocks, maps, projs, rating_pairs, recon_ids, accum="sum", act="leaky",
+                   features=None, fea_maps=None, recon_fea=False):
     """tables {key: (n, D)}; noise {key: int array or None}; adj {(dst, src): [A_r]};
     blocks[b] = list of layers, layer = {dst: dict(src=..., W=[..], b=[..], ow=, ob=)};
     maps[b] = {key: (w0, b0, w1, b1)} or None; projs[b] = {key: (w, b)};
-    rating_pairs (user_key, item_key, u_idx, i_idx) or None; recon_ids {key: ids} or None."""
+    rating_pairs (user_key, item_key, u_idx, i_idx) or None; recon_ids {key: ids} or None.
+    features {key: (n, F)} + fea_maps {key: (w0, b0, w1, b1)}: MODEL.USE_FEA_PROJ of reference STAR-GCN.py:182-192,
+    405-413 -- the mapped features are concatenated to every block's input (and to the reconstruction target when
+    recon_fea, :364-370; otherwise re-attached after the decoder map, :455-459)."""
     f = ACTS[act]
     x = {k: masked_embed(t, np.arange(t.shape[0]), noise.get(k) if noise else None) for k, t in tables.items()}
     gt = {k: tables[k][torch.as_tensor(np.asarray(v), dtype=torch.long)] for k, v in (recon_ids or {}).items()}
+    fea = None
+    if fea_maps is not None:
+        fea = {k: dense(dense(features[k], fea_maps[k][0], fea_maps[k][1], act), fea_maps[k][2], fea_maps[k][3])
+               for k in tables}
+        x = {k: torch.cat([x[k], fea[k]], dim=1) for k in x}
+        if recon_fea:
+            gt = {k: torch.cat([g, fea[k][torch.as_tensor(np.asarray(recon_ids[k]), dtype=torch.long)]], dim=1)
+                  for k, g in gt.items()}
     preds, recons = [], []
     for b, layers in enumerate(blocks):
         for layer in layers:
@@ -142,4 +154,6 @@ def dense_star_gcn(tables, noise, adj, blocks, maps, projs, rating_pairs, recon_
                                for k, v in recon_ids.items()})
             if b < len(blocks) - 1:
                 x = {k: emap(k, out[k]) for k in out}
+                if fea is not None and not recon_fea:
+                    x = {k: torch.cat([x[k], fea[k]], dim=1) for k in x}
     return preds, recons, gt

@@ -164,10 +164,19 @@ def pair_inner_product(pu, pi, pair_plan):
 class Net(nn.Module):
     def __init__(self, graph, name_user, name_item, embed_units=64, agg_units=(250,), out_units=(75,), nblocks=2,
                  use_dae=True, use_recurrent=False, gcn_recurrent=False, activation="leaky", dropout=0.0,
-                 agg_accum="sum", norm_symm=True, rating_mid_map=64, agg_order="auto"):
+                 agg_accum="sum", norm_symm=True, rating_mid_map=64, agg_order="auto", use_embed=True,
+                 use_fea_proj=False, recon_fea=False, fea_mid_map=16, fea_units=16, features=None):
+        """use_embed / use_fea_proj / recon_fea / fea_*: reference MODEL.USE_EMBED, MODEL.USE_FEA_PROJ, MODEL.RECON_FEA,
+        FEA.MID_MAP, FEA.UNITS (STAR-GCN.py:176-192, 231-234): node features (`features` {key: (n, F)} or
+        graph.features, e.g. datasets.LoadData's) pass through Dense(MID_MAP) - act - Dense(UNITS) and are concatenated
+        to the (masked) embeddings at the input of every block; with recon_fea the decoder reconstructs the
+        concatenation instead.  All shipped yamls leave USE_FEA_PROJ off."""
         super().__init__()
+        assert use_embed or use_fea_proj
+        assert use_embed or not use_dae, "the reconstruction target is the embedding table (STAR-GCN.py:359-363)"
         self._name_user, self._name_item = name_user, name_item
         self._nblocks, self._use_dae, self._use_recurrent = nblocks, use_dae, use_recurrent
+        self._use_embed, self._use_fea_proj, self._recon_fea = use_embed, use_fea_proj, bool(recon_fea and use_fea_proj)
         self._norm_symm = norm_symm
         self._act_name = activation
         self.embed_layers = LayerDictionary()
@@ -189,12 +198,23 @@ class Net(nn.Module):
                 if gcn_recurrent:
                     break
             self.encoders.append(enc)
+        if use_fea_proj:
+            features = features if features is not None else getattr(graph, "features", None)
+            self.fea_mappings = LayerDictionary()
+            for key in graph.node_ids_dict:
+                if features is None or features.get(key) is None:
+                    raise ValueError("use_fea_proj needs node features for %r" % key)
+                fea = torch.as_tensor(np.ascontiguousarray(features[key], dtype=np.float32))
+                assert fea.shape[0] == self._n_nodes[key]
+                self.register_buffer("fea_" + key, fea)
+                self.fea_mappings[key] = nn.Sequential(Dense(fea_mid_map, activation=activation), Dense(fea_units))
         if use_dae:
+            out_emb = embed_units + (fea_units if self._recon_fea else 0)     # STAR-GCN.py:231-234
             self.embed_maps = nn.ModuleList()
             for _ in range(1 if use_recurrent else nblocks):
                 m = LayerDictionary()
                 for key in graph.meta_graph:
-                    m[key] = nn.Sequential(Dense(embed_units, activation=activation), Dense(embed_units))
+                    m[key] = nn.Sequential(Dense(out_emb, activation=activation), Dense(out_emb))
                 self.embed_maps.append(m)
         nproj = 1 if use_recurrent else nblocks
         self.rating_user_projs = nn.ModuleList([Dense(rating_mid_map) for _ in range(nproj)])
@@ -217,6 +237,8 @@ class Net(nn.Module):
             if self._use_dae:
                 for m in self.embed_maps:
                     skip.update(id(p) for p in m[key].parameters())
+            if self._use_fea_proj:      # like the replicated embedding table: every rank already holds the total gradient
+                skip.update(id(p) for p in self.fea_mappings[key].parameters())
         if self._name_item in rep:
             skip.update(id(p) for p in self.rating_item_projs.parameters())
         if self._name_user in rep:
@@ -236,6 +258,17 @@ class Net(nn.Module):
 
     def get_embed(self, embed_plans):
         return {key: SF.take_rows(self.embed_layers[key].weight, p) for key, p in embed_plans.items()}
+
+    def _fea_plan(self, node_ids_dict, device):
+        """features are taken by node id, never masked (reference get_feature, STAR-GCN.py:302-309)"""
+        return {key: TakePlan(np.asarray(ids, np.int32), self._n_nodes[key], device) for key, ids in node_ids_dict.items()}
+
+    def get_feature(self, fea_plans):
+        return {key: self.fea_mappings[key](SF.take_rows(getattr(self, "fea_" + key), p)) for key, p in fea_plans.items()}
+
+    @staticmethod
+    def _concat(a, b):
+        return {key: torch.cat([a[key], b[key]], dim=1) for key in a}
 
     # ---- host-side planning (reference STAR-GCN.py:373-397) -------------------------------------------
     def make_plan(self, graph, rating_node_pairs=None, embed_noise_dict=None, recon_node_ids_dict=None,
@@ -266,6 +299,8 @@ class Net(nn.Module):
             names.append("req")
             uniq, idx_l = G.merge_node_ids_dict(parts)
             plan["idx"][b] = dict(zip(names, idx_l))
+            if self._use_fea_proj and not self._recon_fea and b < nb - 1 and self._use_dae:
+                plan["idx"][b]["req_fea"] = self._fea_plan(req, device)    # block_req_node_ids_dict, STAR-GCN.py:455-459
             enc = self.encoders[0] if self._use_recurrent else self.encoders[b]
             req, plan["enc"][b] = enc.gen_plan(graph=graph, sel_node_ids_dict=uniq,
                                                graph_sampler_args=graph_sampler_args, symm=symm, device=device,
@@ -274,6 +309,10 @@ class Net(nn.Module):
         plan["input"] = self._embed_plan(req, embed_noise_dict, embed_noise_dict is not None, device)
         plan["gt"] = (self._embed_plan(recon_node_ids_dict, None, False, device)
                       if recon_node_ids_dict is not None else None)
+        if self._use_fea_proj:
+            plan["input_fea"] = self._fea_plan(req, device)
+            plan["gt_fea"] = (self._fea_plan(recon_node_ids_dict, device)
+                              if recon_node_ids_dict is not None and self._recon_fea else None)
         for b in range(nb):      # resident index plans for the heads
             idx, n_out = plan["idx"][b], plan["idx"][b]["n_out"]
             if "rating" in idx:
@@ -308,16 +347,25 @@ class Net(nn.Module):
                 idx["pair"] = PairPlan.from_device_csr(dgraph.ind_ptr, dgraph.end_points, dgraph.n_item)
             if b < self._nblocks - 1 and self._use_dae:
                 idx["req_take"] = dict(ident)
+                if self._use_fea_proj and not self._recon_fea:
+                    idx["req_fea"] = dict(ident)
             plan["idx"][b] = idx
         plan["input"] = dict(ident)
         plan["gt"] = None
+        if self._use_fea_proj:
+            plan["input_fea"], plan["gt_fea"] = dict(ident), None
         return plan
 
     # ---- device work (reference STAR-GCN.py:399-461) --------------------------------------------------
     def run(self, plan):
         pred_ratings, pred_embeddings = [], []
         gt = self.get_embed(plan["gt"]) if plan["gt"] is not None else dict()
-        x = self.get_embed(plan["input"])
+        if gt and self._recon_fea:
+            gt = self._concat(gt, self.get_feature(plan["gt_fea"]))
+        x = self.get_embed(plan["input"]) if self._use_embed else None
+        if self._use_fea_proj:      # STAR-GCN.py:405-413
+            fea = self.get_feature(plan["input_fea"])
+            x = self._concat(x, fea) if x is not None else fea
         for b in range(self._nblocks):
             enc = self.encoders[0] if self._use_recurrent else self.encoders[b]
             out = enc.heter_sage(x, plan["enc"][b])
@@ -339,6 +387,8 @@ class Net(nn.Module):
             if b < self._nblocks - 1 and self._use_dae:
                 m = self.embed_maps[k]
                 x = {key: m[key](SF.take_rows(out[key], tp)) for key, tp in idx["req_take"].items()}
+                if "req_fea" in idx:
+                    x = self._concat(x, self.get_feature(idx["req_fea"]))
         return pred_ratings, pred_embeddings, gt
 
     def forward(self, graph, rating_node_pairs=None, embed_noise_dict=None, recon_node_ids_dict=None,

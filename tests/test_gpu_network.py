@@ -109,6 +109,71 @@ def test_two_block_star_gcn_matches_dense_oracle(accum, agg_units, order):
         rel_close(p.grad, ref, 3e-5, "grad " + name)
 
 
+@pytest.mark.parametrize("recon_fea", [False, True])
+def test_feature_projection_matches_dense_oracle(recon_fea):
+    """MODEL.USE_FEA_PROJ / RECON_FEA (reference STAR-GCN.py:182-192, 364-370, 405-413, 455-459): mapped node features
+    concatenated to every block's input, and to the reconstruction target when RECON_FEA."""
+    import star_gcn_amd.model as M
+    import star_gcn_amd.synthetic as S
+    dev = torch.device("cuda", 0)
+    graph, eu, ei, vals = S.make_graph("custom", seed=5, n_user=60, n_item=40, n_edges=700, n_levels=5)
+    rng = np.random.default_rng(9)
+    feats = {U: rng.normal(size=(60, 23)).astype(np.float32), I: rng.normal(size=(40, 19)).astype(np.float32)}
+    torch.manual_seed(3)
+    net = M.Net(graph, U, I, embed_units=32, agg_units=(60,), out_units=(75,), nblocks=2, use_dae=True, agg_accum="stack",
+                use_fea_proj=True, recon_fea=recon_fea, fea_mid_map=16, fea_units=12, features=feats).to(dev)
+    noise, recon = {}, {}
+    for key, n in ((U, 60), (I, 40)):
+        perm = rng.permutation(n).astype(np.int32)
+        recon[key] = perm[:int(np.ceil(0.25 * n))]
+        nz = np.arange(n, dtype=np.int32)
+        nz[perm[:5]] = -1
+        noise[key] = nz
+    sel = rng.choice(eu.size, 250, replace=False)
+    pairs = np.stack([eu[sel], ei[sel]])
+    y = torch.from_numpy(((vals[sel] - vals.mean()) / vals.std()).astype(np.float32))
+    preds, recons, gt = net(graph, rating_node_pairs=pairs, embed_noise_dict=noise, recon_node_ids_dict=recon, device=dev)
+    loss = M.star_gcn_loss(preds, recons, gt, y.to(dev), recon_lambda=0.1)
+    loss.backward()
+
+    tables, blocks, maps, projs, leaf = extract(net)
+
+    def cv(p):
+        if id(p) not in leaf:
+            leaf[id(p)] = p.detach().to("cpu", torch.float64).requires_grad_(True)
+        return leaf[id(p)]
+    fmaps = {k: (cv(net.fea_mappings[k][0].weight), cv(net.fea_mappings[k][0].bias), cv(net.fea_mappings[k][1].weight),
+                 cv(net.fea_mappings[k][1].bias)) for k in (U, I)}
+    levels = graph[U, I].multi_link
+    adj = {(U, I): OM.dense_level_adjacency(eu, ei, vals, levels, 60, 40),
+           (I, U): OM.dense_level_adjacency(ei, eu, vals, levels, 40, 60)}
+    opreds, orecons, ogt = OM.dense_star_gcn(tables, noise, adj, blocks, maps, projs, (U, I, pairs[0], pairs[1]), recon,
+                                             accum="stack", features={k: torch.from_numpy(v).double() for k, v in feats.items()},
+                                             fea_maps=fmaps, recon_fea=recon_fea)
+    oloss = 0.0
+    for pr in opreds:
+        oloss = oloss + (0.5 * (pr.view(-1) - y.double()) ** 2).mean()
+    for blk in orecons:
+        for key, pred in blk.items():
+            oloss = oloss + 0.1 * ((ogt[key] - pred) ** 2).sum(dim=1).mean()
+    oloss.backward()
+    width = 32 + (12 if recon_fea else 0)
+    for b in range(2):
+        rel_close(preds[b], opreds[b], 1e-5, "pred_ratings[%d]" % b)
+        for key in (U, I):
+            assert recons[b][key].shape[1] == width
+            rel_close(recons[b][key], orecons[b][key], 1e-5, "pred_embeddings[%d][%s]" % (b, key))
+    for key in (U, I):
+        rel_close(gt[key], ogt[key], 1e-6, "gt[%s]" % key)
+    rel_close(loss, oloss, 1e-5, "loss")
+    for name, p in net.named_parameters():
+        ref = leaf[id(p)].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        rel_close(p.grad, ref, 3e-5, "grad " + name)
+
+
 def test_layer_api_with_reference_style_lists():
     """The aggregator accepts the reference's per-level lists (incl. empty_as_zero padding) and GCNAggregator works."""
     from star_gcn_amd.mxgraph.layers import GCNAggregator, MultiLinkGCNAggregator
