@@ -101,6 +101,9 @@ def main():
                     help="with --data-root: the reference's inductive setting (datasets.py:153-171, iterators.py:171-176): "
                          "10 %% of the items / users are held out as test nodes, 10 %% of the rest as validation nodes; the "
                          "network trains on the graph of the training nodes and sees held-out nodes with a zero embedding")
+    ap.add_argument("--features", action="store_true",
+                    help="with --data-root: feed the data set's node features through the feature projection "
+                         "(reference MODEL.USE_FEA_PROJ)")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--batch", type=int, default=10000)
     ap.add_argument("--embed", type=int, default=32)
@@ -144,8 +147,12 @@ def main():
     train_vals = it.train_graph[U, I].values
     mean, std = float(train_vals.mean()), float(train_vals.std())
     lo, hi = float(it.possible_rating_values.min()), float(it.possible_rating_values.max())
+    fea_kwargs = dict()
+    if args.features:
+        assert args.data_root is not None, "--features needs a data set (--data-root)"
+        fea_kwargs = dict(use_fea_proj=True, features=graph.features)
     net = M.Net(graph, U, I, embed_units=args.embed, agg_units=(250,), out_units=(75,), nblocks=2, use_dae=True,
-                dropout=0.5, agg_accum="sum").to(dev)
+                dropout=0.5, agg_accum="sum", **fea_kwargs).to(dev)
     rating_it = it.rating_sampler(args.batch, "train", return_index=args.resident)
     recon_it = it.recon_nodes_sampler(1000000)
     opt = None

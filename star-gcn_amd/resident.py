@@ -33,6 +33,8 @@ class ResidentPlan(object):
         self.U, self.I = net._name_user, net._name_item
         U, I = self.U, self.I
         full = {k: graph.node_ids_dict[k] for k in graph.meta_graph}
+        if getattr(net, "_recon_fea", False):
+            raise NotImplementedError("resident plan with MODEL.RECON_FEA: the per-batch feature targets are not planned")
         self.plan = net.make_plan(graph, symm=self.symm, device=device, full_node_ids=full)
         self.csr = graph[U, I]
         m = self.csr

@@ -259,7 +259,7 @@ def test_training_from_a_movielens_directory(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "examples", "train_star_gcn.py"), "--data-root", str(tmp_path),
                           "--dataset", "ml-1m", "--iters", "150", "--eval-every", "75", "--batch", "4000", "--resident",
-                          "--device-sampler"], capture_output=True, text=True, timeout=600, cwd=root)
+                          "--device-sampler", "--features"], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "Dataset Name=ml-1m" in out.stdout and "#ratings 40000" in out.stdout
     rmse = [float(x) for x in re.findall(r"valid RMSE ([0-9.]+)", out.stdout)]
