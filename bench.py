@@ -302,8 +302,8 @@ def hbm_leg(args, dev):
 
     def step():
         net.zero_grad(set_to_none=True)
-        preds, _, _ = net.run(plan)
-        loss = SF.l2_loss(preds[0].view(-1), y, 1.0 / E)
+        losses, _, _ = net.run(plan, rating_targets=y, rating_scale=1.0 / E)
+        loss = losses[0]
         loss.backward()
         return loss
 
@@ -379,8 +379,8 @@ def run_config5(args, dev, dist_on, world, rank, backend):
 
     def step():
         net.zero_grad(set_to_none=True)
-        preds, _, _ = net.run(plan)
-        loss = SF.l2_loss(preds[0].view(-1), y, 1.0 / E_total)
+        losses, _, _ = net.run(plan, rating_targets=y, rating_scale=1.0 / E_total)   # = l2_loss(scores, y, 1 / E)
+        loss = losses[0]
         loss.backward()
         if dist_on:
             SD.allreduce_grads(net.local_region_parameters())
@@ -503,8 +503,8 @@ def run_rank(args):
 
     def step():
         net.zero_grad(set_to_none=True)
-        preds, _, _ = net.run(plan)
-        loss = SF.l2_loss(preds[0].view(-1), y, 1.0 / E_total)
+        losses, _, _ = net.run(plan, rating_targets=y, rating_scale=1.0 / E_total)   # = l2_loss(scores, y, 1 / E)
+        loss = losses[0]
         loss.backward()
         if dist_on:
             SD.allreduce_grads(net.local_region_parameters())

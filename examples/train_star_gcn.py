@@ -47,8 +47,8 @@ def run_graph(args, net, it, resident, dsampler, mean, std, lo, hi, dev):
 
     def iteration(advance):
         dbatch = dsampler.next_batch(advance_on_device=advance)
-        preds, recons, gt = net.run(resident.set_batch_device(dbatch))
         y = (dbatch["ratings"] - mean) / std
+        preds, recons, gt = net.run(resident.set_batch_device(dbatch), rating_targets=y, rating_scale=1.0 / y.numel())
         loss = M.star_gcn_loss(preds, recons, gt, y, recon_lambda=0.1)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0, foreach=True)
@@ -175,8 +175,9 @@ def main():
         t_it = time.perf_counter()
         if dsampler is not None:    # samplers, batch plans and edge masking all on the device
             dbatch = dsampler.next_batch()
-            preds, recons, gt = net.run(resident.set_batch_device(dbatch))
             y = (dbatch["ratings"] - mean) / std
+            # training only needs the rating LOSS: the fused head (sg_pair_l2_hip) never materialises the scores
+            preds, recons, gt = net.run(resident.set_batch_device(dbatch), rating_targets=y, rating_scale=1.0 / y.numel())
             batch = None
         else:
             batch = next(rating_it)

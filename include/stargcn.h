@@ -103,6 +103,21 @@ int sg_seg_gather_sum_parts_hip(float* dst, int64_t dst_group, int64_t dst_ld, c
                                 int req, int act, float slope, void* workspace, size_t workspace_bytes, void* stream,
                                 int64_t src_bytes);
 
+/* Rating head in two passes (reference: InnerProductLayer layers.py:210-222 + gluon L2Loss, STAR-GCN.py:428-438, 612):
+ * one gather whose per-edge weight is formed from the row it has just loaded,
+ *     r_j = < src[indices[j]], other[seg(j)] > - y[j],     rows[seg] (+)= sum_j scale * (*scale_dev) * r_j * src[indices[j]],
+ *     loss = loss_scale * sum_j r_j^2   (written when loss != NULL)
+ * Pass A, edges grouped by user: src = item projections, other = user projections -> d(user projections) and the loss;
+ * pass B, edges grouped by item (optionally as a source-partitioned plan with `parts` ranges, indptr then has
+ * parts * seg_num + 1 entries): src = user projections, other = item projections -> d(item projections).  y is in the
+ * pass's edge order.  Replaces seg_take_k_corr + two weighted gathers + the loss kernels: the projections are read
+ * twice instead of four times and no per-pair array is written or re-read.  feat_dim % 4 == 0, feat_dim <= 128. */
+size_t sg_pair_l2_workspace_bytes(int64_t seg_num, int64_t parts, int64_t nnz, int64_t feat_dim);
+int sg_pair_l2_hip(float* rows, float* loss, const float* src, const float* other, const float* y, const int32_t* indices,
+                   const int32_t* indptr, int64_t seg_num, int64_t parts, int64_t nnz, int64_t feat_dim, float scale,
+                   const float* scale_dev, float loss_scale, int req, void* workspace, size_t workspace_bytes, void* stream,
+                   int64_t src_bytes);
+
 /* ------------------------------------------------------------------------------------------------
  * (2) gradient of (1) w.r.t. data == reference `_contrib__backward_seg_take_k_corr_embed2(weights,
  *     ograd, indices, indptr)` seg_op.cc:700-703,718-752; CPU kernel :209-240; GPU seg_op.cu:747-790,

@@ -94,6 +94,8 @@ _SIGS = {
     "sg_multilink_fuse_workspace_bytes": (_SZ, [_I64] * 4),
     "sg_multilink_fuse_hip": (_INT, [_P] * 13 + [_I64] * 4 + [_P, _SZ, _P]),
     "sg_multilink_fuse_csr_hip": (_INT, [_P] * 16 + [_I64] * 4 + [_P, _SZ, _P]),
+    "sg_pair_l2_workspace_bytes": (_SZ, [_I64] * 4),
+    "sg_pair_l2_hip": (_INT, [_P] * 7 + [_I64] * 4 + [_F32, _P, _F32, _INT, _P, _SZ, _P, _I64]),
     "sg_part_keys_hip": (_INT, [_P] * 4 + [_I64] * 3 + [_P]),
     "sg_seg_gather_sum_parts_workspace_bytes": (_SZ, [_I64] * 4),
     "sg_seg_gather_sum_parts_hip": (_INT, [_P, _I64, _I64, _P, _I64, _I64] + [_P] * 4 + [_I64] * 4

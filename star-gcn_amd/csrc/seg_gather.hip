@@ -60,6 +60,14 @@ struct GatherArgs {
   int32_t req, mean;
   int32_t act;
   float slope;
+  // DOT mode (rating head, sg_pair_l2_hip): the weight of edge j is NOT read but formed from the row it gathers:
+  //   r_j = < src[idx[j]], dot_other[seg(j) % dot_mod] > - w[j]        (w holds the targets y in edge order)
+  //   weight_j = dot_scale * (*dot_scale_dev) * r_j,   loss_part[chunk] = sum_j r_j^2
+  const float* dot_other;
+  const float* dot_scale_dev;   // may be null (= 1)
+  float* loss_part;             // [batch][n_chunks], may be null
+  float dot_scale;
+  int32_t dot_mod;              // rows of dot_other (a source-partitioned plan has parts * dot_mod sub-segments)
 };
 
 __device__ __forceinline__ float gather_act(float v, int act, float slope) {
@@ -150,10 +158,12 @@ __device__ __forceinline__ long long uniform_ll(long long v) {
 
 // Accumulate edges [ea, eb) (chunk-relative LDS positions) for the channel tile starting at ct; the
 // result (summed over edge groups) is returned in acc on every lane.
-template <int VEC, bool GROUPED, bool UNI>
+template <int VEC, bool GROUPED, bool UNI, int DLPR = 0>   // DLPR > 0: DOT mode with DLPR lanes per edge (compile time)
 __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const float* __restrict__ src, const long long* s_off,
                                                  const float* s_w, int ea, int eb, int c, bool chan_ok, int grp,
-                                                 int epg, float (&acc)[VEC]) {
+                                                 int epg, float (&acc)[VEC], const float* dvec = nullptr,
+                                                 float dscale = 0.f, float* lacc = nullptr) {
+  constexpr bool DOT = DLPR > 0;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
   int e = ea + grp;
@@ -174,6 +184,21 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
       }
       if (chan_ok) ld_row<VEC>(x[u], src + off + c);
     }
+    if (DOT) {   // the row is in registers: its inner product with the segment's vector gives the weight
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float d = 0.f;
+        if (chan_ok) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) d = fmaf(x[u][v], dvec[v], d);
+        }
+#pragma unroll
+        for (int off = 1; off < DLPR; off <<= 1) d += __shfl_xor(d, off);
+        const float r = d - wv[u];
+        *lacc += r * r;
+        wv[u] = dscale * r;
+      }
+    }
     if (chan_ok) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
@@ -188,23 +213,44 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
       off = uniform_ll(off);
       wv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wv)));
     }
+    float x[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) x[v] = 0.f;
+    if (chan_ok) ld_row<VEC>(x, src + off + c);
+    if (DOT) {
+      float d = 0.f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) d = fmaf(x[v], dvec[v], d);
+#pragma unroll
+      for (int o = 1; o < DLPR; o <<= 1) d += __shfl_xor(d, o);
+      const float r = d - wv;
+      *lacc += r * r;
+      wv = dscale * r;
+    }
     if (chan_ok) {
-      float x[VEC];
-      ld_row<VEC>(x, src + off + c);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[v] = fmaf(wv, x[v], acc[v]);
     }
   }
   if (!UNI) {
-    for (int off = a.lpr; off < kWave; off <<= 1) {
+    if (DOT) {
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], off);
+      for (int off = (DLPR > 0 ? DLPR : kWave); off < kWave; off <<= 1) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], off);
+      }
+    } else {
+      for (int off = a.lpr; off < kWave; off <<= 1) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], off);
+      }
     }
   }
 }
 
-template <int VEC, bool GROUPED, bool UNI>
+template <int VEC, bool GROUPED, bool UNI, int DLPR = 0>
 __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
+  constexpr bool DOT = DLPR > 0;
   __shared__ long long s_off[kChunk];   // element offset of each edge's source row (index -> row address done once)
   __shared__ float s_w[kChunk];
   __shared__ int32_t s_ptr[kPtrTile + 1];
@@ -232,7 +278,10 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
   const long long cb64 = static_cast<long long>(k) * kChunk;
   int32_t* tailseg = a.ws_tailseg + static_cast<long long>(b) * a.n_chunks + k;
   if (cb64 >= E && !(E == 0 && k == 0)) {
-    if (lane == 0 && slice == 0) *tailseg = -1;
+    if (lane == 0 && slice == 0) {
+      *tailseg = -1;
+      if (DOT && a.loss_part) a.loss_part[static_cast<long long>(b) * a.n_chunks + k] = 0.f;
+    }
     return;
   }
   const int cb = static_cast<int>(cb64);
@@ -252,7 +301,7 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
   const int s_lo = wave_lower_bound(indptr, a.seg_num, cb, lane);
   __syncthreads();  // single-wave workgroup: only orders the LDS writes above before the reads below
 
-  const int lpr = a.lpr;
+  const int lpr = DOT ? DLPR : a.lpr;
   const int epg = kWave / lpr;
   const int grp = UNI ? 0 : lane / lpr;
   const int slot = UNI ? lane : lane % lpr;
@@ -262,13 +311,29 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
 
   // ---- head piece: the segment that started before this chunk --------------------------------------
   const int p_lo = indptr[s_lo];  // s_lo <= seg_num
+  // DOT mode: one channel pass (C <= lpr * VEC, checked by the launcher); the segment's own vector is loaded per piece
+  float lacc = 0.f;
+  float dscale = 0.f;
+  if (DOT) dscale = a.dot_scale * (a.dot_scale_dev ? *a.dot_scale_dev : 1.f);
+  auto load_dvec = [&](float (&dv)[VEC], int seg, int c, bool ok) {
+    const int row = a.dot_mod > 0 ? seg % a.dot_mod : seg;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) dv[v] = 0.f;
+    if (ok) ld_vec<VEC>(dv, a.dot_other + static_cast<long long>(row) * a.C + c);
+  };
   if (cb < ce && p_lo > cb) {
     const int hb = min(ce, p_lo);
     for (int ct = c_lo; ct < c_hi; ct += ctile) {
       const int c = ct + slot * VEC;
       const bool chan_ok = c < c_hi;
       float acc[VEC];
-      accumulate_piece<VEC, GROUPED, UNI>(a, src, s_off, s_w, 0, hb - cb, c, chan_ok, grp, epg, acc);
+      if (DOT) {
+        float dv[VEC];
+        load_dvec(dv, s_lo - 1, c, chan_ok);       // the segment that holds edge cb
+        accumulate_piece<VEC, GROUPED, UNI, DLPR>(a, src, s_off, s_w, 0, hb - cb, c, chan_ok, grp, epg, acc, dv, dscale, &lacc);
+      } else {
+        accumulate_piece<VEC, GROUPED, UNI>(a, src, s_off, s_w, 0, hb - cb, c, chan_ok, grp, epg, acc);
+      }
       if (grp == 0 && chan_ok) st_vec<VEC>(a.ws_head + wsrow + c, acc);
     }
   }
@@ -301,7 +366,14 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
         const int c = ct + slot * VEC;
         const bool chan_ok = c < c_hi;
         float acc[VEC];
-        accumulate_piece<VEC, GROUPED, UNI>(a, src, s_off, s_w, pb - cb, eb - cb, c, chan_ok, grp, epg, acc);
+        if (DOT) {
+          float dv[VEC];
+          load_dvec(dv, s, c, chan_ok);
+          accumulate_piece<VEC, GROUPED, UNI, DLPR>(a, src, s_off, s_w, pb - cb, eb - cb, c, chan_ok, grp, epg, acc, dv, dscale,
+                                                    &lacc);
+        } else {
+          accumulate_piece<VEC, GROUPED, UNI>(a, src, s_off, s_w, pb - cb, eb - cb, c, chan_ok, grp, epg, acc);
+        }
         if (grp == 0 && chan_ok) {
           if (whole) {
             if (a.mean) {
@@ -326,6 +398,11 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
     }
   }
   if (lane == 0 && slice == 0) *tailseg = tail_s;
+  if (DOT && a.loss_part) {      // every lane of an edge's group holds the same residual: the wave sum counts it lpr times
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lacc += __shfl_xor(lacc, off);
+    if (lane == 0) a.loss_part[static_cast<long long>(b) * a.n_chunks + k] = lacc / static_cast<float>(a.lpr);
+  }
 }
 
 // Adds, in chunk order, the partial rows of every segment that straddles chunk boundaries.
@@ -381,7 +458,7 @@ size_t gather_workspace_bytes(int64_t batch, int64_t nnz, int64_t C) {
 }
 
 template <int VEC>
-static void launch_variants(const GatherArgs& a, dim3 fix_grid, hipStream_t st, bool grouped, bool uni) {
+static void launch_variants(const GatherArgs& a, dim3 fix_grid, hipStream_t st, bool grouped, bool uni, bool dot = false) {
   dim3 grid = fix_grid;   // sliced: 8 workgroups (one per XCD) per group of 8 / n_slices chunks
   if (a.xcd_ranges) {
     grid.x = ((static_cast<unsigned>(a.n_chunks) + 7u) / 8u) * 8u;
@@ -389,7 +466,18 @@ static void launch_variants(const GatherArgs& a, dim3 fix_grid, hipStream_t st, 
     const unsigned per = 8u / static_cast<unsigned>(a.n_slices);
     grid.x = (static_cast<unsigned>(a.n_chunks) + per - 1) / per * 8u;
   }
-  if (grouped) {
+  if (dot) {      // VEC = 4, plain source rows, several edges per wave step (checked by the launcher)
+    if (VEC == 4) {
+      switch (a.lpr) {
+        case 1: hipLaunchKernelGGL((seg_gather_kernel<4, false, false, 1>), grid, dim3(kWave), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((seg_gather_kernel<4, false, false, 2>), grid, dim3(kWave), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((seg_gather_kernel<4, false, false, 4>), grid, dim3(kWave), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((seg_gather_kernel<4, false, false, 8>), grid, dim3(kWave), 0, st, a); break;
+        case 16: hipLaunchKernelGGL((seg_gather_kernel<4, false, false, 16>), grid, dim3(kWave), 0, st, a); break;
+        default: hipLaunchKernelGGL((seg_gather_kernel<4, false, false, 32>), grid, dim3(kWave), 0, st, a); break;
+      }
+    }
+  } else if (grouped) {
     if (uni) hipLaunchKernelGGL((seg_gather_kernel<VEC, true, true>), grid, dim3(kWave), 0, st, a);
     else hipLaunchKernelGGL((seg_gather_kernel<VEC, true, false>), grid, dim3(kWave), 0, st, a);
   } else {
@@ -446,11 +534,18 @@ static int env_slices_force() {
   return v;
 }
 
+struct DotArgs {   // DOT mode of the gather (see GatherArgs)
+  const float* other;
+  const float* scale_dev;
+  float* loss_part;
+  float scale;
+  int32_t mod;
+};
 int launch_gather_ex(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs, const float* src, int64_t src_group,
                      int64_t src_ld, int64_t src_bs, const float* w, int64_t w_bs, const int32_t* wpos,
                      const int32_t* idx, const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t nnz, int64_t C,
                      int req, int mean, int act, float slope, void* workspace, size_t workspace_bytes, hipStream_t st,
-                     int64_t src_bytes, int xcd_ranges);
+                     int64_t src_bytes, int xcd_ranges, const DotArgs* dot = nullptr);
 
 int launch_gather(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_bs, const float* src, int64_t src_group,
                   int64_t src_ld, int64_t src_bs, const float* w, int64_t w_bs, const int32_t* wpos,
@@ -465,7 +560,7 @@ int launch_gather_ex(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_
                      int64_t src_ld, int64_t src_bs, const float* w, int64_t w_bs, const int32_t* wpos,
                      const int32_t* idx, const int32_t* indptr, int64_t batch, int64_t seg_num, int64_t nnz, int64_t C,
                      int req, int mean, int act, float slope, void* workspace, size_t workspace_bytes, hipStream_t st,
-                     int64_t src_bytes, int xcd_ranges) {
+                     int64_t src_bytes, int xcd_ranges, const DotArgs* dot) {
   if (!valid_req(req)) return fail(SG_ERR_INVALID, "req must be 0 (null), 1 (write) or 3 (add), got %d", req);
   if (req == SG_REQ_NULL) return SG_OK;
   if (batch < 0 || seg_num < 0 || nnz < 0 || C < 0) return fail(SG_ERR_INVALID, "negative dimension");
@@ -524,7 +619,7 @@ int launch_gather_ex(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_
     if (!valid(slices)) slices = 1;
   }
   if (env_slices_force() > 0 && valid(env_slices_force())) slices = env_slices_force();   // tests: slice every launch
-  if (xcd_ranges) slices = 1;     // the source-row partition replaces the column slices
+  if (xcd_ranges || dot) slices = 1;     // the source-row partition replaces the column slices; DOT needs whole rows
   a.xcd_ranges = xcd_ranges ? 1 : 0;
   a.n_slices = slices;
   a.Cs = static_cast<int32_t>(C / slices);
@@ -533,10 +628,16 @@ int launch_gather_ex(float* dst, int64_t dst_group, int64_t dst_ld, int64_t dst_
   a.lpr = lpr;
   const bool uni = (lpr == kWave);
   const bool grouped = (src_group > 1);
+  if (dot) {
+    if (vec != 4 || grouped || uni || batch != 1 || mean || act != SG_ACT_NONE || !w || !dot->other)
+      return fail(SG_ERR_UNSUPPORTED, "DOT-mode gather needs 16-byte aligned rows of 4..128 floats, plain source rows, batch 1");
+    a.dot_other = dot->other; a.dot_scale_dev = dot->scale_dev; a.loss_part = dot->loss_part;
+    a.dot_scale = dot->scale; a.dot_mod = dot->mod;
+  }
   dim3 grid(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch));
   if (batch > 65535) return fail(SG_ERR_INVALID, "batch > 65535 not supported");
   const long rec = prof_begin(st, nnz * batch, C, src_bytes);
-  if (vec == 4) launch_variants<4>(a, grid, st, grouped, uni);
+  if (vec == 4) launch_variants<4>(a, grid, st, grouped, uni, dot != nullptr);
   else if (vec == 2) launch_variants<2>(a, grid, st, grouped, uni);
   else launch_variants<1>(a, grid, st, grouped, uni);
   prof_end(rec, st);
@@ -647,6 +748,75 @@ SG_API int sg_seg_gather_sum_parts_hip(float* dst, int64_t dst_group, int64_t ds
                        static_cast<long long>(dst_ld), part, static_cast<long long>(seg_num), static_cast<int>(parts),
                        static_cast<int>(feat_dim), req, act, slope);
   return sg::check_launch("sg_seg_gather_sum_parts_hip");
+}
+
+namespace sg {
+// loss[0] (+)= loss_scale * sum of the per-chunk partial sums, in chunk order (one wave; deterministic)
+__global__ __launch_bounds__(1024) void pair_l2_loss_kernel(float* __restrict__ loss, const float* __restrict__ part,
+                                                             long long n, float loss_scale, int add) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 1024) acc += part[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k];
+    loss[0] = (add ? loss[0] : 0.f) + loss_scale * s;
+  }
+}
+}  // namespace sg
+
+SG_API size_t sg_pair_l2_workspace_bytes(int64_t seg_num, int64_t parts, int64_t nnz, int64_t feat_dim) {
+  if (seg_num < 0 || parts < 1 || nnz < 0 || feat_dim < 0) return 0;
+  const size_t nchunks = static_cast<size_t>(nnz <= 0 ? 1 : (nnz + sg::kChunk - 1) / sg::kChunk);
+  return sg_seg_gather_sum_parts_workspace_bytes(seg_num, parts, nnz, feat_dim) + ((nchunks * sizeof(float) + 255) & ~static_cast<size_t>(255)) + 256;
+}
+
+SG_API int sg_pair_l2_hip(float* rows, float* loss, const float* src, const float* other, const float* y,
+                          const int32_t* indices, const int32_t* indptr, int64_t seg_num, int64_t parts, int64_t nnz,
+                          int64_t feat_dim, float scale, const float* scale_dev, float loss_scale, int req,
+                          void* workspace, size_t workspace_bytes, void* stream, int64_t src_bytes) {
+  if (!sg::valid_req(req)) return sg::fail(SG_ERR_INVALID, "req must be 0, 1 or 3, got %d", req);
+  if (req == SG_REQ_NULL || seg_num == 0 || feat_dim == 0) return SG_OK;
+  if (seg_num < 0 || nnz < 0 || parts < 1 || parts * seg_num >= (1ll << 31) - 1) return sg::fail(SG_ERR_INVALID, "bad size");
+  if (feat_dim % 4 || feat_dim > 128) return sg::fail(SG_ERR_UNSUPPORTED, "pair_l2 handles rows of 4..128 floats (multiple of 4)");
+  if (!rows || !src || !other || !y || !indptr || (nnz > 0 && !indices)) return sg::fail(SG_ERR_INVALID, "null pointer argument");
+  if (!workspace || workspace_bytes < sg_pair_l2_workspace_bytes(seg_num, parts, nnz, feat_dim))
+    return sg::fail(SG_ERR_WORKSPACE, "pair_l2 workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  const size_t nchunks = static_cast<size_t>(nnz <= 0 ? 1 : (nnz + sg::kChunk - 1) / sg::kChunk);
+  const size_t lbytes = (nchunks * sizeof(float) + 255) & ~static_cast<size_t>(255);
+  float* loss_part = reinterpret_cast<float*>(base);
+  base += lbytes;
+  const size_t left = workspace_bytes - static_cast<size_t>(base - static_cast<char*>(workspace));
+  sg::DotArgs d{other, scale_dev, loss ? loss_part : nullptr, scale, static_cast<int32_t>(parts > 1 ? seg_num : 0)};
+  int rc;
+  if (parts == 1) {
+    rc = sg::launch_gather_ex(rows, 1, feat_dim, 0, src, 1, feat_dim, 0, y, 0, nullptr, indices, indptr, 1, seg_num, nnz,
+                              feat_dim, req, 0, SG_ACT_NONE, 0.f, base, left, st, src_bytes, 0, &d);
+  } else {
+    const size_t pbytes = (static_cast<size_t>(parts) * seg_num * feat_dim * sizeof(float) + 255) & ~static_cast<size_t>(255);
+    float* part = reinterpret_cast<float*>(base);
+    rc = sg::launch_gather_ex(part, 1, feat_dim, 0, src, 1, feat_dim, 0, y, 0, nullptr, indices, indptr, 1, parts * seg_num, nnz,
+                              feat_dim, SG_REQ_WRITE, 0, SG_ACT_NONE, 0.f, base + pbytes, left - pbytes, st, src_bytes,
+                              parts == 8 ? 1 : 0, &d);
+    if (rc == SG_OK) {
+      const long long n = seg_num * (feat_dim / 4);
+      hipLaunchKernelGGL(sg::sum_parts_kernel<4>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, rows, 1ll,
+                         static_cast<long long>(feat_dim), part, static_cast<long long>(seg_num), static_cast<int>(parts),
+                         static_cast<int>(feat_dim), req, SG_ACT_NONE, 0.f);
+    }
+  }
+  if (rc != SG_OK) return rc;
+  if (loss)
+    hipLaunchKernelGGL(sg::pair_l2_loss_kernel, dim3(1), dim3(1024), 0, st, loss, loss_part,
+                       static_cast<long long>(nchunks), loss_scale, 0);
+  return sg::check_launch("sg_pair_l2_hip");
 }
 
 SG_API int sg_seg_gather_sum_hip(float* dst, int64_t dst_group, int64_t dst_ld, const float* src, int64_t src_group,

@@ -82,6 +82,7 @@ def _item_side_partition(self, width):
 
 
 PairPlan.item_side_partition = _item_side_partition
+PairPlan.cached_targets = lambda self, tag, y, pos: _cached_targets(self, tag, y, pos)
 
 
 def _pair_plan_from_device_csr(cls, indptr, end_points, n_item):
@@ -153,6 +154,63 @@ class _PairDot(torch.autograd.Function):
             else:
                 d_i = ops.seg_weighted_pool_bwd_data(g, pu.unsqueeze(0), pp.tplan, pp.n_item)[0]
         return d_u, d_i, None
+
+
+class _PairL2(torch.autograd.Function):
+    """loss = scale * sum_p 0.5 (<pu[user_p], pi[item_p]> - y_p)^2 in two gather passes that form their edge weights from
+    the rows they load (sg_pair_l2_hip): forward = pass over the pairs grouped by user (loss + d pu up to the upstream
+    gradient), backward = pass grouped by item (d pi).  Same value and gradients as pair_inner_product + l2_loss."""
+
+    @staticmethod
+    def forward(ctx, pu, pi, pp, y, scale):
+        pu, pi, y = L.f32c(pu), L.f32c(pi), L.f32c(y).view(-1)
+        if not pp.identity:
+            y = y[pp.order.long()]                       # plan order = pairs grouped by user
+        n = pp.items.numel()
+        if y.numel() < n:                                # padding slots of an empty plan
+            y = torch.nn.functional.pad(y, (0, n - y.numel()))
+        du, loss = ops.pair_l2(pi, pu, y, pp.items, pp.indptr, pp.n_user, scale, loss_scale=0.5 * scale)
+        ctx.pp, ctx.scale = pp, scale
+        ctx.save_for_backward(pu, pi, y, du)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        pu, pi, y, du = ctx.saved_tensors
+        pp = ctx.pp
+        gout = L.f32c(gout).view(1)
+        d_u = du * gout if ctx.needs_input_grad[0] else None
+        d_i = None
+        if ctx.needs_input_grad[1]:
+            sp = pp.item_side_partition(pu.shape[1])
+            if sp is not None:
+                yt = pp.cached_targets("parts", y, sp.pos)
+                d_i, _ = ops.pair_l2(pu, pi, yt, sp.src, sp.indptr, pp.n_item, ctx.scale, parts=sp.parts, scale_dev=gout)
+            else:
+                tp = pp.tplan
+                yt = pp.cached_targets("t", y, tp.t_pos)
+                d_i, _ = ops.pair_l2(pu, pi, yt, tp.t_seg, tp.t_indptr, pp.n_item, ctx.scale, scale_dev=gout)
+        return d_u, d_i, None, None, None
+
+
+def _cached_targets(self, tag, y, pos):
+    """y in another edge order of this plan (y[pos]); kept while the same target tensor is passed again (the full-batch
+    head scores the same ratings every step)."""
+    key = (tag, y.data_ptr(), y._version, y.numel())
+    c = getattr(self, "_y_cache", None)
+    if c is None or c[0] != key:
+        c = (key, y[pos.long()].contiguous())
+        self._y_cache = c if getattr(self, "reused", False) else None
+    return c[1]
+
+
+def pair_l2_supported(width):
+    return width % 4 == 0 and 4 <= width <= 128
+
+
+def pair_l2_loss(pu, pi, pair_plan, y, scale):
+    """scale * sum 0.5 (score - y)^2 over the plan's pairs without materialising the scores (see _PairL2)."""
+    return _PairL2.apply(pu, pi, pair_plan, y, scale)
 
 
 def pair_inner_product(pu, pi, pair_plan):
@@ -357,7 +415,10 @@ class Net(nn.Module):
         return plan
 
     # ---- device work (reference STAR-GCN.py:399-461) --------------------------------------------------
-    def run(self, plan):
+    def run(self, plan, rating_targets=None, rating_scale=None):
+        """rating_targets (standardised ratings of the plan's pairs) + rating_scale: return per-block rating LOSSES
+        scale * sum 0.5 (score - y)^2 in place of the scores (fused rating head, sg_pair_l2_hip) -- what training needs;
+        evaluation keeps the scores."""
         pred_ratings, pred_embeddings = [], []
         gt = self.get_embed(plan["gt"]) if plan["gt"] is not None else dict()
         if gt and self._recon_fea:
@@ -379,7 +440,13 @@ class Net(nn.Module):
                         pi = D.copy_to_local(pi)
                     if self._name_user in self.pair_partition.replicated_keys:
                         pu = D.copy_to_local(pu)
-                pred_ratings.append(pair_inner_product(pu, pi, idx["pair"]).view(-1, 1))
+                if (rating_targets is not None and self.pair_partition is None and pair_l2_supported(pu.shape[1])):
+                    pred_ratings.append(pair_l2_loss(pu, pi, idx["pair"], rating_targets, rating_scale))
+                elif rating_targets is not None:
+                    pred_ratings.append(SF.l2_loss(pair_inner_product(pu, pi, idx["pair"]).view(-1),
+                                                   rating_targets.view(-1), rating_scale))
+                else:
+                    pred_ratings.append(pair_inner_product(pu, pi, idx["pair"]).view(-1, 1))
             if "recon_take" in idx and self._use_dae:
                 m = self.embed_maps[k]
                 pred_embeddings.append({key: m[key](SF.take_rows(out[key], tp))
@@ -392,9 +459,9 @@ class Net(nn.Module):
         return pred_ratings, pred_embeddings, gt
 
     def forward(self, graph, rating_node_pairs=None, embed_noise_dict=None, recon_node_ids_dict=None,
-                graph_sampler_args=None, symm=None, device="cuda"):
+                graph_sampler_args=None, symm=None, device="cuda", rating_targets=None, rating_scale=None):
         return self.run(self.make_plan(graph, rating_node_pairs, embed_noise_dict, recon_node_ids_dict,
-                                       graph_sampler_args, symm, device))
+                                       graph_sampler_args, symm, device), rating_targets, rating_scale)
 
 
 def star_gcn_loss(pred_ratings, pred_embeddings, gt_embeddings, gt_ratings_std, recon_lambda=0.1):
@@ -402,7 +469,10 @@ def star_gcn_loss(pred_ratings, pred_embeddings, gt_embeddings, gt_ratings_std, 
     + recon_lambda * sum over blocks and keys of mean_nodes( sum_c (gt - pred)^2 ); the target is NOT detached."""
     loss = 0.0
     for pr in pred_ratings:
-        loss = loss + SF.l2_loss(pr.view(-1), gt_ratings_std.view(-1), 1.0 / max(pr.numel(), 1))
+        if pr.dim() == 0:       # Net.run(..., rating_targets=..., rating_scale=1 / #pairs) already returned this term
+            loss = loss + pr
+        else:
+            loss = loss + SF.l2_loss(pr.view(-1), gt_ratings_std.view(-1), 1.0 / max(pr.numel(), 1))
     for block in pred_embeddings:
         for key, pred in block.items():
             loss = loss + recon_lambda * ((gt_embeddings[key] - pred) ** 2).sum(dim=1).mean()

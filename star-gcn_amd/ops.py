@@ -68,6 +68,26 @@ def gather_sum_parts(dst, src, sp, weights, feat_dim, dst_group=1, dst_ld=None, 
     return dst
 
 
+def pair_l2(src, other, y, indices, indptr, seg_num, scale, parts=1, scale_dev=None, loss_scale=None, out=None,
+            req=REQ_WRITE):
+    """sg_pair_l2_hip: rows[seg] (+)= sum_j g_j src[indices[j]] with g_j = scale * (*scale_dev) * (<src[indices[j]], other[seg]>
+    - y[j]); returns (rows, loss) with loss = loss_scale * sum_j (..)^2 as a 1-element tensor (None when loss_scale is)."""
+    L.require_gpu(src, other, y, indices, indptr)
+    C = src.shape[1]
+    nnz = indices.numel()
+    if out is None:
+        out = torch.empty((seg_num, C), dtype=torch.float32, device=src.device)
+    loss = torch.empty(1, dtype=torch.float32, device=src.device) if loss_scale is not None else None
+    lib = L.lib()
+    ws, wsn = L.workspace(lib.sg_pair_l2_workspace_bytes(seg_num, parts, nnz, C), src.device)
+    L.check(lib.sg_pair_l2_hip(L.ptr(out), L.ptr(loss) if loss is not None else None, L.ptr(src), L.ptr(other), L.ptr(y),
+                               L.ptr(indices), L.ptr(indptr), seg_num, parts, nnz, C, float(scale),
+                               L.ptr(scale_dev) if scale_dev is not None else None,
+                               float(loss_scale) if loss_scale is not None else 0.0, req, L.ptr(ws), wsn, L.stream_ptr(),
+                               src.numel() * 4), "sg_pair_l2_hip")
+    return out, loss
+
+
 def seg_weighted_pool(data, weights, indices, indptr, out=None, req=REQ_WRITE):
     """reference `_contrib_seg_weighted_pool` forward (seg_op.cc:665-716)."""
     L.require_gpu(data, weights, indices, indptr)

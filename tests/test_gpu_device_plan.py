@@ -249,3 +249,44 @@ def test_pair_plan_uses_the_partitioned_gather_when_it_pays(monkeypatch):
         grads.append((a.grad, b.grad))
     assert torch.equal(grads[0][0], grads[1][0])
     assert float((grads[0][1] - grads[1][1]).abs().max()) <= 1e-5 * float(grads[0][1].abs().max())
+
+
+@pytest.mark.parametrize("kind", ["sorted_device", "host_unsorted", "partitioned"])
+@pytest.mark.parametrize("C", [64, 20, 128])
+def test_fused_rating_loss_equals_scores_plus_l2_loss(kind, C):
+    """model.pair_l2_loss (two DOT-mode gather passes, sg_pair_l2_hip) against pair_inner_product + l2_loss: value and the
+    gradients w.r.t. both projections, with an upstream gradient != 1; pairs with empty users / items, padding-free and
+    permuted plans, and the source-partitioned item pass."""
+    import star_gcn_amd.functional as SF
+    import star_gcn_amd.model as M
+    from star_gcn_amd.plan import SourcePartition
+    rng = np.random.default_rng(C + len(kind))
+    nu, ni, n = 400, 90, 7000
+    cells = rng.choice(nu * ni, n, replace=False)
+    if kind != "host_unsorted":
+        cells.sort()
+    u, i = (cells // ni).astype(np.int32), (cells % ni).astype(np.int32)
+    if kind == "host_unsorted":
+        pp = M.PairPlan(u, i, nu, ni, torch.device("cuda", 0))
+        assert not pp.identity
+    else:
+        pp = M.PairPlan.from_sorted_device_pairs(torch.from_numpy(u).cuda(), torch.from_numpy(i).cuda(), nu, ni)
+        if kind == "partitioned":
+            pp._tparts = SourcePartition(pp.tplan.t_indptr, pp.tplan.t_seg, nu, pos=pp.tplan.t_pos, parts=8)
+    pu0 = torch.randn(nu, C, device="cuda")
+    pi0 = torch.randn(ni, C, device="cuda")
+    y = torch.randn(n, device="cuda")
+    scale = 1.0 / n
+    res = []
+    for fused in (False, True):
+        a, b = pu0.clone().requires_grad_(True), pi0.clone().requires_grad_(True)
+        if fused:
+            loss = M.pair_l2_loss(a, b, pp, y, scale)
+        else:
+            loss = SF.l2_loss(M.pair_inner_product(a, b, pp).view(-1), y, scale)
+        (loss * 3.0).backward()
+        res.append((loss.detach(), a.grad, b.grad))
+    (l0, ga0, gb0), (l1, ga1, gb1) = res
+    assert abs(float(l0) - float(l1)) <= 2e-6 * abs(float(l0))
+    assert float((ga0 - ga1).abs().max()) <= 1e-5 * float(ga0.abs().max())
+    assert float((gb0 - gb1).abs().max()) <= 1e-5 * float(gb0.abs().max())
