@@ -440,7 +440,7 @@ class Net(nn.Module):
                         pi = D.copy_to_local(pi)
                     if self._name_user in self.pair_partition.replicated_keys:
                         pu = D.copy_to_local(pu)
-                if (rating_targets is not None and self.pair_partition is None and pair_l2_supported(pu.shape[1])):
+                if rating_targets is not None and pair_l2_supported(pu.shape[1]):
                     pred_ratings.append(pair_l2_loss(pu, pi, idx["pair"], rating_targets, rating_scale))
                 elif rating_targets is not None:
                     pred_ratings.append(SF.l2_loss(pair_inner_product(pu, pi, idx["pair"]).view(-1),
