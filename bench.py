@@ -593,6 +593,9 @@ def run_rank(args):
                                 "RCCL all-reduce of item-side partials on a side stream, overlapped with the user-side "
                                 "aggregation of the same layer",
                    "order": args.order, "plan_build_s": round(t_plan, 2), "plan_builder": "device (csrc/plan_build.hip)",
+                   "rating_head": "loss and both projection gradients in two gather passes that form the pair scores in "
+                                  "registers (sg_pair_l2_hip); same value / gradients as scores + L2 loss, no per-pair "
+                                  "array is written",
                    "loss": float(loss_total), "edges_per_rank": edges_per_rank,
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
         "roofline": roof,
