@@ -290,3 +290,43 @@ def test_fused_rating_loss_equals_scores_plus_l2_loss(kind, C):
     assert abs(float(l0) - float(l1)) <= 2e-6 * abs(float(l0))
     assert float((ga0 - ga1).abs().max()) <= 1e-5 * float(ga0.abs().max())
     assert float((gb0 - gb1).abs().max()) <= 1e-5 * float(gb0.abs().max())
+
+
+@pytest.mark.parametrize("C", [4, 36, 64])
+def test_pair_l2_raw_entry_against_numpy(C):
+    """sg_pair_l2_hip through ops.pair_l2 against a float64 numpy evaluation of its definition: rows[s] = sum_j g_j
+    src[idx_j], g_j = scale * dev_scale * (<src[idx_j], other[s]> - y_j), loss = loss_scale * sum r_j^2; ragged segments
+    with empty ones, chunk-spanning segments, AddTo, and an edge-free plan."""
+    from star_gcn_amd import ops
+    rng = np.random.default_rng(C)
+    S, T, nnz = 300, 70, 5000
+    lens = rng.multinomial(nnz, rng.dirichlet(np.ones(S) * 0.2))
+    lens[5] += 900                                           # one segment over several 256-edge chunks
+    nnz = int(lens.sum())
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = rng.integers(0, T, nnz).astype(np.int32)
+    src = rng.normal(size=(T, C)).astype(np.float32)
+    other = rng.normal(size=(S, C)).astype(np.float32)
+    y = rng.normal(size=nnz).astype(np.float32)
+    seg = np.repeat(np.arange(S), lens)
+    r = (src[idx].astype(np.float64) * other[seg].astype(np.float64)).sum(1) - y
+    scale, dev_scale = 0.37, 1.7
+    want_rows = np.zeros((S, C))
+    np.add.at(want_rows, seg, (scale * dev_scale * r)[:, None] * src[idx].astype(np.float64))
+    want_loss = 0.25 * (r ** 2).sum()
+    ds = torch.tensor([dev_scale], device="cuda")
+    rows, loss = ops.pair_l2(dev(src), dev(other), dev(y), dev(idx), dev(indptr), S, scale, scale_dev=ds, loss_scale=0.25)
+    sc = float(np.abs(want_rows).max())
+    assert float((rows.cpu().double() - torch.from_numpy(want_rows)).abs().max()) <= 1e-5 * sc
+    assert abs(float(loss) - want_loss) <= 2e-6 * want_loss
+    acc = rows.clone()
+    ops.pair_l2(dev(src), dev(other), dev(y), dev(idx), dev(indptr), S, scale, scale_dev=ds, out=acc, req=ops.REQ_ADD)
+    assert float((acc.cpu().double() - 2 * torch.from_numpy(want_rows)).abs().max()) <= 2e-5 * sc
+    # no edges at all (one padding slot, as the plans carry): zero rows, zero loss
+    rows0, loss0 = ops.pair_l2(dev(src), dev(other), dev(np.zeros(1, np.float32)), dev(np.zeros(1, np.int32)),
+                               dev(np.zeros(S + 1, np.int32)), S, scale, loss_scale=1.0)
+    assert float(rows0.abs().max()) == 0.0 and float(loss0) == 0.0
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
