@@ -53,14 +53,21 @@ class _CommStats(object):
         self.reset()
 
     def reset(self):
-        self.bytes, self.calls, self.events, self.host_s = 0, 0, [], 0.0
+        self.bytes, self.calls, self.events, self.host_s, self.waits = 0, 0, [], 0.0, []
 
     def read(self):
-        ms = 0.0
+        """device_ms: time of the collectives on the communication stream; exposed_ms: time the COMPUTE stream spent
+        blocked on a collective's completion event (what overlap did not hide).  gloo runs are synchronous: all of
+        their time is exposed."""
+        ms = exposed = 0.0
         for a, b in self.events:
             b.synchronize()
             ms += a.elapsed_time(b)
-        return {"bytes": int(self.bytes), "calls": int(self.calls), "device_ms": ms + self.host_s * 1e3}
+        for a, b in self.waits:
+            b.synchronize()
+            exposed += a.elapsed_time(b)
+        return {"bytes": int(self.bytes), "calls": int(self.calls), "device_ms": ms + self.host_s * 1e3,
+                "exposed_ms": exposed + self.host_s * 1e3}
 
 
 STATS = _CommStats()
@@ -76,17 +83,36 @@ def comm_stream(device):
     return s
 
 
+def _wait_on(cur, done):
+    """make stream `cur` wait for event `done`; with statistics on, bracket the wait with two events on `cur` whose
+    distance is the time `cur` sat blocked (0 when the collective had already finished)"""
+    if STATS.enabled and not torch.cuda.is_current_stream_capturing():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(cur)
+        cur.wait_event(done)
+        b.record(cur)
+        STATS.waits.append((a, b))
+    else:
+        cur.wait_event(done)
+
+
 class _Pending(object):
-    """Completion handle of a collective launched on the communication stream (None event: already complete)."""
-    __slots__ = ("events",)
+    """Completion handle of collectives launched on the communication stream (no event: already complete).
+    `users` counts the crossings that were given this handle in the forward pass: a replicated tensor that feeds MORE
+    than one rank-local consumer must not hand out in-flight gradient buffers (autograd would add them on the compute
+    stream before the wait), so `_CopyToLocalAsync` falls back to a blocking all-reduce in that case."""
+    __slots__ = ("events", "users")
 
     def __init__(self):
         self.events = []
+        self.users = 0
 
     def wait(self):
-        for e in self.events:
-            torch.cuda.current_stream().wait_event(e)
-        self.events = []
+        if self.events:
+            cur = torch.cuda.current_stream()
+            for e in self.events:
+                _wait_on(cur, e)
+            self.events = []
 
 
 def _launch_sum(y, pending=None):
@@ -112,19 +138,20 @@ def _launch_sum(y, pending=None):
     cur = torch.cuda.current_stream(y.device)
     cs = comm_stream(y.device)
     cs.wait_stream(cur)
+    timed = STATS.enabled and not torch.cuda.is_current_stream_capturing()     # timing events cannot be captured
     with torch.cuda.stream(cs):
-        if STATS.enabled:
+        if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(cs)
         dist.all_reduce(y, op=dist.ReduceOp.SUM)
-        if STATS.enabled:
+        if timed:
             e1.record(cs)
             STATS.events.append((e0, e1))
         done = torch.cuda.Event()
         done.record(cs)
     y.record_stream(cs)
     if pending is None:
-        cur.wait_event(done)
+        _wait_on(cur, done)
     else:
         pending.events.append(done)
 
@@ -164,9 +191,16 @@ class _ReduceStart(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pending):
-        y = x.detach().contiguous().clone()
-        _launch_sum(y, pending)
-        return y
+        # IN PLACE: `x` is the aggregator's pre-activation partial, a fresh buffer that nothing else reads (the
+        # aggregator does not save an un-activated output, functional._MultiLinkAgg) -- no 1 GB clone per collective
+        # at config 5.  A view / non-contiguous input (never produced by the layers) still goes through a copy.
+        if x._base is not None or not x.is_contiguous():
+            y = x.detach().contiguous().clone()
+            _launch_sum(y, pending)
+            return y
+        ctx.mark_dirty(x)
+        _launch_sum(x, pending)
+        return x
 
     @staticmethod
     def backward(ctx, g):
@@ -209,8 +243,16 @@ class _CopyToLocalAsync(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        y = g.detach().contiguous().clone()
-        _launch_sum(y, ctx.pending)
+        # `g` is the data gradient the rank-local aggregator (or its dropout) has just produced: a fresh buffer owned by
+        # this edge of the graph, so it is summed over the ranks IN PLACE (views / strided gradients are copied first)
+        y = g if (g._base is None and g.is_contiguous()) else g.detach().contiguous().clone()
+        p = ctx.pending
+        if p.users > 1:
+            # more than one crossing shares this handle: autograd will ADD their gradients on the compute stream before
+            # `_GradWait` runs, so every buffer must be complete when it is returned -- blocking all-reduce
+            _launch_sum(y)
+        else:
+            _launch_sum(y, p)
         return y, None
 
 
@@ -245,7 +287,10 @@ def grad_wait(x):
 def copy_to_local_async(x, pending):
     if not _active():
         return x
-    return copy_to_local(x) if pending is None else _CopyToLocalAsync.apply(x, pending)
+    if pending is None:
+        return copy_to_local(x)
+    pending.users += 1
+    return _CopyToLocalAsync.apply(x, pending)
 
 
 def allreduce_grads(params):
@@ -285,19 +330,45 @@ def broadcast_parameters(params, src=0):
 
 
 _rep_generators = {}
+_rep_seed = [None]
+
+
+def set_replicated_seed(seed=None, src=0):
+    """Seed of the mask stream of `replicated_dropout`; every rank must end up with the SAME value.  seed=None: rank
+    `src` draws one from torch's default generator (so `torch.manual_seed` governs it) and broadcasts it.  Calling
+    it again resets the stream (e.g. between models, or to replay a run).  Returns the seed in use."""
+    if seed is None:
+        t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+        if _active() and dist.get_world_size() > 1:
+            if dist.get_backend() == "nccl":
+                d = t.cuda()
+                dist.broadcast(d, src=src)
+                t = d.cpu()
+            else:
+                dist.broadcast(t, src=src)
+        seed = int(t.item())
+    _rep_seed[0] = int(seed)
+    _rep_generators.clear()
+    return _rep_seed[0]
 
 
 def replicated_dropout(x, p, training):
     """Dropout for a REPLICATED tensor of a node-partitioned run: the mask comes from a generator that is seeded
-    identically on every rank and advanced by the same sequence of calls, so replicas stay identical (a per-rank
-    mask would let the replicated activations -- and the gradients of replicated parameters -- drift apart)."""
+    identically on every rank (`set_replicated_seed`) and advanced by the same sequence of calls, so replicas stay
+    identical (a per-rank mask would let the replicated activations -- and the gradients of replicated parameters --
+    drift apart).  The generator is not registered with a hipGraph: a step that uses dropout on replicated tensors
+    cannot be captured (the captured benchmark step runs with dropout 0, which returns before touching it)."""
     if not training or p <= 0.0:
         return x
+    if torch.cuda.is_available() and x.is_cuda and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("replicated_dropout cannot run inside a hipGraph capture (its generator is not graph-registered)")
+    if _rep_seed[0] is None:
+        set_replicated_seed()
     key = str(x.device)
     g = _rep_generators.get(key)
     if g is None:
         g = _rep_generators[key] = torch.Generator(device=x.device)
-        g.manual_seed(0x5747C0DE)
+        g.manual_seed(_rep_seed[0])
     keep = (torch.rand(x.shape, generator=g, device=x.device) >= p).to(x.dtype)
     return x * keep / (1.0 - p)
 

@@ -65,13 +65,20 @@ class _MultiLinkAgg(torch.autograd.Function):
         out, saved = ops.multilink_agg_fwd(x, weights, biases, plan, accum, act, slope, order)
         ctx.plan, ctx.accum, ctx.act, ctx.slope, ctx.order = plan, accum, act, slope, order
         ctx.saved_z = saved            # opaque native buffer (Zext of the aggregate-first order), not a graph tensor
-        ctx.save_for_backward(x, out, *weights)
+        # the output is only needed to evaluate act'; without an activation (the pre-activation partial of a
+        # node-partitioned run) it is NOT saved, so dist.reduce_start may all-reduce it in place
+        ctx.has_out = ops._act_id(act) != 0
+        if ctx.has_out:
+            ctx.save_for_backward(x, out, *weights)
+        else:
+            ctx.save_for_backward(x, *weights)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, out = ctx.saved_tensors[:2]
-        weights = list(ctx.saved_tensors[2:])
+        x = ctx.saved_tensors[0]
+        out = ctx.saved_tensors[1] if ctx.has_out else None
+        weights = list(ctx.saved_tensors[2 if ctx.has_out else 1:])
         R = ctx.plan.R
         need_dw = any(ctx.needs_input_grad[6:6 + R])
         need_db = any(ctx.needs_input_grad[6 + R:6 + 2 * R])

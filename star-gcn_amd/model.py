@@ -199,7 +199,9 @@ def _cached_targets(self, tag, y, pos):
     key = (tag, y.data_ptr(), y._version, y.numel())
     c = getattr(self, "_y_cache", None)
     if c is None or c[0] != key:
-        c = (key, y[pos.long()].contiguous())
+        # the entry holds `y` itself: while it is cached its storage cannot be recycled for another target tensor that
+        # would present the same (address, version, size) key
+        c = (key, y[pos.long()].contiguous(), y)
         self._y_cache = c if getattr(self, "reused", False) else None
     return c[1]
 

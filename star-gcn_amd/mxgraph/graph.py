@@ -253,7 +253,15 @@ class CSRMat(object):
         cols = None if col_indices is None else _i32(np.atleast_1d(col_indices))
         if rows is None and cols is None:
             return CSRMat(self.end_points.copy(), self.ind_ptr.copy(), self.row_ids.copy(), self.col_ids.copy(),
-                          self.values.copy(), self.multi_link)
+                          self.values.copy(), self.multi_link, support_row_degrees=self._sup_rd,
+                          support_col_degrees=self._sup_cd)
+        # A rank-local block normalises with override (GLOBAL) degrees.  Selecting columns keeps the override of the
+        # kept columns exact; selecting ROWS changes the column degrees by an amount only the other ranks know (and vice
+        # versa) -- that is an error, never a silent fall-back to rank-local degrees (same rule as remove_edges_by_id /
+        # ResidentPlan).
+        if (rows is not None and self._sup_cd is not None) or (cols is not None and self._sup_rd is not None):
+            raise ValueError("submat: slicing a rank-local block across its override support degrees needs the degrees "
+                             "of the sliced graph from all ranks; slice the global graph, then take the block")
         col_map = None
         if cols is not None:
             if np.unique(cols).size != cols.size:
@@ -269,8 +277,11 @@ class CSRMat(object):
                                           _vp(self.values), _vp(self.ind_ptr), self.shape[0],
                                           None if rows is None else _vp(rows), n, None if col_map is None else _vp(col_map)),
                 "sg_csr_submat_cpu")
+        sup_rd = None if self._sup_rd is None else (self._sup_rd if rows is None else self._sup_rd[rows])
+        sup_cd = None if self._sup_cd is None else (self._sup_cd if cols is None else self._sup_cd[cols])
         return CSRMat(ep[:m.value], ind_ptr, self.row_ids if rows is None else self.row_ids[rows],
-                      self.col_ids if cols is None else self.col_ids[cols], vals[:m.value], self.multi_link)
+                      self.col_ids if cols is None else self.col_ids[cols], vals[:m.value], self.multi_link,
+                      support_row_degrees=sup_rd, support_col_degrees=sup_cd)
 
     def submat_by_id(self, row_ids=None, col_ids=None):
         """reference graph.py:535-538"""
@@ -381,7 +392,7 @@ class CSRMat(object):
         sup_rd, sup_cd = self._sup_rd, self._sup_cd
         if sup_rd is not None or sup_cd is not None:
             if degree_reducer is None:
-                from .._native import dist as D
+                from ._native import dist as D
                 if D.world() > 1:
                     raise ValueError("remove_edges_by_id on a rank-local block (override support degrees) needs a "
                                      "degree_reducer in a multi-rank run")

@@ -122,3 +122,62 @@ def test_single_process_helpers_are_identity():
     assert SD.replicated_dropout(x, 0.5, training=False) is x
     d1 = SD.replicated_dropout(torch.ones(64, 8), 0.5, training=True)
     assert set(d1.unique().tolist()) <= {0.0, 2.0}
+
+
+def _worker_two_consumers(rank, world, port, out_dir):
+    """A replicated tensor that feeds TWO rank-local consumers through the asynchronous crossing: autograd adds the two
+    gradient buffers before `_GradWait` runs, so the crossing must hand out completed buffers (blocking fallback)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import star_gcn_amd.dist as SD
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 4, generator=g).double().requires_grad_(True)           # replicated
+    a = torch.randn(2, 5, 6, generator=g).double()[rank]                        # rank-local operators
+    b = torch.randn(2, 3, 6, generator=g).double()[rank]
+    xw, pend = SD.grad_wait(x)
+    y1 = a @ SD.copy_to_local_async(xw, pend)
+    y2 = b @ SD.copy_to_local_async(xw, pend)
+    assert pend.users == 2
+    (y1.sum() * 2.0 + (y2 ** 2).sum()).backward()
+    torch.save({"gx": x.grad}, os.path.join(out_dir, "c%d.pt" % rank))
+    # the seed of the replicated dropout stream: drawn on rank 0, identical everywhere, re-settable
+    torch.manual_seed(100 + rank)
+    s = SD.set_replicated_seed()
+    m1 = SD.replicated_dropout(torch.ones(32, 8), 0.5, True)
+    SD.set_replicated_seed(s)
+    m2 = SD.replicated_dropout(torch.ones(32, 8), 0.5, True)
+    assert torch.equal(m1, m2)
+    torch.save({"seed": s, "mask": m1}, os.path.join(out_dir, "s%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_replicated_tensor_with_two_local_consumers(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_two_consumers, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 4, generator=g).double().requires_grad_(True)
+    a = torch.randn(2, 5, 6, generator=g).double()
+    b = torch.randn(2, 3, 6, generator=g).double()
+    loss = sum((a[r] @ x).sum() * 2.0 + ((b[r] @ x) ** 2).sum() for r in range(2))
+    loss.backward()
+    got = [torch.load(os.path.join(str(tmp_path), "c%d.pt" % r)) for r in range(2)]
+    for r in range(2):
+        assert torch.allclose(got[r]["gx"], x.grad, rtol=1e-10, atol=1e-12)
+    s = [torch.load(os.path.join(str(tmp_path), "s%d.pt" % r)) for r in range(2)]
+    assert s[0]["seed"] == s[1]["seed"] and torch.equal(s[0]["mask"], s[1]["mask"])
+
+
+def test_replicated_dropout_seed_follows_torch_manual_seed():
+    import star_gcn_amd.dist as SD
+    torch.manual_seed(7)
+    s1 = SD.set_replicated_seed()
+    a = SD.replicated_dropout(torch.ones(64, 8), 0.5, True)
+    torch.manual_seed(7)
+    s2 = SD.set_replicated_seed()
+    b = SD.replicated_dropout(torch.ones(64, 8), 0.5, True)
+    torch.manual_seed(8)
+    s3 = SD.set_replicated_seed()
+    assert s1 == s2 and torch.equal(a, b) and s3 != s1
+    SD.set_replicated_seed(12345)
+    assert SD._rep_seed[0] == 12345

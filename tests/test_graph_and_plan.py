@@ -289,3 +289,95 @@ def test_native_batch_plan_builders_match_numpy():
     assert not TakePlan(np.arange(6, dtype=np.int32), 7, "cpu").identity
     with pytest.raises(Exception):
         TakePlan(np.array([9], np.int32), 9, "cpu")
+
+
+def test_override_degree_blocks_removal_and_slicing():
+    """Rank-local user blocks carry GLOBAL item degrees for the support (CSRMat(support_col_degrees=...)).  They must
+    survive edge removal (without a reducer in a single-process run, with one when several ranks remove edges) and
+    slicing -- never a silent fall-back to the block's own degrees."""
+    graph, eu, ei, vals = small_graph(seed=11, nu=40, ni=15, ne=300)
+    m = graph["user", "movie"]
+    lo, hi = 7, 29
+    sub = S.user_block(graph, "user", "movie", lo, hi)
+    a, b = int(m.ind_ptr[lo]), int(m.ind_ptr[hi])
+    # remove every third edge of the block: ids of a block are LOCAL user indices / global item ids
+    pos = np.arange(0, sub.nnz, 3)
+    pairs = np.stack([sub.row_ids[sub.edge_row_indices[pos]], sub.col_ids[sub.end_points[pos]]])
+    # reference result: the same removal on the whole graph (global user ids), restricted to the block
+    gpairs = np.stack([pairs[0] + lo, pairs[1]])
+    whole = m.remove_edges_by_id(gpairs)
+    wa, wb = int(whole.ind_ptr[lo]), int(whole.ind_ptr[hi])
+    # (1) single process, no reducer: the override degrees drop by the removed edges
+    cut = sub.remove_edges_by_id(pairs)
+    assert np.array_equal(cut.end_points, whole.end_points[wa:wb])
+    assert np.array_equal(cut.get_support(True), whole.get_support(True)[wa:wb])
+    # (2) with a reducer (here: another "rank" removed nothing, the sum is the identity) -- same result
+    calls = []
+    cut2 = sub.remove_edges_by_id(pairs, degree_reducer=lambda d: (calls.append(d.sum()), d)[1])
+    assert calls and np.array_equal(cut2.get_support(True), cut.get_support(True))
+    # (3) the transposed block (item -> local users) carries the override as ROW degrees
+    tcut = sub.T.remove_edges_by_id(pairs[::-1])
+    gt = whole.T
+    mask = (gt.end_points >= lo) & (gt.end_points < hi)
+    assert np.array_equal(tcut.get_support(True), gt.get_support(True)[mask])
+    # (4) slicing: a column selection keeps the override of the kept columns; a row selection would need the other
+    # ranks' counts and is refused (for the transposed block the roles swap)
+    cols = np.array([14, 0, 5, 9, 2], np.int32)
+    sl = sub.submat(None, cols)
+    gsl = m.submat(None, cols)                      # same slice of the global graph: its own degrees ARE the global ones
+    ga, gb = int(gsl.ind_ptr[lo]), int(gsl.ind_ptr[hi])
+    assert np.array_equal(sl.end_points, gsl.end_points[ga:gb])
+    # the override is the column degree of the UNSLICED global graph for the kept columns
+    want = np.sqrt(np.float32(1.0) / sl.row_degrees[sl.edge_row_indices].astype(np.float32)
+                   / m.col_degrees[cols][sl.end_points].astype(np.float32))
+    assert np.array_equal(sl.get_support(True), want.astype(np.float32))
+    with pytest.raises(ValueError):
+        sub.submat(np.arange(3, 10, dtype=np.int32), None)
+    with pytest.raises(ValueError):
+        sub.T.submat(None, np.arange(3, 10, dtype=np.int32))
+    assert np.array_equal(sub.submat().get_support(True), sub.get_support(True))
+
+
+def test_override_degree_block_needs_reducer_in_multi_rank_run(tmp_path):
+    """remove_edges_by_id on a rank-local block without a degree_reducer is an ERROR when more than one rank runs."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, %r)
+import star_gcn_amd.synthetic as S
+rank = int(sys.argv[1])
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=2)
+graph, eu, ei, vals = S.make_graph("custom", seed=3, n_user=20, n_item=9, n_edges=80, n_levels=3)
+sub = S.user_block(graph, "user", "movie", rank * 10, rank * 10 + 10)
+pairs = np.stack([sub.row_ids[sub.edge_row_indices[:2]], sub.col_ids[sub.end_points[:2]]])
+try:
+    sub.remove_edges_by_id(pairs)
+    print("NOERROR")
+except ValueError as e:
+    print("RAISED", "degree_reducer" in str(e))
+def reducer(d):
+    import torch
+    t = torch.from_numpy(d.copy())
+    dist.all_reduce(t)
+    return t.numpy()
+cut = sub.remove_edges_by_id(pairs, degree_reducer=reducer)
+print("NNZ", cut.nnz, sub.nnz)
+dist.destroy_process_group()
+''' % ROOT
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(port)], stdout=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "RAISED True" in o and "NOERROR" not in o, o
+        nnz = [int(x) for x in o.split("NNZ")[1].split()]
+        assert nnz[0] == nnz[1] - 2
