@@ -121,6 +121,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-hbm-leg", action="store_true")
     p.add_argument("--no-ceiling", action="store_true")
+    p.add_argument("--no-verify", action="store_true", help="skip the float64 verification of both legs (profiling runs)")
     p.add_argument("--graph-replay", action="store_true",
                    help="also time the step as ONE hipGraph replay (secondary figure `graph_replay`; opt-in: stream capture of "
                         "an autograd step depends on the torch build)")
@@ -178,6 +179,38 @@ def build_net(graph_like, D, order, dev, part=None):
     return net
 
 
+VERIFY_TOL = 1e-5      # north star: "within 1e-5 fp32 on embeddings"; max |err| relative to each tensor's scale
+
+
+def prepare_net(net, step, forward, seed, rows, reduce=None):
+    """Materialise the lazily-shaped parameters (one step), re-draw every parameter by NAME (identical replicated
+    parameters on every rank, equal to the N = 1 model's), then calibrate the layer scales so that activations, scores
+    and therefore the loss are O(1) and depend on what the network computes (model.calibrate_output_scale)."""
+    import star_gcn_amd.model as M
+    step()
+    M.deterministic_init(net, seed, rows)
+    return M.calibrate_output_scale(net, forward, reduce=reduce)
+
+
+def verify_leg(net, step, arrays, y, scale):
+    """One extra step with capture hooks, compared tensor by tensor with the float64 evaluation of the network's
+    DEFINITION over the whole graph (tools/f64_check.py: plain torch float64 on the device, none of the product's
+    kernels or plans).  Outside every timed region."""
+    from tools import f64_check as FC
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = FC.verify_step(net, step, arrays, y, scale, U, I)
+    torch.cuda.synchronize()
+    out["seconds"] = round(time.perf_counter() - t0, 2)
+    out["tolerance"] = VERIFY_TOL
+    out["ok"] = bool(out["max_rel_err"] <= VERIFY_TOL)
+    out["method"] = ("float64 evaluation of the definition (aggregators.py:141-160, layers.py:147-187, STAR-GCN.py:428-438) "
+                     "over the whole graph, forward and hand-written backward, by tools/f64_check.py; every layer output "
+                     "row of both node types, both rating projections, every embedding-gradient row and every weight / bias "
+                     "gradient compared; error = max |fp32 - fp64| / max |fp64| per tensor")
+    return out
+
+
 def timed_steps(step, steps, warmup, dev, dist_on):
     import torch.distributed as dist
     import star_gcn_amd.dist as SD
@@ -191,10 +224,13 @@ def timed_steps(step, steps, warmup, dev, dist_on):
     ops.gather_profile(True)      # HIP events around every gather launch, on the launch stream, inside the library
     SD.STATS.reset()
     SD.STATS.enabled = dist_on
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]     # step boundaries on the compute stream
     t0 = time.perf_counter()
     loss = None
-    for _ in range(steps):
+    marks[0].record()
+    for k in range(steps):
         loss = step()
+        marks[k + 1].record()
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -202,6 +238,9 @@ def timed_steps(step, steps, warmup, dev, dist_on):
     elapsed = time.perf_counter() - t0
     ops.gather_profile(False)
     SD.STATS.enabled = False
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps))
+    timed_steps.last_median_ms = per_step[len(per_step) // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
+    timed_steps.last_min_ms, timed_steps.last_max_ms = per_step[0], per_step[-1]
     return elapsed, loss, ops.gather_profile_read(with_src_bytes=True)
 
 
@@ -269,29 +308,48 @@ def measure_stream_ceiling(dev, n_bytes, workgroups, bursts=256):
     return best
 
 
-def profile_record(name):
+def _sha16(path):
+    import hashlib
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(name)
-    except (OSError, ValueError):
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
         return None
 
 
+def profile_record(name):
+    """PMC traffic of the gather (profiles/pmc_traffic.json, reduced from committed rocprofv3 --pmc passes).  The record
+    carries the sha of the kernel source it was measured on; when csrc/seg_gather.hip has changed since, the counters
+    describe another kernel and `traffic` is reported as null instead of going stale silently."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get(name)
+    except (OSError, ValueError):
+        return None
+    if not rec:
+        return None
+    now = _sha16(os.path.join(ROOT, "star-gcn_amd", "csrc", "seg_gather.hip"))
+    if rec.get("kernel_source_sha16") != now:
+        return {"stale": True, "source": "%s measured on seg_gather.hip %s, current source is %s: traffic withheld" %
+                (rec.get("source", "profiles/pmc_traffic.json"), rec.get("kernel_source_sha16"), now)}
+    return rec
+
+
 # ---------------------------------------------------------------------------------------------------------------------
-def hbm_leg(args, dev):
+def hbm_case(hbm_shape, D, order, dev):
     """BASELINE config 5 on ONE GPU of the 8: 1.25 M users x 1 M items, >= 125 M ratings, 16 levels, dim 256.  Graph,
-    degrees, support, transposed CSR and both multi-link plans are generated / built on the device."""
-    import star_gcn_amd.functional as SF
+    degrees, support, transposed CSR and both multi-link plans are generated / built on the device; the network is
+    initialised by parameter name and scale-calibrated.  Shared by the benchmark leg and tests/test_gpu_bench_verify.py."""
+    import types
     from star_gcn_amd.device_graph import synthetic_device_graph
-    nu, ni, ne, R = (int(x) for x in args.hbm_shape.split(","))
-    D = args.dim
+    nu, ni, ne, R = (int(x) for x in hbm_shape.split(","))
     t0 = time.perf_counter()
     dg = synthetic_device_graph(nu, ni, ne, R, dev, seed=5)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     torch.manual_seed(4321)
-    net = build_net(dg, D, args.order, dev)
+    net = build_net(dg, D, order, dev)
     plan = net.make_plan_device(dg)
     torch.cuda.synchronize()
     t_plan = time.perf_counter() - t0
@@ -307,6 +365,17 @@ def hbm_leg(args, dev):
         loss.backward()
         return loss
 
+    calib = prepare_net(net, step, lambda: net.run(plan, rating_targets=y, rating_scale=1.0 / E), 4321,
+                        {U: (0, nu, nu), I: (0, ni, ni)})
+    return types.SimpleNamespace(nu=nu, ni=ni, R=R, D=D, dg=dg, net=net, plan=plan, y=y, E=E, step=step, calib=calib,
+                                 t_gen=t_gen, t_plan=t_plan)
+
+
+def hbm_leg(args, dev):
+    c = hbm_case(args.hbm_shape, args.dim, args.order, dev)
+    nu, ni, R, D, dg, net, plan, y, E, step, calib, t_gen, t_plan = (c.nu, c.ni, c.R, c.D, c.dg, c.net, c.plan, c.y, c.E,
+                                                                       c.step, c.calib, c.t_gen, c.t_plan)
+    del c
     elapsed, loss, timeline = timed_steps(step, args.hbm_steps, 1, dev, False)
     roof = gather_roofline(timeline, E, D, args.hbm_steps)
     src_small = min(nu, ni) * D * 4
@@ -314,19 +383,27 @@ def hbm_leg(args, dev):
                        "%d ratings, %d rating levels, dim %d; same 2-layer network, fwd+bwd; graph generated and planned "
                        "on the device" % (nu, ni, E, R, D),
            "steps": args.hbm_steps, "warmup": 1, "ms_per_step": elapsed / args.hbm_steps * 1e3,
+           "ms_per_step_median_events": timed_steps.last_median_ms,
            "edges_per_s": E / (elapsed / args.hbm_steps), "loss": float(loss.detach()),
            "graph_gen_s": round(t_gen, 2), "plan_build_s": round(t_plan, 2),
            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
            "smallest_gathered_matrix_mb": src_small // 2 ** 20}
     if roof:
         rec = profile_record("hbm-config5-shard:%d" % D)
+        live = rec and not rec.get("stale")
         roof.update(bound="hbm", peak=HBM_PEAK / 1e9, frac=roof["achieved"] * 1e9 / HBM_PEAK,
-                    traffic=(rec["traffic_bytes_per_launch_mean"] * (E / rec["edges_per_launch"]) if rec else None),
+                    traffic=(rec["traffic_bytes_per_launch_mean"] * (E / rec["edges_per_launch"]) if live else None),
                     traffic_source=(rec.get("source") if rec else None))
         roof.pop("_classes", None)
         out["roofline"] = roof
         out["step_roofline_frac"] = out["edges_per_s"] * 8 * (8 + 4 * D) / HBM_PEAK
-    del net, plan, dg, y
+    if not args.no_verify:
+        del loss
+        out["verify"] = verify_leg(net, step, (dg.ind_ptr, dg.end_points, dg.level, ni, R, None), y, 1.0 / E)
+    out["init"] = "embeddings U(-0.1, 0.1), Xavier-in weights, zero biases, then layer-sequential scale calibration " \
+                  "(model.calibrate_output_scale); pre-calibration rms per stage: %s" % json.dumps(
+                      [{k: float("%.3g" % v) for k, v in st.items()} for st in calib])
+    del net, plan, dg, y, step
     torch.cuda.empty_cache()
     return out
 
@@ -386,11 +463,12 @@ def run_config5(args, dev, dist_on, world, rank, backend):
             SD.allreduce_grads(net.local_region_parameters())
         return loss
 
-    step()
     # replicated parameters (and, for simplicity, the user tables) drawn by parameter NAME: identical on every rank
-    M.deterministic_init(net, 1234, {U: (0, nu, nu), I: (0, ni, ni)})
+    prepare_net(net, step, lambda: net.run(plan, rating_targets=y, rating_scale=1.0 / E_total), 1234,
+                {U: (0, nu, nu), I: (0, ni, ni)}, reduce=SD.all_reduce_sum if dist_on else None)
     elapsed, loss, timeline = timed_steps(step, args.steps, args.warmup, dev, dist_on)
     comm = SD.STATS.read() if dist_on else None
+    rank_ms = [elapsed / args.steps * 1e3]
     loss_total = loss.detach().clone()
     edges_per_rank = [E_local]
     if dist_on:
@@ -399,8 +477,10 @@ def run_config5(args, dev, dist_on, world, rank, backend):
         elapsed = float(tmax.item())
         loss_total = SD.all_reduce_sum(loss_total.view(1))[0]
         gathered = [None] * world
-        dist.all_gather_object(gathered, E_local)
-        edges_per_rank = [int(e) for e in gathered]
+        dist.all_gather_object(gathered, (E_local, rank_ms[0], comm["exposed_ms"] / args.steps))
+        edges_per_rank = [int(e[0]) for e in gathered]
+        rank_ms = [float(e[1]) for e in gathered]
+        exposed_ms = [float(e[2]) for e in gathered]
     roof = gather_roofline(timeline, E_local, D, args.steps)
     if roof:
         roof.update(bound="hbm", peak=HBM_PEAK / 1e9, frac=roof["achieved"] * 1e9 / HBM_PEAK, traffic=None)
@@ -424,11 +504,68 @@ def run_config5(args, dev, dist_on, world, rank, backend):
         out["collectives"] = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
                               "calls_per_step": comm["calls"] / args.steps,
                               "allreduce_bytes_per_step": comm["bytes"] / args.steps,
-                              "collective_ms_per_step": comm["device_ms"] / args.steps}
+                              "collective_ms_per_step": comm["device_ms"] / args.steps,
+                              "exposed_ms_per_step_per_rank": exposed_ms}
+        out["ms_per_step_per_rank"] = rank_ms
+    out["ms_per_step_median_events"] = timed_steps.last_median_ms
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()
+
+
+def main_case(shape, D_, order, dev, dist_on=False, world=1, rank=0):
+    """The headline workload, ready to step: graph of `shape` (SURVEY 8(d) recipe), this rank's user block uploaded once,
+    plans built on the device, network initialised (by parameter name) and scale-calibrated.  Used by run_rank and by
+    tests/test_gpu_bench_verify.py, so the test exercises exactly what the benchmark times."""
+    import types
+    import star_gcn_amd.dist as SD
+    import star_gcn_amd.synthetic as S
+    from star_gcn_amd.device_graph import DeviceBipartite
+    from star_gcn_amd.mxgraph.graph import HeterGraph
+    graph, eu, ei, vals = S.make_graph(shape)
+    csr = graph[U, I]
+    n_user, n_item, E_total, R = csr.shape[0], csr.shape[1], csr.nnz, int(csr.multi_link.size)
+    mean, std = float(vals.mean()), float(vals.std())
+    lo, hi = 0, n_user
+    # SG_BENCH_EMULATE_WORLD=N (development, one process): run rank 0's share of an N-rank partition through the
+    # partitioned code path -- what ONE rank of the N-GPU strong-scaling run computes per step, without the other ranks
+    emulate = int(os.environ.get("SG_BENCH_EMULATE_WORLD", "0")) if world == 1 else 0
+    if dist_on:
+        lo, hi = SD.balanced_row_blocks(csr.ind_ptr, emulate if emulate > 1 else world)[rank]
+        sub = S.user_block(graph, U, I, lo, hi)       # this rank's users x ALL items, GLOBAL item degrees for the support
+        lgraph = HeterGraph({U: np.arange(hi - lo, dtype=np.int32), I: np.arange(n_item, dtype=np.int32)}, {(U, I): sub})
+    else:
+        lgraph, sub = graph, csr
+    E_local = sub.nnz
+    y = torch.from_numpy(((sub.values - mean) / std).astype(np.float32)).to(dev)
+
+    D = D_
+    part = SD.NodePartition([U], [I]) if dist_on else None
+    torch.manual_seed(1234)
+    net = build_net(lgraph, D, order, dev, part)
+    t_plan = time.perf_counter()
+    dgraph = DeviceBipartite.from_host(lgraph, U, I, dev)     # one upload of the CSR; every plan is built on the device
+    plan = net.make_plan_device(dgraph)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter() - t_plan
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        losses, _, _ = net.run(plan, rating_targets=y, rating_scale=1.0 / E_total)   # = l2_loss(scores, y, 1 / E)
+        loss = losses[0]
+        loss.backward()
+        if dist_on:
+            SD.allreduce_grads(net.local_region_parameters())
+        return loss
+
+    # one step materialises the lazily-shaped parameters, which are then re-drawn by parameter NAME: identical
+    # replicated parameters on every rank, equal to the N = 1 model's, whatever the rank-local row counts and the order
+    # of first use (user table = rows [lo, hi) of the global one); then the layer scales are calibrated (global rms)
+    calib = prepare_net(net, step, lambda: net.run(plan, rating_targets=y, rating_scale=1.0 / E_total), 1234,
+                        {U: (lo, hi, n_user), I: (0, n_item, n_item)}, reduce=SD.all_reduce_sum if dist_on else None)
+    return types.SimpleNamespace(**{k: v for k, v in locals().items() if k not in ("types", "SD", "S", "DeviceBipartite",
+                                                                                  "HeterGraph")})
 
 
 def run_rank(args):
@@ -474,46 +611,12 @@ def run_rank(args):
         run_config5(args, dev, dist_on, world, rank, backend)
         return
 
-    graph, eu, ei, vals = S.make_graph(args.shape)
-    csr = graph[U, I]
-    n_user, n_item, E_total, R = csr.shape[0], csr.shape[1], csr.nnz, int(csr.multi_link.size)
-    mean, std = float(vals.mean()), float(vals.std())
-    lo, hi = 0, n_user
-    # SG_BENCH_EMULATE_WORLD=N (development, one process): run rank 0's share of an N-rank partition through the
-    # partitioned code path -- what ONE rank of the N-GPU strong-scaling run computes per step, without the other ranks
-    emulate = int(os.environ.get("SG_BENCH_EMULATE_WORLD", "0")) if world == 1 else 0
-    if dist_on:
-        lo, hi = SD.balanced_row_blocks(csr.ind_ptr, emulate if emulate > 1 else world)[rank]
-        sub = S.user_block(graph, U, I, lo, hi)       # this rank's users x ALL items, GLOBAL item degrees for the support
-        lgraph = HeterGraph({U: np.arange(hi - lo, dtype=np.int32), I: np.arange(n_item, dtype=np.int32)}, {(U, I): sub})
-    else:
-        lgraph, sub = graph, csr
-    E_local = sub.nnz
-    y = torch.from_numpy(((sub.values - mean) / std).astype(np.float32)).to(dev)
-
-    D = args.dim
-    part = SD.NodePartition([U], [I]) if dist_on else None
-    torch.manual_seed(1234)
-    net = build_net(lgraph, D, args.order, dev, part)
-    t_plan = time.perf_counter()
-    dgraph = DeviceBipartite.from_host(lgraph, U, I, dev)     # one upload of the CSR; every plan is built on the device
-    plan = net.make_plan_device(dgraph)
-    torch.cuda.synchronize()
-    t_plan = time.perf_counter() - t_plan
-
-    def step():
-        net.zero_grad(set_to_none=True)
-        losses, _, _ = net.run(plan, rating_targets=y, rating_scale=1.0 / E_total)   # = l2_loss(scores, y, 1 / E)
-        loss = losses[0]
-        loss.backward()
-        if dist_on:
-            SD.allreduce_grads(net.local_region_parameters())
-        return loss
-
-    step()      # materialises the lazily-shaped parameters ...
-    # ... which are then re-drawn by parameter NAME: identical replicated parameters on every rank, equal to the N = 1
-    # model's, whatever the rank-local row counts and the order of first use (user table = rows [lo, hi) of the global one)
-    M.deterministic_init(net, 1234, {U: (lo, hi, n_user), I: (0, n_item, n_item)})
+    c = main_case(args.shape, args.dim, args.order, dev, dist_on, world, rank)
+    graph, csr, sub, lgraph, dgraph, net, plan, y, step, calib = (c.graph, c.csr, c.sub, c.lgraph, c.dgraph, c.net,
+                                                                  c.plan, c.y, c.step, c.calib)
+    n_user, n_item, E_total, E_local, R, D, lo, hi, t_plan = (c.n_user, c.n_item, c.E_total, c.E_local, c.R, c.D, c.lo,
+                                                               c.hi, c.t_plan)
+    del c
     if dist_on and world > 1:      # replicas must agree bit for bit: check once
         skip = "embed_layers._layers.%d." % net.embed_layers._key2idx[U]        # the row-sharded user table
         rep = [p.detach().double().sum() for n_, p in net.named_parameters() if skip not in n_]
@@ -527,6 +630,7 @@ def run_rank(args):
 
     elapsed, loss, timeline = timed_steps(step, args.steps, args.warmup, dev, dist_on)
     comm = SD.STATS.read() if dist_on else None
+    rank_ms = [elapsed / args.steps * 1e3]
     if dist_on:
         tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -541,7 +645,8 @@ def run_rank(args):
         roof["hbm_equiv_frac"] = roof["achieved"] * 1e9 / HBM_PEAK     # secondary: algorithmic bytes over the HBM peak
         roof["gathered_matrices_mb"] = src_mb
         rec = profile_record("%s:%d" % (args.shape, D)) if world == 1 else None
-        roof["traffic"] = rec["traffic_bytes_per_launch_mean"] * (E_local / rec["edges_per_launch"]) if rec else None
+        live = rec and not rec.get("stale")
+        roof["traffic"] = rec["traffic_bytes_per_launch_mean"] * (E_local / rec["edges_per_launch"]) if live else None
         roof["traffic_source"] = rec.get("source") if rec else None
         if cache_resident and not args.no_ceiling and world == 1:
             # ceiling of every launch class = the same bytes at the rate of a best-case streaming read, measured NOW, of
@@ -576,14 +681,18 @@ def run_rank(args):
     if dist_on:      # every rank holds its users' share of the loss; report the whole (outside the timed region)
         loss_total = SD.all_reduce_sum(loss_total.view(1))[0]
         gathered = [None] * world
-        dist.all_gather_object(gathered, E_local)
-        edges_per_rank = [int(e) for e in gathered]
+        dist.all_gather_object(gathered, (E_local, rank_ms[0], comm["exposed_ms"] / args.steps))
+        edges_per_rank = [int(e[0]) for e in gathered]
+        rank_ms = [float(e[1]) for e in gathered]
+        exposed_ms = [float(e[2]) for e in gathered]
     ms = elapsed / args.steps * 1e3
     value = E_total / (elapsed / args.steps)
     out = {
         "metric": METRIC,
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": ms, "ms_per_step_median_events": timed_steps.last_median_ms,
+        "ms_per_step_min_max_events": [timed_steps.last_min_ms, timed_steps.last_max_ms],
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s-shaped synthetic bipartite graph: %d users x %d items, %d ratings, %d rating levels, "
                                "dim %d; 2 stacked HeterGCNLayers (sum accum, symm support, leaky 0.1), both node types, "
@@ -597,6 +706,10 @@ def run_rank(args):
                                   "registers (sg_pair_l2_hip); same value / gradients as scores + L2 loss, no per-pair "
                                   "array is written",
                    "loss": float(loss_total), "edges_per_rank": edges_per_rank,
+                   "init": "embeddings U(-0.1, 0.1), Xavier-in weights, zero biases (by parameter name), then "
+                           "layer-sequential scale calibration (model.calibrate_output_scale: outputs rms 1, scores "
+                           "O(1)) so that the loss depends on the scores; pre-calibration rms per stage: %s" % json.dumps(
+                               [{k: float("%.3g" % v) for k, v in st.items()} for st in calib]),
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
         "roofline": roof,
         "step_roofline_frac": value * 8 * (8 + 4 * D) / (world * HBM_PEAK),
@@ -606,8 +719,11 @@ def run_rank(args):
                               "calls_per_step": comm["calls"] / args.steps,
                               "allreduce_bytes_per_step": comm["bytes"] / args.steps,
                               "collective_ms_per_step": comm["device_ms"] / args.steps,
-                              "note": "rank-0 view; device time of the collectives on the communication stream (they "
-                                      "overlap compute, so this is not exposed time)"}
+                              "exposed_ms_per_step_per_rank": exposed_ms,
+                              "note": "calls / bytes / collective_ms: rank-0 view, device time of the collectives on the "
+                                      "communication stream (they overlap compute); exposed_ms: per rank, time the "
+                                      "compute stream sat blocked on a collective's completion event"}
+        out["ms_per_step_per_rank"] = rank_ms
     if world == 1 and not dist_on and args.graph_replay:
         # secondary figure: the same step as ONE hipGraph replay (the library's launches captured through
         # torch.cuda.CUDAGraph, as examples/train_star_gcn.py --graph does for the whole training iteration).  Not the
@@ -617,8 +733,12 @@ def run_rank(args):
             out["graph_replay"] = graph_replay(step, dev, args.steps)
         except Exception as e:      # capture support is a property of the torch build, not of the path
             out["graph_replay"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    if world == 1 and not dist_on and not args.no_verify:
+        loss = None
+        out["verify"] = verify_leg(net, step, (dgraph.ind_ptr, dgraph.end_points, dgraph.level, n_item, R, None), y,
+                                   1.0 / E_total)
     # free the main leg before the big one
-    del net, plan, dgraph, y
+    del net, plan, dgraph, y, step
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_hbm_leg:
         torch.cuda.reset_peak_memory_stats(dev)

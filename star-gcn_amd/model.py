@@ -507,3 +507,57 @@ def deterministic_init(net, seed=1234, embedding_rows=None):
                 p.copy_(((torch.rand(p.shape, generator=g) * 2 - 1) * s).to(p.device))
             else:
                 p.zero_()
+
+
+def calibrate_output_scale(net, run_forward, target=1.0, reduce=None):
+    """Layer-sequential scale calibration of a freshly initialised benchmark network (LSUV-style, Mishkin & Matas
+    2015, without the orthogonalisation): with the reference's init (embeddings U(-0.1, 0.1), Xavier-in weights, zero
+    biases; STAR-GCN.py:180, 548) the symmetric normalisation sqrt(1/d_u/d_i) shrinks every aggregation of a
+    MovieLens-shaped graph by 1-2 orders of magnitude, the scores of a 2-layer network come out ~1e-6 and the loss is
+    0.5 var(y) to seven digits whatever the network computes.  Going through the layers in order, the per-level
+    aggregator weights of each node type are rescaled so that the layer's OUTPUT has root-mean-square `target`; last,
+    the rating projections are rescaled so that the scores have unit scale (each projection to rms width^-1/4).
+    Biases are zero and LeakyReLU is positively homogeneous, so one forward pass per stage gives the exact factor.
+
+    run_forward(): one forward pass of the network (no gradients needed).  reduce(t) -> t summed over the ranks of a
+    node-partitioned run (rank-local node types need the global mean square; replicated types are unaffected because
+    numerator and denominator grow alike).  Returns the measured rms values, stage by stage (before rescaling)."""
+    report = []
+
+    def rms_of(mods):
+        acc = dict()
+        hooks = [m.register_forward_hook(lambda _m, _i, o, k=k: acc.__setitem__(
+            k, torch.stack([o.detach().double().pow(2).sum(), torch.tensor(float(o.numel()), dtype=torch.float64,
+                                                                           device=o.device)])))
+                 for k, m in mods.items()]
+        try:
+            with torch.no_grad():
+                run_forward()
+        finally:
+            for h in hooks:
+                h.remove()
+        out = dict()
+        for k in mods:      # the plan's key order: identical on every rank
+            t = acc[k] if reduce is None else reduce(acc[k])
+            out[k] = float((t[0] / t[1]).sqrt())
+        return out
+
+    with torch.no_grad():
+        for enc in net.encoders:
+            for depth, layer in enumerate(enc._blocks):
+                keys = list(layer._out_fcs.keys())
+                rms = rms_of({k: layer._out_fcs[k] for k in keys})
+                report.append({"layer%d.%s" % (depth, k): v for k, v in rms.items()})
+                for k in keys:
+                    f = target / max(rms[k], 1e-30)
+                    for nb in layer._meta_graph[k]:
+                        agg = layer.aggregators[(k, nb)]
+                        agg = getattr(agg, "_agg", agg)
+                        for r in range(agg._num_links):
+                            getattr(agg, "weight%d" % r).mul_(f)
+        projs = {"user": net.rating_user_projs[0], "item": net.rating_item_projs[0]}
+        rms = rms_of(projs)
+        report.append({"proj.%s" % k: v for k, v in rms.items()})
+        for k, m in projs.items():
+            m.weight.mul_(m.weight.shape[0] ** -0.25 / max(rms[k], 1e-30))
+    return report

@@ -1,0 +1,287 @@
+"""CHECKER (test infrastructure, not product): float64 evaluation of the DEFINITION of the benchmark network -- the
+2-layer multi-link GCN of SURVEY.md section 8(d) -- with plain torch ops on whatever device the inputs live on.
+
+Nothing of the product is used: no HIP kernel of libstargcn_hip.so, no plan, no transposed CSR.  The only inputs are
+the raw user->item CSR (row pointer, item of every rating, rating level of every rating), the degrees the support is
+normalised with, and the parameter VALUES of the network under test.  Every formula cites the reference line it
+restates (paths relative to /root/reference):
+
+  support        sqrt(1 / d_row / d_col) evaluated in fp32 in that order       GraphSampler/graph_sampler.cpp:393-420
+  aggregator     per level r: FullyConnected(x, W_r, b_r) then seg_weighted_pool over the level's edges, add_n over the
+                 levels, activation                                             mxgraph/layers/aggregators.py:141-160
+                 seg_weighted_pool: out[s] = sum_{j in seg s} w_j data[idx_j]   seg_ops_cuda/mxnet_op/seg_op.cc:180-207
+  layer          out Dense + activation on the aggregate                        mxgraph/layers/layers.py:147-187
+  rating head    score = <Dense_u(out_u)[u], Dense_i(out_i)[i]>                 experiments/STAR-GCN.py:249-261, 428-438
+  loss           gluon L2Loss = 0.5 (score - y)^2, mean over the ratings        experiments/STAR-GCN.py:550, 610-613
+
+The forward AND the backward pass (chain rule written out, no autograd) run over the WHOLE graph in float64; the
+product's fp32 results -- loss, every layer's output rows for both node types, the rating projections, the gradient of
+every embedding row and every weight / bias gradient -- are compared element by element.  A 2-hop network has a
+receptive field of (nearly) the whole graph, so anything short of a full evaluation could not check a single output row
+end to end.  Cost at the 125 M-rating shard of BASELINE config 5 on an MI355X: a few seconds (fp64 GEMMs + chunked
+index_add_), about 60 GB of temporaries.
+
+Used by tests/test_gpu_bench_verify.py and by bench.py's `verify` block (outside every timed region).
+"""
+import math
+
+import torch
+
+SLOPE = 0.1          # LeakyReLU(0.1), mxgraph/layers/common.py:47
+
+
+def _leaky(x):
+    return torch.where(x > 0, x, SLOPE * x)
+
+
+def _dleaky(pre):
+    return torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, SLOPE))
+
+
+class RawGraph(object):
+    """user->item ratings in CSR order: ind_ptr (n_user+1), item (E), level (E) in [0, R); degrees for the support."""
+
+    def __init__(self, ind_ptr, item, level, n_item, R, item_degrees=None, chunk=1 << 22):
+        dev = ind_ptr.device
+        self.n_user, self.n_item, self.R = int(ind_ptr.numel() - 1), int(n_item), int(R)
+        self.E = int(item.numel())
+        deg_u = (ind_ptr[1:] - ind_ptr[:-1]).long()
+        self.user = torch.repeat_interleave(torch.arange(self.n_user, device=dev, dtype=torch.int32), deg_u)
+        self.item = item.to(torch.int32)
+        self.level = level.to(torch.int32)
+        assert self.user.numel() == self.E and int(self.level.max()) < R and int(self.level.min()) >= 0
+        deg_i = torch.bincount(item.long(), minlength=self.n_item) if item_degrees is None else item_degrees.long()
+        du, di = deg_u.double(), deg_i.double()
+        # std::sqrt(1.0f / float(r) / float(c)): three correctly rounded fp32 operations in the reference's order (the
+        # user->item matrix and its transpose divide in different orders).  Each is evaluated in float64 and rounded to
+        # fp32 -- exact emulation (53 >= 2*24+2 bits: no double-rounding error for / and sqrt), independent of how the
+        # backend's own fp32 sqrt / division round.
+        f32 = lambda t: t.float().double()
+        self.w_ui = torch.empty(self.E, dtype=torch.float32, device=dev)
+        self.w_iu = torch.empty(self.E, dtype=torch.float32, device=dev)
+        for a in range(0, self.E, chunk):
+            u, i = self.user[a:a + chunk].long(), self.item[a:a + chunk].long()
+            self.w_ui[a:a + chunk] = torch.sqrt(f32(f32(1.0 / du[u]) / di[i])).float()
+            self.w_iu[a:a + chunk] = torch.sqrt(f32(f32(1.0 / di[i]) / du[u])).float()
+        self.chunk = chunk
+
+    def edges(self, dst):
+        """(dst row, src row, support) of every rating for the aggregation INTO node type `dst` ('user' | 'item')"""
+        return (self.user, self.item, self.w_ui) if dst == "user" else (self.item, self.user, self.w_iu)
+
+    def n(self, key):
+        return self.n_user if key == "user" else self.n_item
+
+
+class _Agg(object):
+    """act( sum_r A_r (x W_r^T + b_r) ) and its gradients, float64, definition order"""
+
+    def __init__(self, g, dst, Ws, bs):
+        self.g, self.dst = g, dst
+        self.W = torch.cat([w.double() for w in Ws], 0)            # (R*U, D): row block r = W_r
+        self.b = torch.cat([b.double() for b in bs], 0)            # (R*U)
+        self.U = Ws[0].shape[0]
+
+    def forward(self, x):
+        g, R, U = self.g, self.g.R, self.U
+        d_e, s_e, w_e = g.edges(self.dst)
+        H = (x @ self.W.t() + self.b).view(-1, U)                  # row (src*R + r) = FullyConnected_r(x)[src]
+        out = torch.zeros(g.n(self.dst), U, dtype=torch.float64, device=x.device)
+        for a in range(0, g.E, g.chunk):
+            sl = slice(a, a + g.chunk)
+            rows = H[s_e[sl].long() * R + g.level[sl].long()]
+            rows *= w_e[sl].double()[:, None]
+            out.index_add_(0, d_e[sl].long(), rows)
+        self.x, self.pre = x, out
+        return _leaky(out)
+
+    def backward(self, dh):
+        g, R, U = self.g, self.g.R, self.U
+        d_e, s_e, w_e = g.edges(self.dst)
+        dpre = dh * _dleaky(self.pre)
+        G = torch.zeros(self.x.shape[0] * R, U, dtype=torch.float64, device=dh.device)   # d H
+        for a in range(0, g.E, g.chunk):
+            sl = slice(a, a + g.chunk)
+            rows = dpre[d_e[sl].long()]
+            rows *= w_e[sl].double()[:, None]
+            G.index_add_(0, s_e[sl].long() * R + g.level[sl].long(), rows)
+        G = G.view(self.x.shape[0], R * U)
+        dW = G.t() @ self.x                                        # (R*U, D)
+        db = G.sum(0)
+        dx = G @ self.W
+        self.pre = self.x = None
+        return dx, list(dW.view(R, U, -1).unbind(0)), list(db.view(R, U).unbind(0))
+
+
+class _Dense(object):
+    def __init__(self, W, b, act):
+        self.W, self.b, self.act = W.double(), b.double(), act
+
+    def forward(self, x):
+        self.x = x
+        self.pre = x @ self.W.t() + self.b
+        return _leaky(self.pre) if self.act else self.pre
+
+    def backward(self, dy):
+        dpre = dy * _dleaky(self.pre) if self.act else dy
+        dW, db, dx = dpre.t() @ self.x, dpre.sum(0), dpre @ self.W
+        self.pre = self.x = None
+        return dx, dW, db
+
+
+def evaluate(g, params, y, scale):
+    """-> dict of float64 results.  params: {"embed": {key: table}, "layers": [{key: {"W": [R], "b": [R], "Wo", "bo"}}],
+    "proj": {key: (W, b)}} with key in ('user', 'item'); y: standardised rating of every edge (CSR order)."""
+    other = {"user": "item", "item": "user"}
+    x = {k: params["embed"][k].double() for k in ("user", "item")}
+    aggs, outs, res = [], [], {"layer_out": []}
+    for lp in params["layers"]:
+        a = {k: _Agg(g, k, lp[k]["W"], lp[k]["b"]) for k in ("user", "item")}
+        o = {k: _Dense(lp[k]["Wo"], lp[k]["bo"], True) for k in ("user", "item")}
+        h = {k: a[k].forward(x[other[k]]) for k in ("user", "item")}
+        x = {k: o[k].forward(h[k]) for k in ("user", "item")}
+        aggs.append(a)
+        outs.append(o)
+        res["layer_out"].append(dict(x))
+    proj = {k: _Dense(params["proj"][k][0], params["proj"][k][1], False) for k in ("user", "item")}
+    p = {k: proj[k].forward(x[k]) for k in ("user", "item")}
+    res["proj"] = dict(p)
+    # rating head + loss (chunked: a (E, width) float64 gather would be 64 GB at config 5)
+    yd = y.double().view(-1)
+    loss = torch.zeros((), dtype=torch.float64, device=yd.device)
+    ssq = torch.zeros((), dtype=torch.float64, device=yd.device)
+    dp = {k: torch.zeros_like(p[k]) for k in ("user", "item")}
+    for a in range(0, g.E, g.chunk):
+        sl = slice(a, a + g.chunk)
+        u, i = g.user[sl].long(), g.item[sl].long()
+        ru, ri = p["user"][u], p["item"][i]
+        score = (ru * ri).sum(1)
+        ssq += (score * score).sum()
+        diff = score - yd[sl]
+        loss += 0.5 * (diff * diff).sum()
+        gs = (scale * diff)[:, None]
+        dp["user"].index_add_(0, u, gs * ri)
+        dp["item"].index_add_(0, i, gs * ru)
+    res["loss"] = loss * scale
+    res["score_rms"] = math.sqrt(float(ssq) / max(g.E, 1))
+    grads = {"layers": [None] * len(aggs), "proj": {}, "embed": {}}
+    dx = {}
+    for k in ("user", "item"):
+        dx[k], dW, db = proj[k].backward(dp[k])
+        grads["proj"][k] = (dW, db)
+    for l in range(len(aggs) - 1, -1, -1):
+        gl, nxt = {}, {}
+        for k in ("user", "item"):
+            dh, dWo, dbo = outs[l][k].backward(dx[k])
+            dsrc, dW, db = aggs[l][k].backward(dh)
+            gl[k] = {"W": dW, "b": db, "Wo": dWo, "bo": dbo}
+            nxt[other[k]] = dsrc
+        grads["layers"][l] = gl
+        dx = nxt
+    grads["embed"] = dx
+    res["grads"] = grads
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reading the network under test (parameter VALUES and the tensors it produced) -- no product code is executed here
+def net_params(net, name_user="user", name_item="movie"):
+    key = {"user": name_user, "item": name_item}
+    other = {"user": name_item, "item": name_user}
+    assert len(net.encoders) == 1, "the benchmark network is ONE encoder of stacked layers"
+    layers = []
+    for layer in net.encoders[0]._blocks:
+        lp = {}
+        for k in ("user", "item"):
+            agg = layer.aggregators[(key[k], other[k])]
+            assert not agg._ordinal_sharing and agg._accum == "sum"
+            R = agg._num_links
+            fc = layer._out_fcs[key[k]]
+            lp[k] = {"W": [getattr(agg, "weight%d" % r).detach() for r in range(R)],
+                     "b": [getattr(agg, "bias%d" % r).detach() for r in range(R)],
+                     "Wo": fc.weight.detach(), "bo": fc.bias.detach()}
+        layers.append(lp)
+    proj = {"user": (net.rating_user_projs[0].weight.detach(), net.rating_user_projs[0].bias.detach()),
+            "item": (net.rating_item_projs[0].weight.detach(), net.rating_item_projs[0].bias.detach())}
+    embed = {k: net.embed_layers[key[k]].weight.detach() for k in ("user", "item")}
+    return {"embed": embed, "layers": layers, "proj": proj}
+
+
+class Capture(object):
+    """forward hooks that keep what the product computed: every layer's output per node type and the rating projections"""
+
+    def __init__(self, net, name_user="user", name_item="movie"):
+        self.key = {"user": name_user, "item": name_item}
+        self.layer_out = [dict() for _ in net.encoders[0]._blocks]
+        self.proj = {}
+        self._h = []
+        for l, layer in enumerate(net.encoders[0]._blocks):
+            for k in ("user", "item"):
+                self._h.append(layer._out_fcs[self.key[k]].register_forward_hook(
+                    lambda m, i, o, l=l, k=k: self.layer_out[l].__setitem__(k, o.detach())))
+        self._h.append(net.rating_user_projs[0].register_forward_hook(
+            lambda m, i, o: self.proj.__setitem__("user", o.detach())))
+        self._h.append(net.rating_item_projs[0].register_forward_hook(
+            lambda m, i, o: self.proj.__setitem__("item", o.detach())))
+
+    def close(self):
+        for h in self._h:
+            h.remove()
+        self._h = []
+
+
+def _rel(got, ref):
+    """max |got - ref| relative to the tensor's scale (max |ref|), the measure of every fp32 parity test of this repo"""
+    s = float(ref.abs().max())
+    return float((got.double() - ref).abs().max()) / max(s, 1e-30), s
+
+
+def compare(net, cap, loss, ref, name_user="user", name_item="movie"):
+    """-> {"max_rel_err", "worst", "rows", "tensors", "per_tensor": {name: rel err}} of the product's fp32 results
+    against `ref` = evaluate(...)."""
+    key = {"user": name_user, "item": name_item}
+    other = {"user": name_item, "item": name_user}
+    per, rows = {}, 0
+    per["loss"] = abs(float(loss) - float(ref["loss"])) / max(abs(float(ref["loss"])), 1e-30)
+    for l, lo in enumerate(ref["layer_out"]):
+        for k in ("user", "item"):
+            per["layer%d.out.%s" % (l, k)], _ = _rel(cap.layer_out[l][k], lo[k])
+            rows += lo[k].shape[0]
+    for k in ("user", "item"):
+        per["proj.%s" % k], _ = _rel(cap.proj[k], ref["proj"][k])
+        per["grad.embed.%s" % k], _ = _rel(net.embed_layers[key[k]].weight.grad, ref["grads"]["embed"][k])
+        rows += ref["grads"]["embed"][k].shape[0]
+    for l, layer in enumerate(net.encoders[0]._blocks):
+        for k in ("user", "item"):
+            agg, fc, gl = layer.aggregators[(key[k], other[k])], layer._out_fcs[key[k]], ref["grads"]["layers"][l][k]
+            # the R per-level gradients are one contraction: scale of the whole (R, U, D) block
+            gW = torch.stack([getattr(agg, "weight%d" % r).grad for r in range(agg._num_links)])
+            gb = torch.stack([getattr(agg, "bias%d" % r).grad for r in range(agg._num_links)])
+            per["grad.layer%d.%s.W" % (l, k)], _ = _rel(gW, torch.stack(gl["W"]))
+            per["grad.layer%d.%s.b" % (l, k)], _ = _rel(gb, torch.stack(gl["b"]))
+            per["grad.layer%d.%s.Wo" % (l, k)], _ = _rel(fc.weight.grad, gl["Wo"])
+            per["grad.layer%d.%s.bo" % (l, k)], _ = _rel(fc.bias.grad, gl["bo"])
+    pj = {"user": net.rating_user_projs[0], "item": net.rating_item_projs[0]}
+    for k in ("user", "item"):
+        per["grad.proj.%s.W" % k], _ = _rel(pj[k].weight.grad, ref["grads"]["proj"][k][0])
+        per["grad.proj.%s.b" % k], _ = _rel(pj[k].bias.grad, ref["grads"]["proj"][k][1])
+    worst = max(per, key=lambda n: per[n])
+    act_worst = max((n for n in per if not n.startswith("grad.") and n != "loss"), key=lambda n: per[n])
+    return {"max_rel_err": per[worst], "worst": worst, "max_rel_err_outputs": per[act_worst], "rows": rows,
+            "tensors": len(per), "per_tensor": {n: float("%.3g" % v) for n, v in per.items()},
+            "loss_f64": float(ref["loss"])}
+
+
+def verify_step(net, run_step, graph_arrays, y, scale, name_user="user", name_item="movie"):
+    """Run ONE step of the network under test (`run_step()` -> loss, gradients left in .grad) with capture hooks on,
+    evaluate the definition in float64 and compare.  graph_arrays = (ind_ptr, item, level, n_item, R, item_degrees)."""
+    cap = Capture(net, name_user, name_item)
+    try:
+        loss = run_step()
+    finally:
+        cap.close()
+    g = RawGraph(*graph_arrays)
+    ref = evaluate(g, net_params(net, name_user, name_item), y, scale)
+    out = compare(net, cap, loss.detach(), ref, name_user, name_item)
+    out["score_rms"] = float("%.4g" % ref["score_rms"])
+    return out
