@@ -182,14 +182,14 @@ def build_net(graph_like, D, order, dev, part=None):
 VERIFY_TOL = 1e-5      # north star: "within 1e-5 fp32 on embeddings"; max |err| relative to each tensor's scale
 
 
-def prepare_net(net, step, forward, seed, rows, reduce=None):
+def prepare_net(net, step, forward, seed, rows, reduce=None, scores=None):
     """Materialise the lazily-shaped parameters (one step), re-draw every parameter by NAME (identical replicated
     parameters on every rank, equal to the N = 1 model's), then calibrate the layer scales so that activations, scores
     and therefore the loss are O(1) and depend on what the network computes (model.calibrate_output_scale)."""
     import star_gcn_amd.model as M
     step()
     M.deterministic_init(net, seed, rows)
-    return M.calibrate_output_scale(net, forward, reduce=reduce)
+    return M.calibrate_output_scale(net, forward, reduce=reduce, run_scores=scores)
 
 
 def verify_leg(net, step, arrays, y, scale):
@@ -366,7 +366,7 @@ def hbm_case(hbm_shape, D, order, dev):
         return loss
 
     calib = prepare_net(net, step, lambda: net.run(plan, rating_targets=y, rating_scale=1.0 / E), 4321,
-                        {U: (0, nu, nu), I: (0, ni, ni)})
+                        {U: (0, nu, nu), I: (0, ni, ni)}, scores=lambda: net.run(plan)[0][0])
     return types.SimpleNamespace(nu=nu, ni=ni, R=R, D=D, dg=dg, net=net, plan=plan, y=y, E=E, step=step, calib=calib,
                                  t_gen=t_gen, t_plan=t_plan)
 
@@ -465,7 +465,8 @@ def run_config5(args, dev, dist_on, world, rank, backend):
 
     # replicated parameters (and, for simplicity, the user tables) drawn by parameter NAME: identical on every rank
     prepare_net(net, step, lambda: net.run(plan, rating_targets=y, rating_scale=1.0 / E_total), 1234,
-                {U: (0, nu, nu), I: (0, ni, ni)}, reduce=SD.all_reduce_sum if dist_on else None)
+                {U: (0, nu, nu), I: (0, ni, ni)}, reduce=SD.all_reduce_sum if dist_on else None,
+                scores=lambda: net.run(plan)[0][0])
     elapsed, loss, timeline = timed_steps(step, args.steps, args.warmup, dev, dist_on)
     comm = SD.STATS.read() if dist_on else None
     rank_ms = [elapsed / args.steps * 1e3]
@@ -563,7 +564,8 @@ def main_case(shape, D_, order, dev, dist_on=False, world=1, rank=0):
     # replicated parameters on every rank, equal to the N = 1 model's, whatever the rank-local row counts and the order
     # of first use (user table = rows [lo, hi) of the global one); then the layer scales are calibrated (global rms)
     calib = prepare_net(net, step, lambda: net.run(plan, rating_targets=y, rating_scale=1.0 / E_total), 1234,
-                        {U: (lo, hi, n_user), I: (0, n_item, n_item)}, reduce=SD.all_reduce_sum if dist_on else None)
+                        {U: (lo, hi, n_user), I: (0, n_item, n_item)}, reduce=SD.all_reduce_sum if dist_on else None,
+                        scores=lambda: net.run(plan)[0][0])
     return types.SimpleNamespace(**{k: v for k, v in locals().items() if k not in ("types", "SD", "S", "DeviceBipartite",
                                                                                   "HeterGraph")})
 

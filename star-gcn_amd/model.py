@@ -509,7 +509,7 @@ def deterministic_init(net, seed=1234, embedding_rows=None):
                 p.zero_()
 
 
-def calibrate_output_scale(net, run_forward, target=1.0, reduce=None):
+def calibrate_output_scale(net, run_forward, target=1.0, reduce=None, run_scores=None):
     """Layer-sequential scale calibration of a freshly initialised benchmark network (LSUV-style, Mishkin & Matas
     2015, without the orthogonalisation): with the reference's init (embeddings U(-0.1, 0.1), Xavier-in weights, zero
     biases; STAR-GCN.py:180, 548) the symmetric normalisation sqrt(1/d_u/d_i) shrinks every aggregation of a
@@ -519,7 +519,8 @@ def calibrate_output_scale(net, run_forward, target=1.0, reduce=None):
     the rating projections are rescaled so that the scores have unit scale (each projection to rms width^-1/4).
     Biases are zero and LeakyReLU is positively homogeneous, so one forward pass per stage gives the exact factor.
 
-    run_forward(): one forward pass of the network (no gradients needed).  reduce(t) -> t summed over the ranks of a
+    run_forward(): one forward pass of the network (no gradients needed); run_scores() -> the score of every rating
+    pair of the plan (rank-local pairs in a partitioned run).  reduce(t) -> t summed over the ranks of a
     node-partitioned run (rank-local node types need the global mean square; replicated types are unaffected because
     numerator and denominator grow alike).  Returns the measured rms values, stage by stage (before rescaling)."""
     report = []
@@ -560,4 +561,12 @@ def calibrate_output_scale(net, run_forward, target=1.0, reduce=None):
         report.append({"proj.%s" % k: v for k, v in rms.items()})
         for k, m in projs.items():
             m.weight.mul_(m.weight.shape[0] ** -0.25 / max(rms[k], 1e-30))
+        if run_scores is not None:      # the two projections are correlated: set the SCORES' rms to 1 directly
+            sc = run_scores().detach().double()
+            t = torch.stack([sc.pow(2).sum(), torch.tensor(float(sc.numel()), dtype=torch.float64, device=sc.device)])
+            t = t if reduce is None else reduce(t)
+            srms = float((t[0] / t[1]).sqrt())
+            report.append({"scores": srms})
+            for m in projs.values():
+                m.weight.mul_(max(srms, 1e-30) ** -0.5)
     return report
