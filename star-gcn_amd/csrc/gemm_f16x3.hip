@@ -1,0 +1,450 @@
+// gemm_f16x3.hip -- fp32-accurate GEMM on the f16 matrix cores of gfx950 with THREE matrix instructions per product
+// (the bf16 backends need six), operands pre-split ONCE per call into a fragment-major plane format.
+//
+// Arithmetic (block floating point).  Each operand is cut into blocks of 32 rows of op(X) x 64 k.  A block gets ONE
+// power-of-two scale s that brings its largest magnitude into [2^14, 2^15) -- exact, nothing is lost by it -- and every
+// scaled value is split into two f16 planes
+//     x s = h1 + h2 + e,   h1 = rne_f16(x s),  h2 = rne_f16(x s - h1),   |e| <= 2^-22 |x s|
+// (11 significant bits per plane; the residual is an exact fp32 subtraction).  A product is formed from the three plane
+// pairs a1 b1 + a1 b2 + a2 b1 on v_mfma_f32_32x32x16_f16 with fp32 accumulation; the dropped a2 b2 is <= 2^-22 |a b|,
+// so a term carries a relative error <= 3 * 2^-22 = 7.2e-7 (fp32 product rounding: 6e-8), independent from term to
+// term: over a dot product of length K it adds ~ 7e-7 / sqrt(K) of sum |a||b| -- below the rounding of the fp32
+// accumulation itself for the K >= 96 this backend is used for, and inside the fp64-referenced bound of the exact-fp32
+// kernel (tests/test_gpu_dense_multilink.py).  The three products of a 64-k block accumulate in a block-local register
+// set P (four k steps: short sums, so the 2^-11 corrections are not rounded against a long running sum); at the end of
+// the block P is scaled by 1 / (s_A s_B) with v_ldexp_f32 (exact) and added to the running result -- one fp32 rounding
+// per 64 k, like a plain fp32-accumulating MFMA chain.  Dynamic range: an element more than 2^18 below the largest
+// magnitude of ITS block (32 rows x 64 k) falls into the f16 subnormal range of h2 and keeps an absolute error of 2^-40
+// of the block maximum instead of 2^-22 relative: a row 10^6 times smaller than a neighbour in the same 32-row block
+// still comes out to 1e-6 relative.  Because the scale is per block there is no pass over the operand to find maxima:
+// the split is ONE streaming pass (4 B read + 4 B written per element).
+//
+// Why pre-split.  In the wave-specialised bf16x6 kernel (gemm_x6v2.hip) every 128 x 128 tile re-splits its operand
+// panels: the A panel of the 1 M x 4096 x 256 forward GEMM is converted 32 times, once per column tile, and that VALU +
+// LDS-store work shares issue slots and the LDS pipe with the matrix instructions (each role gains 30 % when
+// another is removed).  Here a streaming pass converts each operand once into "fragment-major" planes: for every
+// 32-row block and 16-k step the 64 x 16 bytes that the 64 lanes of a wave feed to ONE MFMA operand are stored
+// contiguously in lane order.  The GEMM kernel then is nothing but matrix work:
+//   * global -> LDS by global_load_lds_dwordx4 (LDS-DMA: no VGPRs, no VALU, no ds_write); a tile's bytes are contiguous
+//     4 KiB runs in memory, the LDS image is a plain copy and every ds_read_b128 of a fragment reads 1 KiB contiguous --
+//     conflict-free without any swizzle arithmetic;
+//   * 128 x 128 x 32 tiles, 4 waves (64 x 64 each), two 32 KiB LDS stages = 64 KiB: TWO workgroups per CU, so one
+//     workgroup's barrier / epilogue overlaps the other's matrix work; the DMA of K tile t+1 is issued before the
+//     fragments of K tile t are read, one barrier per K tile;
+//   * epilogue through a private LDS block per wave (aliasing the stages) -> 16-byte stores, 256 B per row segment.
+// Conversion costs one read + one write of the operand (two f16 planes = 4 B per element, the bytes of the fp32 original);
+// it is charged to this backend in every measurement.
+//
+// Epilogue / split-K contract identical to gemm_f32.hip (GemmArgs); selected by sg_gemm_f32_hip (backend 3).
+#include "common.hpp"
+
+namespace sg {
+
+struct GemmArgs {   // must match gemm_f32.hip
+  float* C;
+  const float* A;
+  const float* B;
+  const float* bias;
+  float* ws;
+  long long lda, ldb, ldc;
+  int M, N, K;
+  int act;
+  float slope;
+  int accumulate;
+  int splits, tiles_per_split;
+  int tiles_m, tiles_n;
+  int vecA, vecB;
+};
+
+namespace f16x3 {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int UNIT = 1024;                 // bytes one wave feeds to one MFMA operand: 64 lanes x 8 halves
+constexpr int CPITCH = 68;                 // floats per row of a wave's private C staging block (32 x 64 + pad)
+constexpr int CSTAGE = 32 * CPITCH * 4;    // 8704 B per wave
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+__device__ __forceinline__ float act_fn(float v, int act, float slope) {
+  switch (act) {
+    case SG_ACT_LEAKY: return v > 0.f ? v : slope * v;
+    case SG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case SG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case SG_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// split: fp32 operand -> fragment-major f16 planes.  16-byte unit u(rb, ks, plane, lane) = ((rb*KS + ks)*2 + plane)*64 + lane
+// holds op(X)[row = 32 rb + (lane & 31)][k = 16 ks + 8 (lane >> 5) + 0..7]  (the operand layout of v_mfma_f32_32x32x16_f16).
+// One workgroup converts 32 rows x 64 k: coalesced 128-byte row segments in, a [row][k] tile in LDS, 1 KiB units out.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool RC>
+__global__ __launch_bounds__(256) void split_kernel(char* __restrict__ planes, int* __restrict__ expo,
+                                                    const float* __restrict__ p, long long ld, int R, int K, int KS, int vec) {
+  __shared__ float tile[32][65];
+  __shared__ float wmax[4];
+  const int t = threadIdx.x;
+  const int rb = blockIdx.x, k0 = blockIdx.y * 64;
+  const int r0 = rb * 32;
+  float m = 0.f;
+  if (!RC) {            // element (r, k) at p[r * ld + k]: thread = (row t/8, 4 consecutive k), two passes of 32 k
+    const int r = r0 + (t >> 3);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + h * 32 + (t & 7) * 4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (r < R) {
+        if (vec && k + 3 < K) {
+          const float4 x = *reinterpret_cast<const float4*>(p + static_cast<long long>(r) * ld + k);
+          v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (k + j < K) v[j] = p[static_cast<long long>(r) * ld + k + j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        tile[t >> 3][h * 32 + (t & 7) * 4 + j] = v[j];
+        m = fmaxf(m, fabsf(v[j]));
+      }
+    }
+  } else {              // element (k, c) at p[k * ld + c], op row = c: thread = (k row t/8 + 32 h, 4 consecutive c)
+    const int c = r0 + (t & 7) * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + h * 32 + (t >> 3);
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (k < K) {
+        if (vec && c + 3 < R) {
+          const float4 x = *reinterpret_cast<const float4*>(p + static_cast<long long>(k) * ld + c);
+          v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (c + j < R) v[j] = p[static_cast<long long>(k) * ld + c + j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        tile[(t & 7) * 4 + j][h * 32 + (t >> 3)] = v[j];
+        m = fmaxf(m, fabsf(v[j]));
+      }
+    }
+  }
+  // block maximum -> exponent e with max * 2^e in [2^14, 2^15) (fmaxf drops NaNs: a NaN / inf block is not scaled and
+  // propagates through the planes)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((t & 63) == 0) wmax[t >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  int e = 0;
+  {
+    const unsigned b = __float_as_uint(m);
+    const int ex = static_cast<int>((b >> 23) & 0xffu);
+    if (b != 0u && ex != 0xff) e = 14 - (max(ex, 1) - 127);
+    e = min(max(e, -126), 126);
+  }
+  const float s = __uint_as_float(static_cast<unsigned>(127 + e) << 23);
+  if (t == 0) expo[static_cast<long long>(rb) * (KS >> 2) + blockIdx.y] = -e;
+  // thread -> unit: k step ks = t / 64 of this block's four, lane = t % 64
+  const int lane = t & 63, ks = t >> 6;
+  const int row = lane & 31, kk = ks * 16 + (lane >> 5) * 8;
+  unsigned h1[4], h2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 x = {tile[row][kk + 2 * j] * s, tile[row][kk + 2 * j + 1] * s};
+    const f16x2 a = __builtin_convertvector(x, f16x2);
+    const f32x2 res = x - __builtin_convertvector(a, f32x2);
+    const f16x2 b = __builtin_convertvector(res, f16x2);
+    h1[j] = __builtin_bit_cast(unsigned, a);
+    h2[j] = __builtin_bit_cast(unsigned, b);
+  }
+  const long long u = (static_cast<long long>(rb) * KS + (k0 >> 4) + ks) * 2;
+  uint4* out = reinterpret_cast<uint4*>(planes) + u * 64 + lane;
+  out[0] = make_uint4(h1[0], h1[1], h1[2], h1[3]);
+  out[64] = make_uint4(h2[0], h2[1], h2[2], h2[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the GEMM on planes
+// ---------------------------------------------------------------------------------------------------------------------
+struct PlaneArgs {
+  const char* pa;
+  const char* pb;
+  const int* exp_a;     // -log2(scale) of block (32-row block rb, 64-k block kb) at [rb * (KS / 4) + kb]
+  const int* exp_b;
+  int KS;               // 16-k steps per row block = Kp / 16 (a multiple of 4)
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+typedef const __attribute__((address_space(4))) int cst_int;      // constant address space: scalar (s_load) access
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {      // counted wait on this wave's own LDS-DMA / global loads
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else static_assert(N == 0, "add the immediate");
+}
+
+// WM: waves along M (tile = 64 WM x 128, 2 WM waves of 64 x 64); BKS: 16-k steps per K tile; NST: LDS stages.
+//   <2, 2, 2>  128 x 128 x 32, 64 KiB: two workgroups per CU, one K tile in flight each (short K: the other workgroup's
+//              matrix work covers this one's epilogue)
+//   <2, 1, 5>  128 x 128 x 16, 80 KiB: two workgroups per CU, three K tiles in flight each
+//   <4, 2, 3>  256 x 128 x 32, 144 KiB: one workgroup per CU, 25 % fewer operand bytes per flop, one to two K tiles in flight
+// What bounds these kernels is bytes in flight: at the matrix-core rate a CU consumes 31-43 B / clk of planes, the loaded
+// L2 / Infinity-Cache latency is ~2 us, and LDS (160 KiB) is the only place in-flight DMA data can land.
+template <int WM, int BKS, int NST>
+__global__ __launch_bounds__(128 * WM, (WM == 2 ? 2 : 2)) void gemm_f16x3_kernel(const GemmArgs g, const PlaneArgs pl) {
+  constexpr int RBA = 2 * WM, RBB = 4;                 // 32-row blocks of A / B per tile
+  constexpr int UPB = 2 * BKS;                         // units per row block and K tile (k step x plane)
+  constexpr int UNITS = (RBA + RBB) * UPB, NW = 2 * WM, UPW = UNITS / NW;
+  constexpr int STAGE_B = UNITS * UNIT;
+  static_assert(UNITS % NW == 0, "units must divide over the waves");
+  static_assert(NST * STAGE_B >= NW * CSTAGE, "epilogue staging aliases the stages");
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE_B];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  // work item -> (tile, K slice); XCD-aware bijective remap of the tile index (workgroup b runs on XCD b % 8): the tiles of
+  // one XCD are consecutive, consecutive tiles share their A panel
+  const int nt = g.tiles_m * g.tiles_n;
+  const int item = blockIdx.x;
+  const int z = item / nt, lin = item - z * nt;
+  const int q8 = nt >> 3, r8 = nt & 7, x8 = lin & 7;
+  const int tile = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (lin >> 3);
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  // K range of this slice in tiles of BKS k-steps; g.tiles_per_split counts 32-k tiles and is even when g.splits > 1, so a
+  // slice starts on a 64-k scale block
+  const int ksteps = (g.K + 15) / 16;
+  const int s0 = z * g.tiles_per_split * 2, s1 = min((ksteps + 3) & ~3, s0 + g.tiles_per_split * 2);
+  const int T = (s1 - s0 + BKS - 1) / BKS;             // K tiles of this slice (planes are zero-padded to 64 k)
+
+  // acc: running result (true scale); P: products of the current 64-k block (block scale)
+  f32x16 acc[2][2], P[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // DMA of one K tile: UNITS units of 1 KiB, UPW per wave.  unit u: row block u / UPB (A blocks first), part u % UPB of the
+  // block's contiguous UPB KiB (k step x plane)
+  const long long rb_stride = static_cast<long long>(pl.KS) * 2 * UNIT;
+  const char* a_base = pl.pa + static_cast<long long>(tm) * RBA * rb_stride + static_cast<long long>(s0) * 2 * UNIT + lane * 16;
+  const char* b_base = pl.pb + static_cast<long long>(tn) * RBB * rb_stride + static_cast<long long>(s0) * 2 * UNIT + lane * 16;
+  auto issue = [&](int kt) {
+    char* dst = smem + (kt % NST) * STAGE_B;
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+      const int u = wave * UPW + i;
+      const int q = u / UPB, part = u - q * UPB;
+      const char* src = (q < RBA ? a_base + q * rb_stride : b_base + (q - RBA) * rb_stride) +
+                        static_cast<long long>(kt) * (UPB * UNIT) + part * UNIT;
+      __builtin_amdgcn_global_load_lds((glb_void*)(src), (lds_void*)(dst + u * UNIT), 16, 0, 0);
+    }
+  };
+  // block exponents of this wave's two A row blocks and two B row blocks (wave-uniform: scalar loads)
+  const int kbs = pl.KS >> 2;
+  cst_int* ea_p = (cst_int*)(pl.exp_a + static_cast<long long>(tm * RBA + wm * 2) * kbs + (s0 >> 2));
+  cst_int* eb_p = (cst_int*)(pl.exp_b + static_cast<long long>(tn * RBB + wn * 2) * kbs + (s0 >> 2));
+
+  // pipeline: tiles t+1 .. t+NST-2 stay in flight while tile t is multiplied; ONE barrier per K tile.  The barrier of
+  // iteration t also says that every wave has finished tile t-1, whose stage then receives tile t+NST-1.
+  // The loop runs over 64-k scale blocks (TPB K tiles each, compile-time positions inside a block): the first product of a
+  // block starts from a zero accumulator operand (an inline constant: no register clearing), the last tile folds the block
+  // into the running result with one FMA per element.
+  constexpr int TPB = 4 / BKS;
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < T) issue(i);
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb * TPB < T; ++kb) {
+#pragma unroll
+    for (int tt = 0; tt < TPB; ++tt) {
+      const int kt = kb * TPB + tt;
+      if (kt < T) {                                         // wave-uniform; only the last block of a slice can be short
+        if (kt + NST - 2 < T) wait_vm<UPW * (NST - 2)>();   // in order: everything up to tile kt has landed
+        else wait_vm<0>();                                  // tail: fewer tiles in flight than the count assumes
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NST - 1 < T) issue(kt + NST - 1);
+        const char* st = smem + (kt % NST) * STAGE_B;
+#pragma unroll
+        for (int ks = 0; ks < BKS; ++ks) {
+          f16x8 a[2][2], b[2][2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              a[i][p] = *reinterpret_cast<const f16x8*>(st + ((wm * 2 + i) * UPB + ks * 2 + p) * UNIT + lane * 16);
+              b[i][p] = *reinterpret_cast<const f16x8*>(st + ((RBA + wn * 2 + i) * UPB + ks * 2 + p) * UNIT + lane * 16);
+            }
+          // corrections first, leading product last; the four tiles interleave so consecutive MFMAs never depend on each other
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], (tt == 0 && ks == 0) ? zero : P[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], P[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], P[i][j], 0, 0, 0);
+        }
+      }
+    }
+    // end of the 64-k block: fold it into the running result at its true scale 2^ex (exact)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ex = ea_p[i * kbs + kb] + eb_p[j * kbs + kb];
+        if (ex >= -126 && ex <= 127) {                      // wave-uniform
+          const float sc = __uint_as_float(static_cast<unsigned>(127 + ex) << 23);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(P[i][j][e], sc, acc[i][j][e]);
+        } else {                                            // beyond a normal fp32 scale: two exact steps
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += ldexpf(P[i][j][e], ex);
+        }
+      }
+  }
+  __syncthreads();       // every wave is done with the stages: they become the epilogue's staging blocks
+
+  // ---- epilogue; MFMA layout (col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 kh) turned
+  // around in a private LDS block per wave so that every lane stores 16 bytes and a row segment is 256 contiguous bytes
+  const bool partial = (g.splits > 1);
+  float* out = partial ? g.ws + static_cast<long long>(z) * g.M * g.N : g.C;
+  const long long ldo = partial ? g.N : g.ldc;
+  const bool vec_c = ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((ldo & 3) == 0);
+  float* cst = reinterpret_cast<float*>(smem + wave * CSTAGE);
+  const int m0 = tm * (64 * WM), n0 = tn * BN;
+  const int c4 = (lane & 15) * 4, r4 = lane >> 4;
+  const int col = n0 + wn * 64 + c4;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!partial && g.bias) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[q] = (col + q < g.N) ? g.bias[col + q] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        cst[((e & 3) + 8 * (e >> 2) + 4 * kh) * CPITCH + j * 32 + l31] = acc[i][j][e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = r4 + 4 * it;
+      const int row = m0 + wm * 64 + i * 32 + r;
+      const float4 t4 = *reinterpret_cast<const float4*>(cst + r * CPITCH + c4);
+      float v[4] = {t4.x, t4.y, t4.z, t4.w};
+      if (row < g.M && col < g.N) {
+        float* o = out + static_cast<long long>(row) * ldo + col;
+        const bool full = vec_c && (col + 3 < g.N);
+        if (!partial) {
+          if (g.accumulate) {
+            if (full) {
+              const float4 old = *reinterpret_cast<const float4*>(o);
+              v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) if (col + q < g.N) v[q] += o[q];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q] + bv[q], g.act, g.slope);
+        }
+        if (full) {
+          typedef float f4 __attribute__((ext_vector_type(4)));
+          const f4 tt = {v[0], v[1], v[2], v[3]};
+          // a finished C tile is not re-read by this kernel: streamed past the caches; split-K partials are re-read at
+          // once by the reduce kernel and stay cacheable
+          if (!partial) __builtin_nontemporal_store(tt, reinterpret_cast<f4*>(o));
+          else *reinterpret_cast<f4*>(o) = tt;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (col + q < g.N) o[q] = v[q];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+static inline size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+}  // namespace f16x3
+
+// bytes of plane / exponent storage the backend needs for an M x N x K product (on top of the split-K partials)
+size_t f16x3_plane_bytes(long long M, long long N, long long K) {
+  using namespace f16x3;
+  const long long Mp = (M + 255) / 256 * 256, Np = (N + BN - 1) / BN * BN, Kp = (K + 63) / 64 * 64;
+  return align256(static_cast<size_t>(Mp) * Kp * 4) + align256(static_cast<size_t>(Np) * Kp * 4) +
+         align256(static_cast<size_t>(Mp / 32) * (Kp / 64) * 4) + align256(static_cast<size_t>(Np / 32) * (Kp / 64) * 4);
+}
+
+static int x3_variant() {      // tuning aid: SG_X3_VARIANT = 0 auto, 1 <2,2,2>, 2 <2,1,5>, 3 <4,2,3>
+  static const int v = [] { const char* e = getenv("SG_X3_VARIANT"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
+// called by sg_gemm_f32_hip when backend 3 is selected; g.tiles_n is for 128-wide tiles (g.tiles_m is recomputed here for
+// the tile height chosen), g.tiles_per_split is EVEN when g.splits > 1 (a 64-k scale block = two K tiles must not straddle
+// two slices), g.ws holds the split-K partials, `scratch` the plane storage (f16x3_plane_bytes)
+int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scratch, hipStream_t st) {
+  using namespace f16x3;
+  GemmArgs g = g_in;
+  const long long Mp = (static_cast<long long>(g.M) + 255) / 256 * 256, Np = static_cast<long long>(g.tiles_n) * BN;
+  const long long Kp = (static_cast<long long>(g.K) + 63) / 64 * 64;
+  const int KS = static_cast<int>(Kp / 16);
+  if (g.splits > 1 && (g.tiles_per_split & 1)) return fail(SG_ERR_INVALID, "f16x3: odd K-tile count per split-K slice");
+  char* pa = scratch;
+  char* pb = pa + align256(static_cast<size_t>(Mp) * Kp * 4);
+  int* ea = reinterpret_cast<int*>(pb + align256(static_cast<size_t>(Np) * Kp * 4));
+  int* eb = reinterpret_cast<int*>(reinterpret_cast<char*>(ea) + align256(static_cast<size_t>(Mp / 32) * (Kp / 64) * 4));
+  const dim3 ga(static_cast<unsigned>(Mp / 32), static_cast<unsigned>(Kp / 64)), gb(static_cast<unsigned>(Np / 32),
+                                                                                  static_cast<unsigned>(Kp / 64));
+  if (ga.y > 65535u) return fail(SG_ERR_INVALID, "f16x3: K too large for the split grid");
+  if (transA) hipLaunchKernelGGL((split_kernel<true>), ga, dim3(256), 0, st, pa, ea, g.A, g.lda, g.M, g.K, KS, g.vecA);
+  else hipLaunchKernelGGL((split_kernel<false>), ga, dim3(256), 0, st, pa, ea, g.A, g.lda, g.M, g.K, KS, g.vecA);
+  if (transB) hipLaunchKernelGGL((split_kernel<false>), gb, dim3(256), 0, st, pb, eb, g.B, g.ldb, g.N, g.K, KS, g.vecB);
+  else hipLaunchKernelGGL((split_kernel<true>), gb, dim3(256), 0, st, pb, eb, g.B, g.ldb, g.N, g.K, KS, g.vecB);
+  PlaneArgs pl{pa, pb, ea, eb, KS};
+  // variant: short K slices are dominated by the epilogue (two workgroups per CU overlap it); long ones by DMA latency
+  const int ktiles32 = (g.K + 31) / 32;
+  const int slice = g.splits > 1 ? g.tiles_per_split : ktiles32;
+  int variant = x3_variant();
+  if (variant == 0) variant = slice <= 16 ? 1 : 3;
+  if (variant == 3) {
+    g.tiles_m = static_cast<int>((g.M + 255) / 256);
+    const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
+    hipLaunchKernelGGL((gemm_f16x3_kernel<4, 2, 3>), dim3(static_cast<unsigned>(items)), dim3(512), 0, st, g, pl);
+  } else {
+    g.tiles_m = static_cast<int>((g.M + 127) / 128);
+    const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
+    if (variant == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 5>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
+    else hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
+  }
+  return SG_OK;
+}
+
+}  // namespace sg

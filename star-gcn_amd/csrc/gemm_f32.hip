@@ -55,24 +55,42 @@ struct GemmArgs {
   int vecA, vecB;  // 16-byte vector loads allowed
 };
 
+static std::atomic<int> g_backend_override{-1};
+static inline int g_backend_override_load() { return g_backend_override.load(std::memory_order_relaxed); }
 void launch_gemm_bf16x6(const GemmArgs& g, bool transA, bool transB, hipStream_t st);   // gemm_bf16x6.hip
 void launch_gemm_x6v2(const GemmArgs& g, bool transA, bool transB, int n_cus, hipStream_t st);   // gemm_x6v2.hip
 bool x6v2_supported(const GemmArgs& g, bool transA, bool transB);
+size_t f16x3_plane_bytes(long long M, long long N, long long K);                                  // gemm_f16x3.hip
+int launch_gemm_f16x3(const GemmArgs& g, bool transA, bool transB, char* scratch, hipStream_t st);
 
 #ifndef SG_GEMM_DEFAULT_BACKEND
-#define SG_GEMM_DEFAULT_BACKEND 2      // 0 exact-fp32 MFMA (this file), 1 bf16x6, 2 x6v2 (wave-specialised bf16x6)
-#endif
-static int gemm_backend() {            // SG_GEMM_BACKEND = fp32 | bf16x6 | x6v2, read once
+#define SG_GEMM_DEFAULT_BACKEND 3      // 0 exact-fp32 MFMA (this file), 1 bf16x6, 2 x6v2 (wave-specialised bf16x6),
+#endif                                 // 3 f16x3 (pre-split f16 planes, three MFMAs per product)
+static int gemm_backend() {            // SG_GEMM_BACKEND = fp32 | bf16x6 | x6v2 | f16x3, read once
   static const int v = [] {
     const char* e = getenv("SG_GEMM_BACKEND");
     if (!e) return SG_GEMM_DEFAULT_BACKEND;
+    if (e[0] == 'f' && e[1] == '1') return 3;
     if (e[0] == 'x') return 2;
     if (e[0] == 'b') return 1;
     return 0;
   }();
   return v;
 }
-static std::atomic<int> g_backend_override{-1};
+// Backend for a product, from what BOTH the workspace query and the launch know (sizes, layout, the override): the f16x3
+// planes need workspace, so the two must agree.  f16x3 pays one conversion pass per operand: it takes over from K = 96 on
+// (below that the bf16x6 kernel's in-loop split, or the exact kernel, has less to amortise).
+static int backend_for(int64_t M, int64_t N, int64_t K, int transA) {
+  int backend = g_backend_override_load();
+  const bool forced = backend >= 0;
+  if (!forced) backend = gemm_backend();
+  if (K < 1) return 0;
+  // ... and needs enough output tiles to fill the chip with its non-persistent workgroups: a 256 x 256 weight gradient over
+  // 70 k rows (4 tiles, everything in split-K slices) stays on the persistent x6v2 kernel (85 vs 71 TFLOP/s)
+  if (backend == 3 && !forced && (K < 96 || (transA && M <= 64) || ((M + 127) / 128) * ((N + 127) / 128) < 16)) backend = 2;
+  if (backend == 2 && !forced && (K <= 64 || (transA && M <= 64))) backend = 0;
+  return backend;
+}
 static int cu_count() {
   static const int n = [] {
     int dev = 0, c = 0;
@@ -485,12 +503,15 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(float* __restrict__ 
 
 using namespace sg;
 
+static inline size_t ws_align(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
 SG_API size_t sg_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K, int transA) {
-  (void)transA;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   int s, per;
   plan_split(M, N, K, &s, &per);
-  return s > 1 ? static_cast<size_t>(s) * M * N * sizeof(float) : 0;
+  size_t need = s > 1 ? static_cast<size_t>(s) * M * N * sizeof(float) : 0;
+  if (backend_for(M, N, K, transA) == 3) need = ws_align(need) + f16x3_plane_bytes(M, N, K);
+  return need;
 }
 
 SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, int transA, const float* B, int64_t ldb,
@@ -514,36 +535,44 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
   // backend: exact-fp32 MFMA (this file) or the fp32-accurate bf16x6 split on the bf16 matrix cores (gemm_bf16x6.hip)
   // measured (profiles/): bf16x6 wins for row-major A (forward / data-gradient GEMMs), fp32 MFMA for the transposed-A
   // weight gradients; tiny K has nothing to amortise the split
-  int backend = g_backend_override.load(std::memory_order_relaxed);
-  if (backend < 0) backend = gemm_backend();
-  if (K < 1) backend = 0;
+  int backend = backend_for(M, N, K, transA);
   g.vecA = (lda % 4 == 0) && aligned(A, 16);
   g.vecB = (ldb % 4 == 0) && aligned(B, 16);
   if (backend == 2 && !x6v2_supported(g, transA != 0, transB != 0)) backend = 0;   // odd K / unaligned operands: exact-fp32 kernel
-  // x6v2 has nothing to amortise its split on when K is one or two tiles (the rating projection's data gradient,
-  // K = 64) or when the whole output is half a tile high (its weight gradient, 64 x 256 x n): tools/exp_small_gemm.py
-  if (backend == 2 && g_backend_override.load(std::memory_order_relaxed) < 0 && (K <= 64 || (transA && M <= 64))) backend = 0;
-  const bool use_bx6 = backend == 1, use_v2 = backend == 2;
-  if (use_bx6 || use_v2) tm = 128;
+  const bool use_bx6 = backend == 1, use_v2 = backend == 2, use_x3 = backend == 3;
+  if (use_bx6 || use_v2 || use_x3) tm = 128;
+  if (use_x3 && g.splits > 1 && (g.tiles_per_split & 1)) {   // f16x3 scales 64-k blocks = two K tiles: keep slices block-aligned
+    const int ktiles = static_cast<int>((K + BK - 1) / BK);
+    g.tiles_per_split += 1;
+    g.splits = (ktiles + g.tiles_per_split - 1) / g.tiles_per_split;     // never more slices than the workspace query assumed
+  }
   g.tiles_m = static_cast<int>((M + tm - 1) / tm);
   g.tiles_n = static_cast<int>((N + BN - 1) / BN);
   if (static_cast<int64_t>(g.tiles_m) * g.tiles_n >= (1ll << 31)) return fail(SG_ERR_INVALID, "too many tiles");
-  if (g.splits > 1) {
-    const size_t need = static_cast<size_t>(g.splits) * M * N * sizeof(float);
+  size_t need = g.splits > 1 ? static_cast<size_t>(g.splits) * M * N * sizeof(float) : 0;
+  char* planes = nullptr;
+  if (use_x3) {
+    planes = static_cast<char*>(workspace) + ws_align(need);
+    need = ws_align(need) + f16x3_plane_bytes(M, N, K);
+  }
+  if (need) {
     if (!workspace || workspace_bytes < need)
-      return fail(SG_ERR_WORKSPACE, "split-K workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+      return fail(SG_ERR_WORKSPACE, "GEMM workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     g.ws = static_cast<float*>(workspace);
   }
   g.vecA = (lda % 4 == 0) && aligned(A, 16);
   g.vecB = (ldb % 4 == 0) && aligned(B, 16);
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(static_cast<unsigned>(g.tiles_m * g.tiles_n), static_cast<unsigned>(g.splits));
+#define SG_TRY_RC(expr_) do { const int rc_ = (expr_); if (rc_ != SG_OK) return rc_; } while (0)
 #define SG_LAUNCH_GEMM(TA_, TB_)                                                                         \
   do {                                                                                                  \
     if (tm == 128) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, 128>), grid, dim3(kThreads), 0, st, g); \
     else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, 64>), grid, dim3(kThreads), 0, st, g);            \
   } while (0)
-  if (use_v2) {
+  if (use_x3) {
+    SG_TRY_RC(launch_gemm_f16x3(g, transA != 0, transB != 0, planes, st));
+  } else if (use_v2) {
     launch_gemm_x6v2(g, transA != 0, transB != 0, cu_count(), st);
   } else if (use_bx6) {
     launch_gemm_bf16x6(g, transA != 0, transB != 0, st);
@@ -560,9 +589,9 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
   return check_launch("gemm_f32");
 }
 
-// tuning aid (tests, benchmarks): GEMM backend 0 exact-fp32 MFMA, 1 bf16x6, 2 x6v2; -1 = environment / build default
+// tuning aid (tests, benchmarks): GEMM backend 0 exact-fp32 MFMA, 1 bf16x6, 2 x6v2, 3 f16x3; -1 = environment / build default
 SG_API int sg_gemm_backend(int backend) {
-  g_backend_override.store(backend < 0 || backend > 2 ? -1 : backend, std::memory_order_relaxed);
+  g_backend_override.store(backend < 0 || backend > 3 ? -1 : backend, std::memory_order_relaxed);
   return SG_OK;
 }
 

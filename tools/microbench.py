@@ -39,7 +39,7 @@ def gemm_cases():
         b = torch.randn((N, K) if tb else (K, N), device="cuda")
         from star_gcn_amd import _lib as L
         res = []
-        for be, nm in ((0, "fp32"), (1, "x6"), (2, "x6v2")):
+        for be, nm in ((0, "fp32"), (2, "x6v2"), (3, "f16x3")):
             L.lib().sg_gemm_backend(be)
             t = timeit(lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb))
             res.append("%s %6.3f ms %5.1f TF/s" % (nm, t * 1e3, 2.0 * M * N * K / t / 1e12))
@@ -62,7 +62,7 @@ def gemm_big_cases():
         b = torch.randn((N, K) if tb else (K, N), device="cuda")
         res = []
         from star_gcn_amd import _lib as L
-        for be, nm in ((0, "fp32"), (1, "x6"), (2, "x6v2")):
+        for be, nm in ((2, "x6v2"), (3, "f16x3")):
             L.lib().sg_gemm_backend(be)
             t = timeit(lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb), n=5, warm=2)
             res.append("%s %8.3f ms %6.1f TF/s" % (nm, t * 1e3, 2.0 * M * N * K / t / 1e12))

@@ -1,0 +1,15 @@
+#!/bin/bash
+# kernel trace + PMC passes on the f16x3 GEMM (one counter group per run):  tools/pmc_f16x3.sh "M N K ta tb" [variant]
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+O=gpurun_out/pmc_f16x3; rm -rf $O; mkdir -p $O
+SHAPE="${1:-4096 4096 4096 0 1} 3"
+export SG_X3_VARIANT="${2:-0}"
+timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o run -- python tools/one_gemm.py $SHAPE > $O/trace.log 2>&1
+i=0
+for grp in "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD" \
+           "SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout -s KILL 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/g$i -o run -- python tools/one_gemm.py $SHAPE > $O/g$i.log 2>&1
+done
+python tools/prof_summary.py $O 2>/dev/null | grep -E "^#|f16x3|split_kernel|Name" | grep -v "kernel_trace"
