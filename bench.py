@@ -126,6 +126,9 @@ def parse():
                    help="also time the step as ONE hipGraph replay (secondary figure `graph_replay`; opt-in: stream capture of "
                         "an autograd step depends on the torch build)")
     p.add_argument("--hbm-only", action="store_true", help="run only the HBM-bound leg (profiling)")
+    p.add_argument("--verify-only", choices=["main", "hbm"], default=None,
+                   help="build one leg's workload exactly as the benchmark does, run ONE step and print its float64 "
+                        "verification as JSON (tests/test_gpu_bench_verify.py runs this in a subprocess)")
     p.add_argument("--hbm-steps", type=int, default=3)
     p.add_argument("--hbm-shape", default="1250000,1000000,125000000,16",
                    help="n_user,n_item,n_edges,n_levels of the HBM-bound leg (default: 1-GPU shard of BASELINE config 5)")
@@ -202,6 +205,7 @@ def verify_leg(net, step, arrays, y, scale):
     out = FC.verify_step(net, step, arrays, y, scale, U, I)
     torch.cuda.synchronize()
     out["seconds"] = round(time.perf_counter() - t0, 2)
+    out["peak_hbm_gb_incl_checker"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
     out["tolerance"] = VERIFY_TOL
     out["ok"] = bool(out["max_rel_err"] <= VERIFY_TOL)
     out["method"] = ("float64 evaluation of the definition (aggregators.py:141-160, layers.py:147-187, STAR-GCN.py:428-438) "
@@ -608,6 +612,22 @@ def run_rank(args):
     if args.hbm_only:
         out = {"metric": METRIC, "hbm_bound": hbm_leg(args, dev)}
         print(json.dumps(out))
+        return
+    if args.verify_only:
+        if args.verify_only == "main":
+            c = main_case(args.shape, args.dim, args.order, dev)
+            pp = c.plan["idx"][0]["pair"].item_side_partition(64)
+            v = verify_leg(c.net, c.step, (c.dgraph.ind_ptr, c.dgraph.end_points, c.dgraph.level, c.n_item, c.R, None),
+                           c.y, 1.0 / c.E_total)
+            v.update(n_user=c.n_user, n_item=c.n_item, edges=c.E_total, levels=c.R,
+                     rating_head_item_side_parts=(pp.parts if pp is not None else 1))
+            a, b = float(c.step().detach()), float(c.step().detach())
+            v["deterministic"] = (a == b)
+        else:
+            c = hbm_case(args.hbm_shape, args.dim, args.order, dev)
+            v = verify_leg(c.net, c.step, (c.dg.ind_ptr, c.dg.end_points, c.dg.level, c.ni, c.R, None), c.y, 1.0 / c.E)
+            v.update(n_user=c.nu, n_item=c.ni, edges=c.E, levels=c.R)
+        print(json.dumps({"verify": v}))
         return
     if args.shape == "config5":
         run_config5(args, dev, dist_on, world, rank, backend)

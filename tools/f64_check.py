@@ -19,7 +19,7 @@ product's fp32 results -- loss, every layer's output rows for both node types, t
 every embedding row and every weight / bias gradient -- are compared element by element.  A 2-hop network has a
 receptive field of (nearly) the whole graph, so anything short of a full evaluation could not check a single output row
 end to end.  Cost at the 125 M-rating shard of BASELINE config 5 on an MI355X: a few seconds (fp64 GEMMs + chunked
-index_add_), about 60 GB of temporaries.
+index_add_), about 25 GB of temporaries.
 
 Used by tests/test_gpu_bench_verify.py and by bench.py's `verify` block (outside every timed region).
 """
@@ -92,43 +92,53 @@ class RawGraph(object):
 
 
 class _Agg(object):
-    """act( sum_r A_r (x W_r^T + b_r) ) and its gradients, float64, definition order"""
+    """act( sum_r A_r (x W_r^T + b_r) ) and its gradients, float64, definition order: level by level, FullyConnected of
+    the level then seg_weighted_pool over the level's edges (memory stays at a few (n, U) float64 matrices; evaluating all
+    levels at once would need a 41 GB (n_src, R U) matrix at the config-5 shard)."""
 
     def __init__(self, g, dst, Ws, bs):
         self.g, self.dst = g, dst
-        self.W = torch.cat([w.double() for w in Ws], 0)            # (R*U, D): row block r = W_r
-        self.b = torch.cat([b.double() for b in bs], 0)            # (R*U)
+        self.W = [w.double() for w in Ws]                          # R x (U, D)
+        self.b = [b.double() for b in bs]
         self.U = Ws[0].shape[0]
 
+    def _level_edges(self, r):
+        idx = (self.g.level == r).nonzero().view(-1)
+        for a in range(0, idx.numel(), self.g.chunk):
+            yield idx[a:a + self.g.chunk]
+
     def forward(self, x):
-        g, R, U = self.g, self.g.R, self.U
+        g = self.g
         d_e, s_e, w_e = g.edges(self.dst)
-        H = (x @ self.W.t() + self.b).view(-1, U)                  # row (src*R + r) = FullyConnected_r(x)[src]
-        out = torch.zeros(g.n(self.dst), U, dtype=torch.float64, device=x.device)
-        for a in range(0, g.E, g.chunk):
-            sl = slice(a, a + g.chunk)
-            rows = H[s_e[sl].long() * R + g.level[sl].long()]
-            rows *= w_e[sl].double()[:, None]
-            out.index_add_(0, d_e[sl].long(), rows)
+        out = torch.zeros(g.n(self.dst), self.U, dtype=torch.float64, device=x.device)
+        for r in range(g.R):
+            H = x @ self.W[r].t() + self.b[r]                       # FullyConnected_r(x): (n_src, U)
+            for sel in self._level_edges(r):
+                rows = H[s_e[sel].long()]
+                rows *= w_e[sel].double()[:, None]
+                out.index_add_(0, d_e[sel].long(), rows)
+            del H
         self.x, self.pre = x, out
         return _leaky(out)
 
     def backward(self, dh, prod_out=None, stats=None):
-        g, R, U = self.g, self.g.R, self.U
+        g = self.g
         d_e, s_e, w_e = g.edges(self.dst)
         dpre = dh * _dleaky(self.pre, prod_out, stats)
-        G = torch.zeros(self.x.shape[0] * R, U, dtype=torch.float64, device=dh.device)   # d H
-        for a in range(0, g.E, g.chunk):
-            sl = slice(a, a + g.chunk)
-            rows = dpre[d_e[sl].long()]
-            rows *= w_e[sl].double()[:, None]
-            G.index_add_(0, s_e[sl].long() * R + g.level[sl].long(), rows)
-        G = G.view(self.x.shape[0], R * U)
-        dW = G.t() @ self.x                                        # (R*U, D)
-        db = G.sum(0)
-        dx = G @ self.W
+        dx = torch.zeros_like(self.x)
+        dW, db = [], []
+        for r in range(g.R):
+            G = torch.zeros(self.x.shape[0], self.U, dtype=torch.float64, device=dh.device)     # d H_r
+            for sel in self._level_edges(r):
+                rows = dpre[d_e[sel].long()]
+                rows *= w_e[sel].double()[:, None]
+                G.index_add_(0, s_e[sel].long(), rows)
+            dW.append(G.t() @ self.x)
+            db.append(G.sum(0))
+            dx += G @ self.W[r]
+            del G
         self.pre = self.x = None
-        return dx, list(dW.view(R, U, -1).unbind(0)), list(db.view(R, U).unbind(0))
+        return dx, dW, db
 
 
 class _Dense(object):
@@ -308,6 +318,9 @@ def verify_step(net, run_step, graph_arrays, y, scale, name_user="user", name_it
         loss = run_step()
     finally:
         cap.close()
+    if loss.is_cuda:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()          # hand the step's cached temporaries back before the float64 pass allocates
     g = RawGraph(*graph_arrays)
     ref = evaluate(g, net_params(net, name_user, name_item), y, scale, product=cap)
     out = compare(net, cap, loss.detach(), ref, name_user, name_item)
