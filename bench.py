@@ -121,6 +121,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-hbm-leg", action="store_true")
     p.add_argument("--no-ceiling", action="store_true")
+    p.add_argument("--no-minibatch-leg", action="store_true", help="skip the ML-1M mini-batch training-iteration leg")
     p.add_argument("--no-verify", action="store_true", help="skip the float64 verification of both legs (profiling runs)")
     p.add_argument("--graph-replay", action="store_true",
                    help="also time the step as ONE hipGraph replay (secondary figure `graph_replay`; opt-in: stream capture of "
@@ -746,15 +747,23 @@ def run_rank(args):
                                       "communication stream (they overlap compute); exposed_ms: per rank, time the "
                                       "compute stream sat blocked on a collective's completion event"}
         out["ms_per_step_per_rank"] = rank_ms
-    if world == 1 and not dist_on and args.graph_replay:
+    if args.graph_replay and (not dist_on or backend == "nccl"):
         # secondary figure: the same step as ONE hipGraph replay (the library's launches captured through
         # torch.cuda.CUDAGraph, as examples/train_star_gcn.py --graph does for the whole training iteration).  Not the
         # headline: the HIP events that time the gathers for `roofline` cannot live inside a captured graph.
+        # Partitioned runs capture their RCCL all-reduces with the step (communication stream forked from and joined
+        # back into the capturing stream, dist._launch_sum): every rank captures and replays the same sequence.
         try:
             del loss                  # the last step's autograd graph (and its AccumulateGrad nodes) must be gone
             out["graph_replay"] = graph_replay(step, dev, args.steps)
+            if dist_on:
+                tmax = torch.tensor([out["graph_replay"]["ms_per_step"]], device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                out["graph_replay"]["ms_per_step"] = float(tmax.item())
+                out["graph_replay"]["note"] += "; RCCL all-reduces captured inside the graph, max over ranks"
         except Exception as e:      # capture support is a property of the torch build, not of the path
             out["graph_replay"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        loss = None
     if world == 1 and not dist_on and not args.no_verify:
         loss = None
         out["verify"] = verify_leg(net, step, (dgraph.ind_ptr, dgraph.end_points, dgraph.level, n_item, R, None), y,
@@ -765,12 +774,97 @@ def run_rank(args):
     if rank == 0 and world == 1 and not args.no_hbm_leg:
         torch.cuda.reset_peak_memory_stats(dev)
         out["hbm_bound"] = hbm_leg(args, dev)
+    if rank == 0 and world == 1 and not dist_on and not args.no_minibatch_leg:
+        try:
+            out["minibatch_iteration"] = minibatch_leg(dev)
+        except Exception as e:      # a secondary figure must never cost the headline
+            out["minibatch_iteration"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(graph, D, args)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()
+
+
+def minibatch_leg(dev, shape="ml-1m", batch=100000, iters=20):
+    """Secondary figure: one TRAINING ITERATION of the reference's real loop
+    (experiments/STAR-GCN.py:583-632) -- rating mini-batch + masked-reconstruction nodes sampled, the batch's rating edges
+    removed from the aggregation graph in both directions (graph.py:952-974), 2-block STAR-GCN with decoder (AGG 250 /
+    OUT 75, dropout 0.5), both losses, backward, global-norm clipping, Adam -- on an ML-1M-shaped synthetic graph with
+    everything resident: plan of the whole training graph in HBM (resident.ResidentPlan), edge removal, samplers and
+    batch plans on the device (device_sampler.DeviceBatchSampler).  Timed eagerly and as ONE hipGraph replay."""
+    import star_gcn_amd.model as M
+    import star_gcn_amd.synthetic as S
+    from star_gcn_amd.device_sampler import DeviceBatchSampler
+    from star_gcn_amd.mxgraph.iterators import DataIterator
+    from star_gcn_amd.resident import ResidentPlan
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    graph, eu, ei, vals = S.make_graph(shape, signal=True)
+    n = eu.size
+    perm = rng.permutation(n)
+    n_test, n_valid = int(0.2 * n), int(0.08 * n)
+    it = DataIterator(graph, U, I, np.stack([eu[perm[:n_test]], ei[perm[:n_test]]]),
+                      np.stack([eu[perm[n_test:n_test + n_valid]], ei[perm[n_test:n_test + n_valid]]]),
+                      embed_P_mask=0.1, embed_p_zero=0.0, embed_p_self=1.0, seed=0)
+    tv = it.train_graph[U, I].values
+    mean, std = float(tv.mean()), float(tv.std())
+    net = M.Net(graph, U, I, embed_units=64, agg_units=(250,), out_units=(75,), nblocks=2, use_dae=True, dropout=0.5,
+                agg_accum="sum").to(dev)
+    resident = ResidentPlan(net, it.train_graph, device=dev)
+    sampler = DeviceBatchSampler(resident, batch, embed_P_mask=0.1, embed_p_zero=0.0, seed=0)
+    state = dict()
+
+    def iteration(advance):
+        db = sampler.next_batch(advance_on_device=advance)
+        y = (db["ratings"] - mean) / std
+        preds, recons, gt = net.run(resident.set_batch_device(db), rating_targets=y, rating_scale=1.0 / y.numel())
+        loss = M.star_gcn_loss(preds, recons, gt, y, recon_lambda=0.1)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0, foreach=True)
+        state["opt"].step()
+        state["opt"].zero_grad(set_to_none=True)
+        return loss.detach()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        net.run(resident.set_batch_device(sampler.next_batch(advance_on_device=True)))      # materialises the parameters
+        state["opt"] = torch.optim.Adam(net.parameters(), lr=0.002, capturable=True)
+        for _ in range(3):
+            iteration(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            loss = iteration(True)
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) / iters * 1e3
+    torch.cuda.current_stream().wait_stream(side)
+    out = {"workload": "%s-shaped synthetic graph (%d users x %d items, %d training ratings), batch %d ratings, 2-block "
+                       "STAR-GCN with decoder (embed 64, AGG 250, OUT 75, dropout 0.5), rating + reconstruction loss, "
+                       "clipping, Adam; resident plan, device edge removal / samplers / batch plans" %
+                       (shape, graph[U, I].shape[0], graph[U, I].shape[1], it.train_graph[U, I].nnz, batch),
+           "iters": iters, "ms_per_iteration_eager": eager_ms, "loss": float(loss)}
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            state["loss"] = iteration(True)
+        torch.cuda.synchronize()
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            g.replay()
+        torch.cuda.synchronize()
+        out["ms_per_iteration_hipgraph"] = (time.perf_counter() - t0) / iters * 1e3
+        out["loss_after_replays"] = float(state["loss"])
+    except Exception as e:      # capture support is a property of the torch build
+        out["ms_per_iteration_hipgraph"] = None
+        out["hipgraph_error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+    return out
 
 
 def cpu_baseline(graph, D, args):

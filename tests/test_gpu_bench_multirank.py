@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--shape", "ml-100k", "--dim", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-leg",
-          "--no-ceiling"]
+          "--no-ceiling", "--no-minibatch-leg", "--no-verify"]
 
 
 def _bench(extra, env_extra):
@@ -36,6 +36,7 @@ def test_bench_self_launches_two_ranks_and_matches_single_rank():
     l1, l2 = one["config"]["loss"], two["config"]["loss"]
     assert abs(l1 - l2) <= 1e-5 * max(1.0, abs(l1)), (l1, l2)
     assert one["metric"] == two["metric"] and one["roofline"] is not None
+    assert len(two["ms_per_step_per_rank"]) == 2 and len(two["collectives"]["exposed_ms_per_step_per_rank"]) == 2
 
 
 def test_bench_rccl_code_path_with_one_rank():
@@ -195,3 +196,19 @@ def test_bench_step_replays_as_one_hipgraph():
     g = r["graph_replay"]
     assert "error" not in g, g
     assert g["ms_per_step"] > 0 and abs(g["loss"] - r["config"]["loss"]) <= 1e-6 * max(1.0, abs(r["config"]["loss"]))
+
+
+def test_partitioned_step_with_rccl_replays_as_one_hipgraph():
+    """The partitioned step -- item-side all-reduces on the communication stream, gradient all-reduce of the local-region
+    parameters -- captured INCLUDING its RCCL collectives and replayed as one hipGraph (one rank here; every rank of an
+    N-GPU run captures and replays the same sequence).  The replay reproduces the eager loss."""
+    r = _bench(["--graph-replay"], {"SG_BENCH_FORCE_DIST": "1"})
+    assert r["collectives"]["backend"] == "nccl"
+    g = r["graph_replay"]
+    assert "error" not in g, g
+    assert g["ms_per_step"] > 0 and abs(g["loss"] - r["config"]["loss"]) <= 1e-6 * max(1.0, abs(r["config"]["loss"]))
+    assert "RCCL" in g["note"]
+    # per-rank step time and the time the compute stream sat blocked on a collective
+    assert len(r["ms_per_step_per_rank"]) == 1 and r["ms_per_step_per_rank"][0] > 0
+    ex = r["collectives"]["exposed_ms_per_step_per_rank"]
+    assert len(ex) == 1 and 0.0 <= ex[0] <= r["ms_per_step"]
