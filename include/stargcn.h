@@ -466,6 +466,24 @@ int sg_bounds_from_sorted_hip(int32_t* out_indptr, const int32_t* sorted_keys, i
 int sg_gather_i32_hip(int32_t* dst, const int32_t* src, const int32_t* pos, int64_t n, void* stream);
 int sg_inverse_index_hip(int32_t* inv, const int32_t* ids, int64_t n_ids, int64_t n_rows, void* stream);
 
+/* Device twins of the last host-only plan primitives.
+ *   sg_unique_inverse_hip       unique_inverse / unique_cnt, graph_sampler.h:441-534 (py_ext.cpp:612-627): unique ids in
+ *                               FIRST-OCCURRENCE order for ids in [0, max_id], + inverse, + counts (may be NULL).  Same
+ *                               outputs as sg_unique_inverse_cpu; the number of unique ids goes to DEVICE memory
+ *                               (*n_uniq_dev), *bad_dev (may be NULL) becomes 1 when an id lies outside [0, max_id].
+ *                               Integer atomicMin / atomicAdd only: the result does not depend on execution order.
+ *   sg_sample_fix_neighbor_hip  random_sample_fix_neighbor, graph_sampler.cpp:742-779: bit-identical to
+ *                               sg_sample_fix_neighbor_cpu for the same seed (row i's draw depends on (seed, i) only,
+ *                               positions ascending).  sampled == NULL: only dst_ind_ptr (sel_num + 1, device). */
+size_t sg_unique_inverse_workspace_bytes(int64_t n, int64_t max_id);
+int sg_unique_inverse_hip(int32_t* uniq, int32_t* inverse, int32_t* counts, int32_t* n_uniq_dev, int32_t* bad_dev,
+                          const int32_t* ids, int64_t n, int64_t max_id, void* workspace, size_t workspace_bytes,
+                          void* stream);
+size_t sg_sample_fix_neighbor_workspace_bytes(int64_t sel_num);
+int sg_sample_fix_neighbor_hip(int32_t* sampled, int32_t* dst_ind_ptr, const int32_t* src_ind_ptr,
+                               const int32_t* sel_indices, int64_t sel_num, int64_t neighbor_num, uint64_t seed,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

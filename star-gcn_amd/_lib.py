@@ -114,6 +114,10 @@ _SIGS = {
     "sg_bounds_from_sorted_hip": (_INT, [_P, _P, _I64, _I64, _P]),
     "sg_gather_i32_hip": (_INT, [_P, _P, _P, _I64, _P]),
     "sg_inverse_index_hip": (_INT, [_P, _P, _I64, _I64, _P]),
+    "sg_unique_inverse_workspace_bytes": (_SZ, [_I64, _I64]),
+    "sg_unique_inverse_hip": (_INT, [_P] * 6 + [_I64, _I64, _P, _SZ, _P]),
+    "sg_sample_fix_neighbor_workspace_bytes": (_SZ, [_I64]),
+    "sg_sample_fix_neighbor_hip": (_INT, [_P] * 4 + [_I64, _I64, _c.c_uint64, _P, _SZ, _P]),
     "sg_multilink_agg_resolve_order": (_INT, [_P, _INT]),
     "sg_multilink_agg_saved_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT]),
     "sg_multilink_agg_workspace_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT, _INT]),

@@ -930,3 +930,171 @@ SG_API int sg_part_keys_hip(int32_t* keys, const int32_t* src_ids, const int32_t
                      bounds, static_cast<int>(parts), static_cast<long long>(n_seg), static_cast<long long>(n));
   return check_launch("sg_part_keys_hip");
 }
+
+// ---- device twins of the last host-only plan primitives --------------------------------------------
+namespace sg {
+namespace {
+// unique_inverse, first-occurrence order (graph_sampler.h:465-534), for ids in [0, max_id]:
+//   first[v] = smallest position holding v (atomicMin on integers: order-independent, so deterministic);
+//   a position is a HEAD when it is the first occurrence of its value; heads numbered by an exclusive scan over the
+//   positions = rank of the value in first-occurrence order; slot[v] = that rank; inverse[i] = slot[ids[i]].
+__global__ void ui_first_kernel(int32_t* __restrict__ first, int32_t* __restrict__ bad, const int32_t* __restrict__ ids,
+                                long long n, long long max_id) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t v = ids[i];
+  if (v < 0 || v > max_id) { atomicMax(bad, 1); return; }
+  atomicMin(first + v, static_cast<int32_t>(i));
+}
+__global__ void ui_heads_kernel(int32_t* __restrict__ head, const int32_t* __restrict__ first, const int32_t* __restrict__ ids,
+                                long long n, long long max_id) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t v = ids[i];
+  head[i] = (v >= 0 && v <= max_id && first[v] == static_cast<int32_t>(i)) ? 1 : 0;
+}
+__global__ void ui_uniq_kernel(int32_t* __restrict__ uniq, int32_t* __restrict__ slot, const int32_t* __restrict__ rank,
+                               const int32_t* __restrict__ first, const int32_t* __restrict__ ids, long long n,
+                               long long max_id) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t v = ids[i];
+  if (v >= 0 && v <= max_id && first[v] == static_cast<int32_t>(i)) {
+    uniq[rank[i]] = v;
+    slot[v] = rank[i];
+  }
+}
+__global__ void ui_inverse_kernel(int32_t* __restrict__ inverse, int32_t* __restrict__ counts, const int32_t* __restrict__ slot,
+                                  const int32_t* __restrict__ ids, long long n, long long max_id) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t v = ids[i];
+  if (v < 0 || v > max_id) return;
+  const int32_t s = slot[v];
+  if (inverse) inverse[i] = s;
+  if (counts) atomicAdd(counts + s, 1);       // integer counts: order-independent
+}
+
+// random_sample_fix_neighbor (graph_sampler.cpp:742-779): the arithmetic of sg_sample_fix_neighbor_cpu, one thread per
+// selected row -- row i's draw depends on (seed, i) only, positions ascending -- so host and device agree bit for bit
+__device__ __forceinline__ uint64_t splitmix64_dev(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void sfn_lens_kernel(int32_t* __restrict__ lens, const int32_t* __restrict__ src_ind_ptr,
+                                const int32_t* __restrict__ sel, long long sel_num, long long k) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= sel_num) return;
+  const int32_t len = src_ind_ptr[sel[i] + 1] - src_ind_ptr[sel[i]];
+  lens[i] = (k < 0) ? len : static_cast<int32_t>(min(static_cast<long long>(len), k));
+}
+__global__ void sfn_fill_kernel(int32_t* __restrict__ sampled, const int32_t* __restrict__ dst_ind_ptr,
+                                const int32_t* __restrict__ src_ind_ptr, const int32_t* __restrict__ sel, long long sel_num,
+                                uint64_t seed) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= sel_num) return;
+  const int32_t b = src_ind_ptr[sel[i]], e = src_ind_ptr[sel[i] + 1];
+  const int32_t k = dst_ind_ptr[i + 1] - dst_ind_ptr[i], len = e - b;
+  int32_t* out = sampled + dst_ind_ptr[i];
+  if (k == len) {
+    for (int32_t j = 0; j < len; ++j) out[j] = b + j;
+    return;
+  }
+  uint64_t st = seed ^ (0xD1B54A32D192ED03ull * static_cast<uint64_t>(i + 1));
+  int32_t n = 0;
+  for (int32_t j = len - k; j < len; ++j) {      // Floyd: k distinct values of [0, len), kept sorted
+    const int32_t t = static_cast<int32_t>(splitmix64_dev(st) % static_cast<uint64_t>(j + 1));
+    int32_t v = b + t;
+    int32_t lo = 0, hi = n;                      // lower_bound(out, out + n, v)
+    while (lo < hi) {
+      const int32_t mid = (lo + hi) >> 1;
+      if (out[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    if (lo != n && out[lo] == v) {               // already chosen -> take j itself (larger than everything chosen so far)
+      v = b + j;
+      lo = n;
+    }
+    for (int32_t q = n; q > lo; --q) out[q] = out[q - 1];
+    out[lo] = v;
+    ++n;
+  }
+}
+}  // namespace
+}  // namespace sg
+
+SG_API size_t sg_unique_inverse_workspace_bytes(int64_t n, int64_t max_id) {
+  if (n < 0 || max_id < -1) return 0;
+  // first[max_id+1] | slot[max_id+1] | head / rank [n+1] | bad flag | scan
+  return 2 * sg::al256(static_cast<size_t>(max_id + 1) * 4 + 4) + sg::al256(static_cast<size_t>(n + 1) * 4) + 256 +
+         sg::scan_ws_bytes(n) + 256;
+}
+// uniq (n entries, *n_uniq_dev used), inverse (n) and counts (n, may be NULL) as sg_unique_inverse_cpu; the number of
+// unique ids is written to DEVICE memory (no host synchronisation); *bad_dev (may be NULL) is set to 1 when an id lies
+// outside [0, max_id] (such positions get no inverse)
+SG_API int sg_unique_inverse_hip(int32_t* uniq, int32_t* inverse, int32_t* counts, int32_t* n_uniq_dev, int32_t* bad_dev,
+                                 const int32_t* ids, int64_t n, int64_t max_id, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  using namespace sg;
+  if (n < 0 || max_id < -1 || n >= (1ll << 31) - 1) return fail(SG_ERR_INVALID, "bad unique_inverse arguments");
+  if (!n_uniq_dev || (n > 0 && (!uniq || !ids))) return fail(SG_ERR_INVALID, "null pointer argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    if (hipMemsetAsync(n_uniq_dev, 0, 4, st) != hipSuccess) return fail(SG_ERR_HIP, "memset");
+    return SG_OK;
+  }
+  if (!workspace || workspace_bytes < sg_unique_inverse_workspace_bytes(n, max_id))
+    return fail(SG_ERR_WORKSPACE, "unique_inverse workspace too small");
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  const size_t tb = al256(static_cast<size_t>(max_id + 1) * 4 + 4);
+  int32_t* first = reinterpret_cast<int32_t*>(base);
+  int32_t* slot = reinterpret_cast<int32_t*>(base + tb);
+  int32_t* rank = reinterpret_cast<int32_t*>(base + 2 * tb);
+  int32_t* bad = reinterpret_cast<int32_t*>(base + 2 * tb + al256(static_cast<size_t>(n + 1) * 4));
+  void* scan_ws = reinterpret_cast<char*>(bad) + 256;
+  if (hipMemsetAsync(first, 0x7f, tb, st) != hipSuccess || hipMemsetAsync(bad, 0, 4, st) != hipSuccess)
+    return fail(SG_ERR_HIP, "memset");
+  if (counts && hipMemsetAsync(counts, 0, static_cast<size_t>(n) * 4, st) != hipSuccess) return fail(SG_ERR_HIP, "memset");
+  hipLaunchKernelGGL(ui_first_kernel, dim3(blocks(n)), dim3(256), 0, st, first, bad, ids, static_cast<long long>(n),
+                     static_cast<long long>(max_id));
+  hipLaunchKernelGGL(ui_heads_kernel, dim3(blocks(n)), dim3(256), 0, st, rank, first, ids, static_cast<long long>(n),
+                     static_cast<long long>(max_id));
+  int rc = exclusive_scan(rank, rank, n, true, scan_ws, st);
+  if (rc != SG_OK) return rc;
+  hipLaunchKernelGGL(ui_uniq_kernel, dim3(blocks(n)), dim3(256), 0, st, uniq, slot, rank, first, ids, static_cast<long long>(n),
+                     static_cast<long long>(max_id));
+  if (inverse || counts)
+    hipLaunchKernelGGL(ui_inverse_kernel, dim3(blocks(n)), dim3(256), 0, st, inverse, counts, slot, ids,
+                       static_cast<long long>(n), static_cast<long long>(max_id));
+  if (hipMemcpyAsync(n_uniq_dev, rank + n, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(SG_ERR_HIP, "memcpy");
+  if (bad_dev && hipMemcpyAsync(bad_dev, bad, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(SG_ERR_HIP, "memcpy");
+  return check_launch("sg_unique_inverse_hip");
+}
+
+SG_API size_t sg_sample_fix_neighbor_workspace_bytes(int64_t sel_num) {
+  return sel_num < 0 ? 0 : sg::scan_ws_bytes(sel_num) + 256;
+}
+// device twin of sg_sample_fix_neighbor_cpu, bit-identical for the same seed.  sampled == NULL: only dst_ind_ptr
+// (sel_num + 1, device) is filled -- read its last entry to size `sampled`, then call again with both.
+SG_API int sg_sample_fix_neighbor_hip(int32_t* sampled, int32_t* dst_ind_ptr, const int32_t* src_ind_ptr,
+                                      const int32_t* sel_indices, int64_t sel_num, int64_t neighbor_num, uint64_t seed,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace sg;
+  if (sel_num < 0 || sel_num >= (1ll << 31) - 1) return fail(SG_ERR_INVALID, "bad dimension");
+  if (!dst_ind_ptr || !src_ind_ptr || (sel_num > 0 && !sel_indices)) return fail(SG_ERR_INVALID, "null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!sampled) {
+    if (sel_num > 0 && (!workspace || workspace_bytes < sg_sample_fix_neighbor_workspace_bytes(sel_num)))
+      return fail(SG_ERR_WORKSPACE, "sample_fix_neighbor workspace too small");
+    if (sel_num > 0)
+      hipLaunchKernelGGL(sfn_lens_kernel, dim3(blocks(sel_num)), dim3(256), 0, st, dst_ind_ptr, src_ind_ptr, sel_indices,
+                         static_cast<long long>(sel_num), static_cast<long long>(neighbor_num));
+    char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+    return exclusive_scan(dst_ind_ptr, dst_ind_ptr, sel_num, true, base, st);
+  }
+  if (sel_num > 0)
+    hipLaunchKernelGGL(sfn_fill_kernel, dim3(blocks(sel_num)), dim3(256), 0, st, sampled, dst_ind_ptr, src_ind_ptr,
+                       sel_indices, static_cast<long long>(sel_num), seed);
+  return check_launch("sg_sample_fix_neighbor_hip");
+}

@@ -181,3 +181,42 @@ def synthetic_device_graph(n_user, n_item, n_edges, n_levels, device, seed=0, na
     level = level.clamp_(max=n_levels - 1).to(torch.int32)
     return DeviceBipartite(ind_ptr.to(torch.int32), i.to(torch.int32), level, n_item, level_values(n_levels),
                            name_user, name_item)
+
+
+# ---- device twins of the remaining host-only plan primitives -----------------------------------------
+def unique_inverse_device(ids, max_id, return_counts=False):
+    """unique_inverse / unique_cnt of the reference (graph_sampler.h:441-534) for a DEVICE id tensor with values in
+    [0, max_id]: (unique ids in first-occurrence order, inverse[, counts]).  One 4-byte read-back sizes the result
+    (sg_unique_inverse_hip keeps the count on the device for callers that do not need it on the host)."""
+    ids = L.i32c(ids).view(-1)
+    n, dev = int(ids.numel()), ids.device
+    lib, st = L.lib(), L.stream_ptr()
+    uniq, inv = _i32(n, dev), _i32(n, dev)
+    counts = _i32(n, dev) if return_counts else None
+    meta = torch.zeros(2, dtype=torch.int32, device=dev)
+    ws, wsn = L.workspace(lib.sg_unique_inverse_workspace_bytes(n, int(max_id)), dev)
+    L.check(lib.sg_unique_inverse_hip(L.ptr(uniq), L.ptr(inv), L.ptr(counts), L.ptr(meta), L.ptr(meta[1:]), L.ptr(ids), n,
+                                      int(max_id), L.ptr(ws), wsn, st), "sg_unique_inverse_hip")
+    m, bad = (int(x) for x in meta.tolist())
+    if bad:
+        raise L.StarGCNError("unique_inverse_device: an id lies outside [0, %d]" % int(max_id))
+    out = (uniq[:m], inv[:n]) + ((counts[:m],) if return_counts else ())
+    return out
+
+
+def sample_fix_neighbor_device(ind_ptr, sel_indices, neighbor_num, seed):
+    """random_sample_fix_neighbor of the reference (graph_sampler.cpp:742-779) on DEVICE tensors: (edge positions,
+    dst_ind_ptr) -- bit-identical to the host sampler (sg_sample_fix_neighbor_cpu) for the same seed."""
+    ind_ptr, sel = L.i32c(ind_ptr), L.i32c(sel_indices).view(-1)
+    n, dev = int(sel.numel()), ind_ptr.device
+    lib, st = L.lib(), L.stream_ptr()
+    dst_ptr = _i32(n + 1, dev)
+    ws, wsn = L.workspace(lib.sg_sample_fix_neighbor_workspace_bytes(n), dev)
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    L.check(lib.sg_sample_fix_neighbor_hip(None, L.ptr(dst_ptr), L.ptr(ind_ptr), L.ptr(sel), n, int(neighbor_num), seed,
+                                           L.ptr(ws), wsn, st), "sg_sample_fix_neighbor_hip")
+    total = int(dst_ptr[n].item())
+    sampled = _i32(total, dev)
+    L.check(lib.sg_sample_fix_neighbor_hip(L.ptr(sampled), L.ptr(dst_ptr), L.ptr(ind_ptr), L.ptr(sel), n, int(neighbor_num),
+                                           seed, L.ptr(ws), wsn, st), "sg_sample_fix_neighbor_hip")
+    return sampled[:total], dst_ptr[:n + 1]
