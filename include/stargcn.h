@@ -371,8 +371,13 @@ int64_t sg_gather_profile_read2(float* ms, int64_t* nnz, int64_t* feat_dim, int6
  * SG_GATHER_SLICES_FORCE give the initial values and are read once, at the first launch.  Returns 0. */
 int sg_gather_tuning(int slices, int slices_force);
 /* tuning aid: GEMM backend of sg_gemm_f32_hip -- 0 exact-fp32 MFMA, 1 bf16x6, 2 x6v2 (wave-specialised bf16x6; both
- * bf16 backends are fp32-accurate: dropped terms <= 2^-24 |a b|); -1 = SG_GEMM_BACKEND / build default.  Returns 0. */
+ * bf16 backends are fp32-accurate: dropped terms <= 2^-24 |a b|), 3 f16x3 (block-scaled f16 planes, three MFMAs per
+ * product, per-term error <= 7e-7, used from K = 96 on; needs the workspace sg_gemm_f32_workspace_bytes reports);
+ * -1 = SG_GEMM_BACKEND / build default.  Returns 0. */
 int sg_gemm_backend(int backend);
+/* tuning aid for backend 3 (f16x3): 0 automatic; 1-3 force a plane-kernel geometry; 4 never use the in-kernel split of a
+ * huge fp32 operand ("hybrid"); 5 use it whenever the layout allows, whatever the size (tests).  -1 = SG_X3_VARIANT / 0. */
+int sg_gemm_x3_variant(int variant);
 /* measurement aid: best-case streaming read with the gather's launch geometry: `workgroups` single-wave workgroups each
  * read `bursts` consecutive 1 KiB bursts (4 in flight) of a `bytes`-long buffer, wrapping around; bench.py uses it to
  * measure, in the same run, the Infinity-Cache and L2 ceilings that price cache-resident shapes */

@@ -38,6 +38,9 @@
 // Epilogue / split-K contract identical to gemm_f32.hip (GemmArgs); selected by sg_gemm_f32_hip (backend 3).
 #include "common.hpp"
 
+#include <atomic>
+#include <cstdlib>
+
 namespace sg {
 
 struct GemmArgs {   // must match gemm_f32.hip
@@ -196,6 +199,77 @@ __device__ __forceinline__ void wait_vm() {      // counted wait on this wave's 
   else static_assert(N == 0, "add the immediate");
 }
 
+// ---- epilogue shared by the kernels: one 64 x 64 wave tile (2 x 2 MFMA tiles).  TRANSPOSED: the product was formed with
+// the operands swapped (rows of this tile are COLUMNS of C); it is written as C^T into `out` (leading dimension ldo) and a
+// small pass transposes it afterwards -- used for weight gradients, whose C is a few MB.
+__device__ __forceinline__ void store_tile(const GemmArgs& g, f32x16 (&acc)[2][2], char* smem, int wave, int lane, int m0,
+                                           int n0, int z) {
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  // ---- epilogue; MFMA layout (col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 kh) turned
+  // around in a private LDS block per wave so that every lane stores 16 bytes and a row segment is 256 contiguous bytes
+  const bool partial = (g.splits > 1);
+  float* out = partial ? g.ws + static_cast<long long>(z) * g.M * g.N : g.C;
+  const long long ldo = partial ? g.N : g.ldc;
+  const bool vec_c = ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((ldo & 3) == 0);
+  float* cst = reinterpret_cast<float*>(smem + wave * CSTAGE);
+  const int c4 = (lane & 15) * 4, r4 = lane >> 4;
+  const int col = n0 + wn * 64 + c4;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!partial && g.bias) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[q] = (col + q < g.N) ? g.bias[col + q] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        cst[((e & 3) + 8 * (e >> 2) + 4 * kh) * CPITCH + j * 32 + l31] = acc[i][j][e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = r4 + 4 * it;
+      const int row = m0 + wm * 64 + i * 32 + r;
+      const float4 t4 = *reinterpret_cast<const float4*>(cst + r * CPITCH + c4);
+      float v[4] = {t4.x, t4.y, t4.z, t4.w};
+      if (row < g.M && col < g.N) {
+        float* o = out + static_cast<long long>(row) * ldo + col;
+        const bool full = vec_c && (col + 3 < g.N);
+        if (!partial) {
+          if (g.accumulate) {
+            if (full) {
+              const float4 old = *reinterpret_cast<const float4*>(o);
+              v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) if (col + q < g.N) v[q] += o[q];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q] + bv[q], g.act, g.slope);
+        }
+        if (full) {
+          typedef float f4 __attribute__((ext_vector_type(4)));
+          const f4 tt = {v[0], v[1], v[2], v[3]};
+          // a finished C tile is not re-read by this kernel: streamed past the caches; split-K partials are re-read at
+          // once by the reduce kernel and stay cacheable
+          if (!partial) __builtin_nontemporal_store(tt, reinterpret_cast<f4*>(o));
+          else *reinterpret_cast<f4*>(o) = tt;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (col + q < g.N) o[q] = v[q];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 // WM: waves along M (tile = 64 WM x 128, 2 WM waves of 64 x 64); BKS: 16-k steps per K tile; NST: LDS stages.
 //   <2, 2, 2>  128 x 128 x 32, 64 KiB: two workgroups per CU, one K tile in flight each (short K: the other workgroup's
 //              matrix work covers this one's epilogue)
@@ -324,70 +398,217 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 2 : 2)) void gemm_f16x3_kernel
   }
   __syncthreads();       // every wave is done with the stages: they become the epilogue's staging blocks
 
-  // ---- epilogue; MFMA layout (col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 kh) turned
-  // around in a private LDS block per wave so that every lane stores 16 bytes and a row segment is 256 contiguous bytes
-  const bool partial = (g.splits > 1);
-  float* out = partial ? g.ws + static_cast<long long>(z) * g.M * g.N : g.C;
-  const long long ldo = partial ? g.N : g.ldc;
-  const bool vec_c = ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((ldo & 3) == 0);
-  float* cst = reinterpret_cast<float*>(smem + wave * CSTAGE);
-  const int m0 = tm * (64 * WM), n0 = tn * BN;
-  const int c4 = (lane & 15) * 4, r4 = lane >> 4;
-  const int col = n0 + wn * 64 + c4;
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (!partial && g.bias) {
+  store_tile(g, acc, smem, wave, lane, tm * (64 * WM), tn * BN, z);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Hybrid: op(A) stays fp32 in memory and is split INSIDE the kernel; op(B) comes as planes by LDS-DMA.  For the products
+// whose A operand is huge and is used by only one or two column tiles (N <= 256: the 16-21 GB R-expanded matrices of the
+// config-5 step against a 256-wide weight or feature matrix) the streaming split pass would cost as much as the product
+// (read 4 B + write 4 B per element, then the planes are read again); here A is read ONCE, as fp32.  Each of the four
+// waves converts one 32-row block of the next K tile (32 x 32 values, 16 per lane) while the matrix pipe works on the
+// current one: block maximum by a wave reduction -> exponent -> scale, two cvt_pk + one subtraction per pair of values,
+// eight (K-contiguous A) or four (row-contiguous A) LDS stores into the fragment-major image the consumers read.  The
+// scale block of A is 32 rows x 32 k here (one K tile), so the block-local products P are folded into the running result
+// after every K tile; B keeps its 64-k blocks.  128 x 128 x 32 tiles, two stages, two workgroups per CU.
+// ARC = false: A element (m, k) at A[m * lda + k] (K % 4 == 0, 16-byte aligned rows); true: at A[k * lda + m].
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool ARC>
+__global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, const PlaneArgs pl) {
+  constexpr int UPB = 4, RBA = 4, UNITS_B = 16, STAGE_B = 32 * UNIT;      // per stage: A units 0..15, B units 16..31
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B + 64];
+  int* exp_lds = reinterpret_cast<int*>(smem + 2 * STAGE_B);               // [stage][row block]
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = g.tiles_m * g.tiles_n;
+  const int item = blockIdx.x;
+  const int z = item / nt, lin = item - z * nt;
+  const int q8 = nt >> 3, r8 = nt & 7, x8 = lin & 7;
+  const int tile = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (lin >> 3);
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int ktiles = (g.K + 31) / 32;
+  const int kt0 = z * g.tiles_per_split, kt1 = min(ktiles, kt0 + g.tiles_per_split);
+  const int T = kt1 - kt0;
+
+  f32x16 acc[2][2], P[2][2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bv[q] = (col + q < g.N) ? g.bias[col + q] : 0.f;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        cst[((e & 3) + 8 * (e >> 2) + 4 * kh) * CPITCH + j * 32 + l31] = acc[i][j][e];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- B planes by DMA: 16 units per K tile, 4 per wave ----
+  const long long rb_stride = static_cast<long long>(pl.KS) * 2 * UNIT;
+  const char* b_base = pl.pb + static_cast<long long>(tn) * 4 * rb_stride + static_cast<long long>(kt0) * (UPB * UNIT) + lane * 16;
+  auto issue_b = [&](int kt) {
+    char* dst = smem + (kt & 1) * STAGE_B + 16 * UNIT;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int r = r4 + 4 * it;
-      const int row = m0 + wm * 64 + i * 32 + r;
-      const float4 t4 = *reinterpret_cast<const float4*>(cst + r * CPITCH + c4);
-      float v[4] = {t4.x, t4.y, t4.z, t4.w};
-      if (row < g.M && col < g.N) {
-        float* o = out + static_cast<long long>(row) * ldo + col;
-        const bool full = vec_c && (col + 3 < g.N);
-        if (!partial) {
-          if (g.accumulate) {
-            if (full) {
-              const float4 old = *reinterpret_cast<const float4*>(o);
-              v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
-            } else {
+    for (int i = 0; i < 4; ++i) {
+      const int u = wave * 4 + i;
+      const int q = u >> 2, part = u & 3;
+      const char* src = b_base + q * rb_stride + static_cast<long long>(kt) * (UPB * UNIT) + part * UNIT;
+      __builtin_amdgcn_global_load_lds((glb_void*)(src), (lds_void*)(dst + u * UNIT), 16, 0, 0);
+    }
+  };
+  const int kbs = pl.KS >> 2;
+  cst_int* eb_p = (cst_int*)(pl.exp_b + static_cast<long long>(tn * 4 + wn * 2) * kbs);
+
+  // ---- A: this wave's 32-row block of a K tile, 16 fp32 per lane, loaded unconditionally from clamped coordinates ----
+  const int m_blk = tm * BM + wave * 32;
+  float va[16];
+  auto load_a = [&](int kt) {
+    const int k0 = (kt0 + kt) * 32;
+    if (!ARC) {           // lane = (row lane / 8 + 8 i, k = 4 (lane % 8) .. + 3)
+      const int k = min(k0 + (lane & 7) * 4, g.K - 4);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) if (col + q < g.N) v[q] += o[q];
-            }
-          }
+      for (int i = 0; i < 4; ++i) {
+        const int row = min(m_blk + (lane >> 3) + 8 * i, g.M - 1);
+        const float4 x = *reinterpret_cast<const float4*>(g.A + static_cast<long long>(row) * g.lda + k);
+        va[4 * i] = x.x; va[4 * i + 1] = x.y; va[4 * i + 2] = x.z; va[4 * i + 3] = x.w;
+      }
+    } else {              // lane = (op row m = lane % 32, k = 16 (lane / 32) + i): coalesced dword loads along m
+      const int m = min(m_blk + (lane & 31), g.M - 1);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = act_fn(v[q] + bv[q], g.act, g.slope);
+      for (int i = 0; i < 16; ++i) {
+        const int k = min(k0 + (lane >> 5) * 16 + i, g.K - 1);
+        va[i] = g.A[static_cast<long long>(k) * g.lda + m];
+      }
+    }
+  };
+  auto store_a = [&](int kt) {      // convert va (tile kt) and write its planes + exponent into stage kt & 1
+    const int k0 = (kt0 + kt) * 32;
+    float x[16];
+    float mx = 0.f;
+    if (!ARC) {
+      const bool kdead = k0 + (lane & 7) * 4 >= g.K;       // K % 4 == 0: a float4 is in or out as a whole
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool dead = kdead || (m_blk + (lane >> 3) + 8 * i >= g.M);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[4 * i + j] = dead ? 0.f : va[4 * i + j]; mx = fmaxf(mx, fabsf(x[4 * i + j])); }
+      }
+    } else {
+      const bool mdead = m_blk + (lane & 31) >= g.M;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        x[i] = (mdead || k0 + (lane >> 5) * 16 + i >= g.K) ? 0.f : va[i];
+        mx = fmaxf(mx, fabsf(x[i]));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    int e = 0;
+    {
+      const unsigned bits = __float_as_uint(mx);
+      const int ex = static_cast<int>((bits >> 23) & 0xffu);
+      if (bits != 0u && ex != 0xff) e = 14 - (max(ex, 1) - 127);
+      e = min(max(e, -126), 126);
+    }
+    const float sc = __uint_as_float(static_cast<unsigned>(127 + e) << 23);
+    unsigned h1[8], h2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x2 v = {x[2 * j] * sc, x[2 * j + 1] * sc};
+      const f16x2 a = __builtin_convertvector(v, f16x2);
+      const f32x2 res = v - __builtin_convertvector(a, f32x2);
+      const f16x2 b = __builtin_convertvector(res, f16x2);
+      h1[j] = __builtin_bit_cast(unsigned, a);
+      h2[j] = __builtin_bit_cast(unsigned, b);
+    }
+    char* st = smem + (kt & 1) * STAGE_B + wave * (UPB * UNIT);
+    if (!ARC) {           // 4 consecutive k of row r: half a 16-byte slot of unit (ks, plane), lane slot kg * 32 + r
+      const int kq = lane & 7;
+      const int off = ((kq >> 2) * 2) * UNIT + (((kq >> 1) & 1) * 32) * 16 + (kq & 1) * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = (lane >> 3) + 8 * i;
+        *reinterpret_cast<uint2*>(st + off + r * 16) = make_uint2(h1[2 * i], h1[2 * i + 1]);
+        *reinterpret_cast<uint2*>(st + off + UNIT + r * 16) = make_uint2(h2[2 * i], h2[2 * i + 1]);
+      }
+    } else {              // 16 consecutive k of op row m: k step ks = lane / 32, both k groups
+      const int ks = lane >> 5, m = lane & 31;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        *reinterpret_cast<uint4*>(st + (ks * 2) * UNIT + (kg * 32 + m) * 16) = make_uint4(h1[4 * kg], h1[4 * kg + 1], h1[4 * kg + 2], h1[4 * kg + 3]);
+        *reinterpret_cast<uint4*>(st + (ks * 2 + 1) * UNIT + (kg * 32 + m) * 16) = make_uint4(h2[4 * kg], h2[4 * kg + 1], h2[4 * kg + 2], h2[4 * kg + 3]);
+      }
+    }
+    if (lane == 0) exp_lds[(kt & 1) * 4 + wave] = -e;
+  };
+
+  if (T > 0) {
+    issue_b(0);
+    load_a(0);
+    store_a(0);
+  }
+  __syncthreads();
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < T; ++kt) {
+    const bool more = kt + 1 < T;                          // wave-uniform
+    if (more) {
+      issue_b(kt + 1);                                     // the other stage was released by the barrier just passed
+      load_a(kt + 1);
+    }
+    const char* st = smem + (kt & 1) * STAGE_B;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 a[2][2], b[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          a[i][p] = *reinterpret_cast<const f16x8*>(st + ((wm * 2 + i) * UPB + ks * 2 + p) * UNIT + lane * 16);
+          b[i][p] = *reinterpret_cast<const f16x8*>(st + ((RBA + wn * 2 + i) * UPB + ks * 2 + p) * UNIT + lane * 16);
         }
-        if (full) {
-          typedef float f4 __attribute__((ext_vector_type(4)));
-          const f4 tt = {v[0], v[1], v[2], v[3]};
-          // a finished C tile is not re-read by this kernel: streamed past the caches; split-K partials are re-read at
-          // once by the reduce kernel and stay cacheable
-          if (!partial) __builtin_nontemporal_store(tt, reinterpret_cast<f4*>(o));
-          else *reinterpret_cast<f4*>(o) = tt;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], ks == 0 ? zero : P[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], P[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], P[i][j], 0, 0, 0);
+    }
+    // fold the K tile at its true scale: A block exponent from LDS (written before the last barrier), B from memory
+    const int kb = (kt0 + kt) >> 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ea = __builtin_amdgcn_readfirstlane(exp_lds[(kt & 1) * 4 + wm * 2 + i]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ex = ea + eb_p[j * kbs + kb];
+        if (ex >= -126 && ex <= 127) {
+          const float sc = __uint_as_float(static_cast<unsigned>(127 + ex) << 23);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(P[i][j][e], sc, acc[i][j][e]);
         } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) if (col + q < g.N) o[q] = v[q];
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += ldexpf(P[i][j][e], ex);
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (more) store_a(kt + 1);       // the loads had the whole multiplication to land
+    __syncthreads();                 // planes + exponent of tile kt+1 visible, B DMA landed (vmcnt(0) precedes the barrier)
   }
+  store_tile(g, acc, smem, wave, lane, tm * BM, tn * BN, z);
+}
+
+// C^T (N x M, leading dimension M) -> C (M x N): the swapped-operand products of weight gradients
+__global__ void transpose_out_kernel(float* __restrict__ C, long long ldc, const float* __restrict__ Ct, int M, int N) {
+  __shared__ float tile[32][33];
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 256 threads: 8 rows per pass
+  for (int r = ty; r < 32; r += 8)
+    tile[r][tx] = (n0 + r < N && m0 + tx < M) ? Ct[static_cast<long long>(n0 + r) * M + m0 + tx] : 0.f;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (m0 + r < M && n0 + tx < N) C[static_cast<long long>(m0 + r) * ldc + n0 + tx] = tile[tx][r];
 }
 
 static inline size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
@@ -397,23 +618,43 @@ static inline size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t
 // bytes of plane / exponent storage the backend needs for an M x N x K product (on top of the split-K partials)
 size_t f16x3_plane_bytes(long long M, long long N, long long K) {
   using namespace f16x3;
-  const long long Mp = (M + 255) / 256 * 256, Np = (N + BN - 1) / BN * BN, Kp = (K + 63) / 64 * 64;
+  const long long Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + 63) / 64 * 64;
   return align256(static_cast<size_t>(Mp) * Kp * 4) + align256(static_cast<size_t>(Np) * Kp * 4) +
-         align256(static_cast<size_t>(Mp / 32) * (Kp / 64) * 4) + align256(static_cast<size_t>(Np / 32) * (Kp / 64) * 4);
+         align256(static_cast<size_t>(Mp / 32) * (Kp / 64) * 4) + align256(static_cast<size_t>(Np / 32) * (Kp / 64) * 4) +
+         (M <= 256 ? align256(static_cast<size_t>(M) * N * 4) : 0);       // C^T of a swapped-operand product
 }
 
-static int x3_variant() {      // tuning aid: SG_X3_VARIANT = 0 auto, 1 <2,2,2>, 2 <2,1,5>, 3 <4,2,3>
+static std::atomic<int> g_x3_variant_override{-1};
+static int x3_variant() {      // tuning aid: SG_X3_VARIANT / sg_gemm_x3_variant = 0 auto, 1 <2,2,2>, 2 <2,1,5>, 3 <4,2,3>,
+                               // 4 never hybrid, 5 hybrid at any size
+  const int o = g_x3_variant_override.load(std::memory_order_relaxed);
+  if (o >= 0) return o;
   static const int v = [] { const char* e = getenv("SG_X3_VARIANT"); return e ? atoi(e) : 0; }();
   return v;
 }
 
+namespace f16x3 {
+// C[m][n] = sum_z ws[z][n][m]: split-K partials of a swapped-operand product, summed in slice order and transposed
+__global__ void reduce_t_kernel(float* __restrict__ C, long long ldc, const float* __restrict__ ws, int M, int N, int splits) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long total = static_cast<long long>(M) * N;
+  if (i >= total) return;
+  const int n = static_cast<int>(i / M), m = static_cast<int>(i - static_cast<long long>(n) * M);      // coalesced reads
+  float v = 0.f;
+  for (int z = 0; z < splits; ++z) v += ws[static_cast<long long>(z) * total + i];
+  C[static_cast<long long>(m) * ldc + n] = v;
+}
+}  // namespace f16x3
+
 // called by sg_gemm_f32_hip when backend 3 is selected; g.tiles_n is for 128-wide tiles (g.tiles_m is recomputed here for
 // the tile height chosen), g.tiles_per_split is EVEN when g.splits > 1 (a 64-k scale block = two K tiles must not straddle
-// two slices), g.ws holds the split-K partials, `scratch` the plane storage (f16x3_plane_bytes)
-int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scratch, hipStream_t st) {
+// two slices), g.ws holds the split-K partials, `scratch` the plane storage (f16x3_plane_bytes).  *reduced is set when
+// the split-K slices have already been combined here (swapped-operand products).
+int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scratch, hipStream_t st, bool* reduced) {
   using namespace f16x3;
   GemmArgs g = g_in;
-  const long long Mp = (static_cast<long long>(g.M) + 255) / 256 * 256, Np = static_cast<long long>(g.tiles_n) * BN;
+  *reduced = false;
+  const long long Mp = (static_cast<long long>(g.M) + 255) / 256 * 256, Np = (static_cast<long long>(g.N) + 255) / 256 * 256;
   const long long Kp = (static_cast<long long>(g.K) + 63) / 64 * 64;
   const int KS = static_cast<int>(Kp / 16);
   if (g.splits > 1 && (g.tiles_per_split & 1)) return fail(SG_ERR_INVALID, "f16x3: odd K-tile count per split-K slice");
@@ -421,30 +662,78 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
   char* pb = pa + align256(static_cast<size_t>(Mp) * Kp * 4);
   int* ea = reinterpret_cast<int*>(pb + align256(static_cast<size_t>(Np) * Kp * 4));
   int* eb = reinterpret_cast<int*>(reinterpret_cast<char*>(ea) + align256(static_cast<size_t>(Mp / 32) * (Kp / 64) * 4));
-  const dim3 ga(static_cast<unsigned>(Mp / 32), static_cast<unsigned>(Kp / 64)), gb(static_cast<unsigned>(Np / 32),
-                                                                                  static_cast<unsigned>(Kp / 64));
-  if (ga.y > 65535u) return fail(SG_ERR_INVALID, "f16x3: K too large for the split grid");
-  if (transA) hipLaunchKernelGGL((split_kernel<true>), ga, dim3(256), 0, st, pa, ea, g.A, g.lda, g.M, g.K, KS, g.vecA);
-  else hipLaunchKernelGGL((split_kernel<false>), ga, dim3(256), 0, st, pa, ea, g.A, g.lda, g.M, g.K, KS, g.vecA);
-  if (transB) hipLaunchKernelGGL((split_kernel<false>), gb, dim3(256), 0, st, pb, eb, g.B, g.ldb, g.N, g.K, KS, g.vecB);
-  else hipLaunchKernelGGL((split_kernel<true>), gb, dim3(256), 0, st, pb, eb, g.B, g.ldb, g.N, g.K, KS, g.vecB);
+  float* ct = reinterpret_cast<float*>(reinterpret_cast<char*>(eb) + align256(static_cast<size_t>(Np / 32) * (Kp / 64) * 4));
+  if (Kp / 64 > 65535) return fail(SG_ERR_INVALID, "f16x3: K too large for the split grid");
+  auto split = [&](char* planes, int* expo, const float* p, long long ld, bool rc, int R, long long Rp, int vec) {
+    const dim3 grid(static_cast<unsigned>(Rp / 32), static_cast<unsigned>(Kp / 64));
+    if (rc) hipLaunchKernelGGL((split_kernel<true>), grid, dim3(256), 0, st, planes, expo, p, ld, R, g.K, KS, vec);
+    else hipLaunchKernelGGL((split_kernel<false>), grid, dim3(256), 0, st, planes, expo, p, ld, R, g.K, KS, vec);
+  };
+  const int variant = x3_variant();
+  const int tm128 = (g.M + 127) / 128, tn128 = (g.N + 127) / 128;
+  const long long big = variant == 5 ? 0 : 16ll << 20;  // elements: a 64 MB operand is worth keeping out of a split pass
+  // A may stay fp32 when its layout allows the in-kernel loads (K-contiguous rows need 16-byte vectors)
+  const bool a_fly_ok = transA || (g.vecA && g.K % 4 == 0 && g.K >= 4);
+  const bool b_fly_ok = !transB || (g.vecB && g.K % 4 == 0 && g.K >= 4);
+  const bool plain_epi = !g.bias && g.act == SG_ACT_NONE && !g.accumulate;
+  if (variant != 4 && tn128 <= 2 && static_cast<long long>(g.M) * g.K >= big && a_fly_ok) {
+    // ---- hybrid: A fp32 in the kernel, B planes ----
+    split(pb, eb, g.B, g.ldb, !transB, g.N, Np, g.vecB);
+    PlaneArgs pl{nullptr, pb, nullptr, eb, KS};
+    g.tiles_m = tm128;
+    const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
+    if (transA) hipLaunchKernelGGL((gemm_f16x3h_kernel<true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
+    else hipLaunchKernelGGL((gemm_f16x3h_kernel<false>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
+    return SG_OK;
+  }
+  if (variant != 4 && tm128 <= 2 && g.M <= 256 && static_cast<long long>(g.N) * g.K >= big && b_fly_ok && plain_epi) {
+    // ---- swapped hybrid: C^T = op(B)^T op(A)^T with op(B)^T (the huge operand) fp32 in the kernel, op(A)^T as planes ----
+    split(pa, ea, g.A, g.lda, transA, g.M, Mp, g.vecA);              // planes of op(A): rows m, K-contiguous units
+    GemmArgs h = g;
+    h.M = g.N; h.N = g.M;
+    h.A = g.B; h.lda = g.ldb; h.vecA = g.vecB;
+    h.C = ct; h.ldc = g.M;
+    h.bias = nullptr;
+    h.tiles_m = tn128; h.tiles_n = tm128;
+    PlaneArgs pl{nullptr, pa, nullptr, ea, KS};
+    const long long items = static_cast<long long>(h.tiles_m) * h.tiles_n * h.splits;
+    // op(B)^T element (n, k): B stored (K x N) when !transB -> row-contiguous in n (ARC); (N x K) when transB -> K-contiguous
+    if (!transB) hipLaunchKernelGGL((gemm_f16x3h_kernel<true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, h, pl);
+    else hipLaunchKernelGGL((gemm_f16x3h_kernel<false>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, h, pl);
+    const long long total = static_cast<long long>(g.M) * g.N;
+    if (g.splits > 1) {
+      hipLaunchKernelGGL(reduce_t_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, g.C, g.ldc, g.ws,
+                         g.M, g.N, g.splits);
+    } else {
+      hipLaunchKernelGGL(transpose_out_kernel, dim3(static_cast<unsigned>((g.N + 31) / 32), static_cast<unsigned>((g.M + 31) / 32)),
+                         dim3(256), 0, st, g.C, g.ldc, ct, g.M, g.N);
+    }
+    *reduced = true;
+    return SG_OK;
+  }
+  split(pa, ea, g.A, g.lda, transA, g.M, Mp, g.vecA);
+  split(pb, eb, g.B, g.ldb, !transB, g.N, Np, g.vecB);
   PlaneArgs pl{pa, pb, ea, eb, KS};
   // variant: short K slices are dominated by the epilogue (two workgroups per CU overlap it); long ones by DMA latency
   const int ktiles32 = (g.K + 31) / 32;
   const int slice = g.splits > 1 ? g.tiles_per_split : ktiles32;
-  int variant = x3_variant();
-  if (variant == 0) variant = slice <= 16 ? 1 : 3;
-  if (variant == 3) {
+  int v = (variant >= 1 && variant <= 3) ? variant : (slice <= 16 ? 1 : 3);
+  if (v == 3) {
     g.tiles_m = static_cast<int>((g.M + 255) / 256);
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
     hipLaunchKernelGGL((gemm_f16x3_kernel<4, 2, 3>), dim3(static_cast<unsigned>(items)), dim3(512), 0, st, g, pl);
   } else {
-    g.tiles_m = static_cast<int>((g.M + 127) / 128);
+    g.tiles_m = tm128;
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
-    if (variant == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 5>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
+    if (v == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 5>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
   }
   return SG_OK;
 }
 
 }  // namespace sg
+
+SG_API int sg_gemm_x3_variant(int variant) {
+  sg::g_x3_variant_override.store(variant < 0 || variant > 5 ? -1 : variant, std::memory_order_relaxed);
+  return SG_OK;
+}

@@ -61,7 +61,7 @@ void launch_gemm_bf16x6(const GemmArgs& g, bool transA, bool transB, hipStream_t
 void launch_gemm_x6v2(const GemmArgs& g, bool transA, bool transB, int n_cus, hipStream_t st);   // gemm_x6v2.hip
 bool x6v2_supported(const GemmArgs& g, bool transA, bool transB);
 size_t f16x3_plane_bytes(long long M, long long N, long long K);                                  // gemm_f16x3.hip
-int launch_gemm_f16x3(const GemmArgs& g, bool transA, bool transB, char* scratch, hipStream_t st);
+int launch_gemm_f16x3(const GemmArgs& g, bool transA, bool transB, char* scratch, hipStream_t st, bool* reduced);
 
 #ifndef SG_GEMM_DEFAULT_BACKEND
 #define SG_GEMM_DEFAULT_BACKEND 3      // 0 exact-fp32 MFMA (this file), 1 bf16x6, 2 x6v2 (wave-specialised bf16x6),
@@ -570,8 +570,9 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
     if (tm == 128) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, 128>), grid, dim3(kThreads), 0, st, g); \
     else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, 64>), grid, dim3(kThreads), 0, st, g);            \
   } while (0)
+  bool reduced = false;
   if (use_x3) {
-    SG_TRY_RC(launch_gemm_f16x3(g, transA != 0, transB != 0, planes, st));
+    SG_TRY_RC(launch_gemm_f16x3(g, transA != 0, transB != 0, planes, st, &reduced));
   } else if (use_v2) {
     launch_gemm_x6v2(g, transA != 0, transB != 0, cu_count(), st);
   } else if (use_bx6) {
@@ -582,7 +583,7 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
     if (transB) SG_LAUNCH_GEMM(false, true); else SG_LAUNCH_GEMM(false, false);
   }
 #undef SG_LAUNCH_GEMM
-  if (g.splits > 1) {
+  if (g.splits > 1 && !reduced) {
     const long long total = static_cast<long long>(M) * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, g);
   }

@@ -63,7 +63,7 @@ def test_gemm_bf16x6_backend_is_fp32_accurate(M, N, K, ta, tb, backend):
         L.lib().sg_gemm_backend(-1)
 
 
-def _bf16_backend_case(M, N, K, ta, tb, ops, L):
+def _bf16_backend_case(M, N, K, ta, tb, ops, L, reset_backend=None):
     g = torch.Generator().manual_seed(M * 5 + N * 11 + K)
     scale_rows = torch.logspace(-3, 3, M)   # rows of op(A) span six decades
     A = torch.randn((K, M) if ta else (M, K), generator=g) * (scale_rows.view(1, -1) if ta else scale_rows.view(-1, 1))
@@ -84,6 +84,8 @@ def _bf16_backend_case(M, N, K, ta, tb, ops, L):
     out32 = ops.gemm(A.cuda(), B.cuda(), trans_a=ta, trans_b=tb, bias=bias.cuda(), act="leaky", slope=0.1)
     e32 = float(((out32.double().cpu() - want).abs() / (mag + 1e-30)).max())
     assert float((err / (mag + 1e-30)).max()) <= 4 * e32 + 2e-7     # same accuracy class as the exact-fp32 MFMA kernel
+    if reset_backend is not None:
+        L.lib().sg_gemm_backend(reset_backend)
 
 
 @pytest.mark.parametrize("backend", [0, 1, 2, 3])
@@ -117,6 +119,42 @@ def test_gemm_x6v2_persistent_multi_item_shapes():
             assert torch.equal(out, again)                      # deterministic
       finally:
         L.lib().sg_gemm_backend(-1)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 5])
+def test_gemm_f16x3_geometries_and_in_kernel_split(variant):
+    """Backend 3 has three plane-kernel geometries and the "hybrid" forms that split a huge fp32 operand inside the kernel
+    (variant 5 uses them at any size: A K-contiguous / row-contiguous, and the swapped-operand form of wide, short-M
+    products incl. its split-K transposing reduction).  Every form, ragged edges, all layouts, same fp64-referenced bound."""
+    from star_gcn_amd import _lib as L
+    from star_gcn_amd import ops
+    cases = [(130, 250, 96), (257, 64, 2570), (1000, 76, 252), (5, 300, 1028), (700, 2576, 256), (200, 130, 40000),
+             (96, 200, 40004), (3000, 256, 128)]
+    try:
+        L.lib().sg_gemm_backend(3)
+        L.lib().sg_gemm_x3_variant(variant)
+        for (M, N, K) in cases:
+            for ta in (False, True):
+                for tb in (False, True):
+                    _bf16_backend_case(M, N, K, ta, tb, ops, L, reset_backend=3)
+    finally:
+        L.lib().sg_gemm_backend(-1)
+        L.lib().sg_gemm_x3_variant(-1)
+
+
+def test_gemm_f16x3_in_kernel_split_at_step_shapes():
+    """The hybrid forms at the sizes that select them by themselves (>= 64 MB operand against a <= 256-wide one): the
+    ML-10M step's data- and weight-gradient shapes, default routing."""
+    from star_gcn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K, ta, tb) in [(69878, 256, 256, False, True), (10677, 256, 2560, False, False), (2560, 256, 10677, True, False),
+                              (256, 2624, 10677, True, False), (10677, 256, 2624, False, True)]:
+        A = torch.randn((K, M) if ta else (M, K), generator=g)
+        B = torch.randn((N, K) if tb else (K, N), generator=g)
+        ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+        out = ops.gemm(A.cuda(), B.cuda(), trans_a=ta, trans_b=tb)
+        rel_close(out, ref, 2e-6 * max(1, K ** 0.5), "f16x3 hybrid %s" % ((M, N, K, ta, tb),))
+        assert torch.equal(out, ops.gemm(A.cuda(), B.cuda(), trans_a=ta, trans_b=tb))      # deterministic
 
 
 def _split_k_case(ops):

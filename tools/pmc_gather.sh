@@ -9,9 +9,10 @@ for cfg in "1 4" "8 4" "8 1"; do
              "TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" \
              "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum" \
              "TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" \
-             "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+             "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+             "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
     i=$((i+1))
     timeout -s KILL 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/c${tag}_g$i -o run -- python tools/one_gather.py $cfg > $O/c${tag}_g$i.log 2>&1
   done
 done
-python tools/prof_summary.py $O 2>/dev/null | grep -E "^# .*counter|seg_gather_kernel" | grep -v fixup
+python tools/prof_summary.py $O 2>/dev/null | grep -E "^# |seg_gather_kernel" | grep -v fixup
