@@ -413,7 +413,9 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 ? 2 : 2)) void gemm_f16x3_kernel
 // after every K tile; B keeps its 64-k blocks.  128 x 128 x 32 tiles, two stages, two workgroups per CU.
 // ARC = false: A element (m, k) at A[m * lda + k] (K % 4 == 0, 16-byte aligned rows); true: at A[k * lda + m].
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool ARC>
+// AV4 (row-contiguous A only): M % 4 == 0 and 16-byte aligned k rows -> float4 loads along m (four per K tile and lane, like
+// the K-contiguous form) instead of sixteen dword loads.
+template <bool ARC, bool AV4 = false>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, const PlaneArgs pl) {
   constexpr int UPB = 4, RBA = 4, UNITS_B = 16, STAGE_B = 32 * UNIT;      // per stage: A units 0..15, B units 16..31
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B + 64];
@@ -467,6 +469,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
         const float4 x = *reinterpret_cast<const float4*>(g.A + static_cast<long long>(row) * g.lda + k);
         va[4 * i] = x.x; va[4 * i + 1] = x.y; va[4 * i + 2] = x.z; va[4 * i + 3] = x.w;
       }
+    } else if (AV4) {     // lane = (4 op rows m = 4 (lane % 8) .., k = 4 (lane / 8) + i): 128-byte k-row segments, va[4 i + j] = (k i, m j)
+      const int m = min(m_blk + (lane & 7) * 4, g.M - 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = min(k0 + (lane >> 3) * 4 + i, g.K - 1);
+        const float4 x = *reinterpret_cast<const float4*>(g.A + static_cast<long long>(k) * g.lda + m);
+        va[4 * i] = x.x; va[4 * i + 1] = x.y; va[4 * i + 2] = x.z; va[4 * i + 3] = x.w;
+      }
     } else {              // lane = (op row m = lane % 32, k = 16 (lane / 32) + i): coalesced dword loads along m
       const int m = min(m_blk + (lane & 31), g.M - 1);
 #pragma unroll
@@ -487,6 +497,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
         const bool dead = kdead || (m_blk + (lane >> 3) + 8 * i >= g.M);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { x[4 * i + j] = dead ? 0.f : va[4 * i + j]; mx = fmaxf(mx, fabsf(x[4 * i + j])); }
+      }
+    } else if (AV4) {     // transpose in registers: x[4 j + i] = (m j, k i) -> four consecutive k per op row, as in the K-contiguous form
+      const bool mdead = m_blk + (lane & 7) * 4 >= g.M;       // M % 4 == 0: four rows are in or out together
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool dead = mdead || (k0 + (lane >> 3) * 4 + i >= g.K);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[4 * j + i] = dead ? 0.f : va[4 * i + j]; mx = fmaxf(mx, fabsf(x[4 * j + i])); }
       }
     } else {
       const bool mdead = m_blk + (lane & 31) >= g.M;
@@ -517,12 +535,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
       h2[j] = __builtin_bit_cast(unsigned, b);
     }
     char* st = smem + (kt & 1) * STAGE_B + wave * (UPB * UNIT);
-    if (!ARC) {           // 4 consecutive k of row r: half a 16-byte slot of unit (ks, plane), lane slot kg * 32 + r
-      const int kq = lane & 7;
+    if (!ARC || AV4) {    // 4 consecutive k of row r: half a 16-byte slot of unit (ks, plane), lane slot kg * 32 + r
+      const int kq = AV4 ? (lane >> 3) : (lane & 7);
       const int off = ((kq >> 2) * 2) * UNIT + (((kq >> 1) & 1) * 32) * 16 + (kq & 1) * 8;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = (lane >> 3) + 8 * i;
+        const int r = AV4 ? (lane & 7) * 4 + i : (lane >> 3) + 8 * i;
         *reinterpret_cast<uint2*>(st + off + r * 16) = make_uint2(h1[2 * i], h1[2 * i + 1]);
         *reinterpret_cast<uint2*>(st + off + UNIT + r * 16) = make_uint2(h2[2 * i], h2[2 * i + 1]);
       }
@@ -682,7 +700,9 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     PlaneArgs pl{nullptr, pb, nullptr, eb, KS};
     g.tiles_m = tm128;
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
-    if (transA) hipLaunchKernelGGL((gemm_f16x3h_kernel<true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
+    if (transA && g.vecA && g.M % 4 == 0)
+      hipLaunchKernelGGL((gemm_f16x3h_kernel<true, true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
+    else if (transA) hipLaunchKernelGGL((gemm_f16x3h_kernel<true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
     else hipLaunchKernelGGL((gemm_f16x3h_kernel<false>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
     return SG_OK;
   }
@@ -698,7 +718,9 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     PlaneArgs pl{nullptr, pa, nullptr, ea, KS};
     const long long items = static_cast<long long>(h.tiles_m) * h.tiles_n * h.splits;
     // op(B)^T element (n, k): B stored (K x N) when !transB -> row-contiguous in n (ARC); (N x K) when transB -> K-contiguous
-    if (!transB) hipLaunchKernelGGL((gemm_f16x3h_kernel<true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, h, pl);
+    if (!transB && h.vecA && h.M % 4 == 0)
+      hipLaunchKernelGGL((gemm_f16x3h_kernel<true, true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, h, pl);
+    else if (!transB) hipLaunchKernelGGL((gemm_f16x3h_kernel<true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, h, pl);
     else hipLaunchKernelGGL((gemm_f16x3h_kernel<false>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, h, pl);
     const long long total = static_cast<long long>(g.M) * g.N;
     if (g.splits > 1) {
