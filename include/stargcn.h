@@ -195,6 +195,9 @@ int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, int tran
                     int64_t ldb, int transB, int64_t M, int64_t N, int64_t K, const float* bias, int act,
                     float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* dpre = dout * act'(.) evaluated from the activation OUTPUT `out` (all supported activations allow it) */
+/* out = act(in) elementwise (reference common.py:32-57: leaky / relu / sigmoid / tanh), for the places where the
+ * activation cannot ride on a GEMM / gather epilogue (after the all-reduce of a partitioned aggregate); out may alias in */
+int sg_act_hip(float* out, const float* in, int64_t n, int act, float slope, void* stream);
 int sg_act_bwd_hip(float* dpre, const float* dout, const float* out, int64_t n, int act, float slope,
                    void* stream);
 /* dst[N] (+)= column sums of X (M,N) with leading dim ldx (bias gradient) */

@@ -60,6 +60,7 @@ _SIGS = {
     "sg_gemm_f32_workspace_bytes": (_SZ, [_I64, _I64, _I64, _INT]),
     "sg_gemm_f32_hip": (_INT, [_P, _I64, _P, _I64, _INT, _P, _I64, _INT, _I64, _I64, _I64, _P, _INT, _F32, _INT,
                                _P, _SZ, _P]),
+    "sg_act_hip": (_INT, [_P, _P, _I64, _INT, _F32, _P]),
     "sg_act_bwd_hip": (_INT, [_P, _P, _P, _I64, _INT, _F32, _P]),
     "sg_colsum_workspace_bytes": (_SZ, [_I64, _I64]),
     "sg_colsum_hip": (_INT, [_P, _P, _I64, _I64, _I64, _INT, _P, _SZ, _P]),

@@ -596,6 +596,41 @@ SG_API int sg_gemm_backend(int backend) {
   return SG_OK;
 }
 
+namespace sg {
+// out[i] = act(in[i]); 16 bytes per lane when both pointers allow it.  `out` may alias `in`.
+__global__ void act_fwd_kernel(float* __restrict__ out, const float* __restrict__ in, long long n, int act, float slope, int vec) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
+  if (vec) {
+    const long long n4 = n >> 2;
+    for (long long p = i; p < n4; p += stride) {
+      float4 v = reinterpret_cast<const float4*>(in)[p];
+      v.x = apply_act(v.x, act, slope); v.y = apply_act(v.y, act, slope);
+      v.z = apply_act(v.z, act, slope); v.w = apply_act(v.w, act, slope);
+      reinterpret_cast<float4*>(out)[p] = v;
+    }
+    for (long long p = (n4 << 2) + i; p < n; p += stride) out[p] = apply_act(in[p], act, slope);
+  } else {
+    for (long long p = i; p < n; p += stride) out[p] = apply_act(in[p], act, slope);
+  }
+}
+}  // namespace sg
+
+// Elementwise activation (reference common.py:32-57) for the places where it cannot ride on a GEMM / gather epilogue: after
+// the all-reduce of a node-partitioned aggregate (the activation follows the SUM over ranks).  out may alias in.
+SG_API int sg_act_hip(float* out, const float* in, int64_t n, int act, float slope, void* stream) {
+  if (n < 0) return fail(SG_ERR_INVALID, "negative size");
+  if (act < SG_ACT_NONE || act > SG_ACT_TANH) return fail(SG_ERR_INVALID, "bad activation %d", act);
+  if (n == 0) return SG_OK;
+  if (!out || !in) return fail(SG_ERR_INVALID, "null pointer argument");
+  const int vec = aligned(out, 16) && aligned(in, 16);
+  int64_t blocks = ((vec ? (n + 3) / 4 : n) + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(sg::act_fwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), out,
+                     in, static_cast<long long>(n), act, slope, vec);
+  return check_launch("act_fwd");
+}
+
 SG_API int sg_act_bwd_hip(float* dpre, const float* dout, const float* out, int64_t n, int act, float slope,
                           void* stream) {
   if (n < 0) return fail(SG_ERR_INVALID, "negative size");

@@ -100,6 +100,30 @@ def multilink_aggregate(x, weights, biases, plan, accum="stack", act=None, slope
     return _MultiLinkAgg.apply(x, plan, accum, act, slope, order, *weights, *biases)
 
 
+class _Activation(torch.autograd.Function):
+    """y = act(x) on the native elementwise kernel; the derivative is evaluated from the OUTPUT, as the fused epilogues do."""
+
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        y = ops.act_fwd(x, act, slope)
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.act_bwd(L.f32c(dy), y, ctx.act, ctx.slope), None, None
+
+
+def activation(x, act, slope=0.1):
+    """leaky / relu / sigmoid / tanh as ONE native pass each way (used where the activation cannot be fused into the
+    producing kernel: after the all-reduce of a node-partitioned aggregate)."""
+    if act is None or ops._act_id(act) == 0:
+        return x
+    return _Activation.apply(x, act, slope)
+
+
 class _TakeRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, tplan):

@@ -26,6 +26,8 @@ class Activation(nn.Module):
         n = self.name
         if n == "identity":
             return x
+        if self.fused is not None and x.is_cuda and x.dtype == torch.float32:
+            return SF.activation(x, self.fused, self.slope)       # one native pass (sg_act_hip), output-based derivative
         if n == "leaky":
             return torch.where(x > 0, x, self.slope * x)
         if n == "relu":

@@ -225,6 +225,17 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, act=None, slope=0.1, out
     return out
 
 
+def act_fwd(x, act, slope=0.1):
+    """act(x) elementwise on the native kernel (sg_act_hip); identity returns x itself."""
+    if _act_id(act) == 0:
+        return x
+    L.require_gpu(x)
+    x = L.f32c(x)
+    out = torch.empty_like(x)
+    L.check(L.lib().sg_act_hip(L.ptr(out), L.ptr(x), x.numel(), _act_id(act), float(slope), L.stream_ptr()), "sg_act_hip")
+    return out
+
+
 def act_bwd(dout, out_act, act, slope=0.1):
     """dpre = dout * act'(.) computed from the activation output."""
     if _act_id(act) == 0:

@@ -467,3 +467,24 @@ def test_fused_aggregator_at_config5_scale():
         del out, xg, const
     a, b = outs["transform_first"], outs["aggregate_first"]
     assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("act", ["leaky", "relu", "sigmoid", "tanh"])
+@pytest.mark.parametrize("n", [1, 1027, 300000])
+def test_native_elementwise_activation(act, n):
+    """sg_act_hip / functional.activation (the activation that follows the all-reduce of a partitioned aggregate, where it
+    cannot ride on an epilogue): value and output-based derivative against the float64 definition (common.py:32-57)."""
+    from star_gcn_amd import functional as F
+    from star_gcn_amd.mxgraph.layers import get_activation
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g) * 2
+    gy = torch.randn(n, generator=g)
+    xd = x.cuda().requires_grad_(True)
+    y = F.activation(xd, act, 0.1)
+    y.backward(gy.cuda())
+    xr = x.double().requires_grad_(True)
+    yr = OM.ACTS[act](xr)
+    yr.backward(gy.double())
+    rel_close(y, yr, 1e-6, "act")
+    rel_close(xd.grad, xr.grad, 1e-6, "dact")
+    assert torch.equal(get_activation(act)(x.cuda()), y.detach())        # the layer API routes CUDA tensors to the same kernel
