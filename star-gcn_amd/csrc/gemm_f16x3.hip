@@ -271,14 +271,15 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, f32x16 (&acc)[2][2
 }
 
 // WM: waves along M (tile = 64 WM x 128, 2 WM waves of 64 x 64); BKS: 16-k steps per K tile; NST: LDS stages.
-//   <2, 2, 2>  128 x 128 x 32, 64 KiB: two workgroups per CU, one K tile in flight each (short K: the other workgroup's
-//              matrix work covers this one's epilogue)
+//   <2, 1, 3, 3>  128 x 128 x 16, 48 KiB, <= 168 VGPRs: THREE workgroups per CU, one K tile in flight each -- the default: the
+//              third workgroup's matrix work fills the barrier / DMA-wait gaps of the other two (4-14 % over the rest)
+//   <2, 2, 2>  128 x 128 x 32, 64 KiB: two workgroups per CU, one K tile in flight each
 //   <2, 1, 5>  128 x 128 x 16, 80 KiB: two workgroups per CU, three K tiles in flight each
 //   <4, 2, 3>  256 x 128 x 32, 144 KiB: one workgroup per CU, 25 % fewer operand bytes per flop, one to two K tiles in flight
 // What bounds these kernels is bytes in flight: at the matrix-core rate a CU consumes 31-43 B / clk of planes, the loaded
 // L2 / Infinity-Cache latency is ~2 us, and LDS (160 KiB) is the only place in-flight DMA data can land.
-template <int WM, int BKS, int NST>
-__global__ __launch_bounds__(128 * WM, (WM == 2 ? 2 : 2)) void gemm_f16x3_kernel(const GemmArgs g, const PlaneArgs pl) {
+template <int WM, int BKS, int NST, int MINW = 2>
+__global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmArgs g, const PlaneArgs pl) {
   constexpr int RBA = 2 * WM, RBB = 4;                 // 32-row blocks of A / B per tile
   constexpr int UPB = 2 * BKS;                         // units per row block and K tile (k step x plane)
   constexpr int UNITS = (RBA + RBB) * UPB, NW = 2 * WM, UPW = UNITS / NW;
@@ -739,7 +740,11 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
   // variant: short K slices are dominated by the epilogue (two workgroups per CU overlap it); long ones by DMA latency
   const int ktiles32 = (g.K + 31) / 32;
   const int slice = g.splits > 1 ? g.tiles_per_split : ktiles32;
-  int v = (variant >= 1 && variant <= 3) ? variant : (slice <= 16 ? 1 : 3);
+  // measured (tools/exp_x3_variants.py): three workgroups per CU (128 x 128 x 16, three stages, <= 168 VGPRs) beat the two-
+  // workgroup and the 256-row geometries on every plane-path shape by 4-14 %: the third workgroup's matrix work fills the
+  // barrier / DMA-wait gaps of the other two
+  (void)slice;
+  int v = ((variant >= 1 && variant <= 3) || variant == 6) ? variant : 6;
   if (v == 3) {
     g.tiles_m = static_cast<int>((g.M + 255) / 256);
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
@@ -748,6 +753,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     g.tiles_m = tm128;
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
     if (v == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 5>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
+    else if (v == 6) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 3, 3>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
   }
   return SG_OK;
@@ -756,6 +762,6 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
 }  // namespace sg
 
 SG_API int sg_gemm_x3_variant(int variant) {
-  sg::g_x3_variant_override.store(variant < 0 || variant > 5 ? -1 : variant, std::memory_order_relaxed);
+  sg::g_x3_variant_override.store(variant < 0 || variant > 6 ? -1 : variant, std::memory_order_relaxed);
   return SG_OK;
 }
