@@ -668,11 +668,14 @@ __global__ void reduce_t_kernel(float* __restrict__ C, long long ldc, const floa
 // called by sg_gemm_f32_hip when backend 3 is selected; g.tiles_n is for 128-wide tiles (g.tiles_m is recomputed here for
 // the tile height chosen), g.tiles_per_split is EVEN when g.splits > 1 (a 64-k scale block = two K tiles must not straddle
 // two slices), g.ws holds the split-K partials, `scratch` the plane storage (f16x3_plane_bytes).  *reduced is set when
-// the split-K slices have already been combined here (swapped-operand products).
-int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scratch, hipStream_t st, bool* reduced) {
+// the split-K slices have already been combined here (swapped-operand products); *splits_used is the slice count written
+// to g.ws (never more than the caller planned).
+int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scratch, hipStream_t st, bool* reduced,
+                      int* splits_used) {
   using namespace f16x3;
   GemmArgs g = g_in;
   *reduced = false;
+  *splits_used = g.splits;
   const long long Mp = (static_cast<long long>(g.M) + 255) / 256 * 256, Np = (static_cast<long long>(g.N) + 255) / 256 * 256;
   const long long Kp = (static_cast<long long>(g.K) + 63) / 64 * 64;
   const int KS = static_cast<int>(Kp / 16);
@@ -690,6 +693,28 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
   };
   const int variant = x3_variant();
   const int tm128 = (g.M + 127) / 128, tn128 = (g.N + 127) / 128;
+  // Split-K slice count against the number of workgroups the chip holds at once (`slots`): the caller's plan aims at ~3 per
+  // CU for the 256-thread fp32 kernel; here 64 tiles x 12 slices = 768 workgroups on 512 slots run as 1.5 rounds (75 %
+  // efficient).  Fewer slices are always allowed (the workspace was sized for the plan's count): take the count in
+  // [splits / 2, splits] with the fullest rounds.
+  auto fit_splits = [&](long long tiles, int slots) {
+    if (g.splits <= 1) return;
+    const int ktiles = (g.K + 31) / 32;
+    int best = g.splits;
+    double best_eff = 0.0;
+    for (int sp = g.splits; sp >= (g.splits + 1) / 2; --sp) {
+      int per = (ktiles + sp - 1) / sp;
+      per += per & 1;
+      const int real = (ktiles + per - 1) / per;
+      const long long items = tiles * real;
+      const double eff = static_cast<double>(items) / (static_cast<double>((items + slots - 1) / slots) * slots);
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = real; }
+    }
+    int per = (ktiles + best - 1) / best;
+    per += per & 1;
+    g.tiles_per_split = per;
+    g.splits = (ktiles + per - 1) / per;
+  };
   const long long big = variant == 5 ? 0 : 16ll << 20;  // elements: a 64 MB operand is worth keeping out of a split pass
   // A may stay fp32 when its layout allows the in-kernel loads (K-contiguous rows need 16-byte vectors)
   const bool a_fly_ok = transA || (g.vecA && g.K % 4 == 0 && g.K >= 4);
@@ -700,6 +725,8 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     split(pb, eb, g.B, g.ldb, !transB, g.N, Np, g.vecB);
     PlaneArgs pl{nullptr, pb, nullptr, eb, KS};
     g.tiles_m = tm128;
+    fit_splits(static_cast<long long>(g.tiles_m) * g.tiles_n, 512);
+    *splits_used = g.splits;
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
     if (transA && g.vecA && g.M % 4 == 0)
       hipLaunchKernelGGL((gemm_f16x3h_kernel<true, true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
@@ -710,6 +737,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
   if (variant != 4 && tm128 <= 2 && g.M <= 256 && static_cast<long long>(g.N) * g.K >= big && b_fly_ok && plain_epi) {
     // ---- swapped hybrid: C^T = op(B)^T op(A)^T with op(B)^T (the huge operand) fp32 in the kernel, op(A)^T as planes ----
     split(pa, ea, g.A, g.lda, transA, g.M, Mp, g.vecA);              // planes of op(A): rows m, K-contiguous units
+    fit_splits(static_cast<long long>(tn128) * tm128, 512);
     GemmArgs h = g;
     h.M = g.N; h.N = g.M;
     h.A = g.B; h.lda = g.ldb; h.vecA = g.vecB;

@@ -61,7 +61,8 @@ void launch_gemm_bf16x6(const GemmArgs& g, bool transA, bool transB, hipStream_t
 void launch_gemm_x6v2(const GemmArgs& g, bool transA, bool transB, int n_cus, hipStream_t st);   // gemm_x6v2.hip
 bool x6v2_supported(const GemmArgs& g, bool transA, bool transB);
 size_t f16x3_plane_bytes(long long M, long long N, long long K);                                  // gemm_f16x3.hip
-int launch_gemm_f16x3(const GemmArgs& g, bool transA, bool transB, char* scratch, hipStream_t st, bool* reduced);
+int launch_gemm_f16x3(const GemmArgs& g, bool transA, bool transB, char* scratch, hipStream_t st, bool* reduced,
+                      int* splits_used);
 
 #ifndef SG_GEMM_DEFAULT_BACKEND
 #define SG_GEMM_DEFAULT_BACKEND 3      // 0 exact-fp32 MFMA (this file), 1 bf16x6, 2 x6v2 (wave-specialised bf16x6),
@@ -86,8 +87,11 @@ static int backend_for(int64_t M, int64_t N, int64_t K, int transA) {
   if (!forced) backend = gemm_backend();
   if (K < 1) return 0;
   // ... and needs enough output tiles to fill the chip with its non-persistent workgroups: a 256 x 256 weight gradient over
-  // 70 k rows (4 tiles, everything in split-K slices) stays on the persistent x6v2 kernel (85 vs 71 TFLOP/s)
-  if (backend == 3 && !forced && (K < 96 || (transA && M <= 64) || ((M + 127) / 128) * ((N + 127) / 128) < 16)) backend = 2;
+  // a few thousand rows (4 tiles, everything in split-K slices) stays on the persistent x6v2 kernel
+  // (a 64 MB operand against a <= 256-wide one is taken by the in-kernel-split form whatever the tile count: 95 vs 89)
+  if (backend == 3 && !forced && (K < 96 || (transA && M <= 64) ||
+                                  (((M + 127) / 128) * ((N + 127) / 128) < 16 && (M > N ? M : N) * K < (16ll << 20))))
+    backend = 2;
   if (backend == 2 && !forced && (K <= 64 || (transA && M <= 64))) backend = 0;
   return backend;
 }
@@ -572,7 +576,9 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
   } while (0)
   bool reduced = false;
   if (use_x3) {
-    SG_TRY_RC(launch_gemm_f16x3(g, transA != 0, transB != 0, planes, st, &reduced));
+    int used = g.splits;
+    SG_TRY_RC(launch_gemm_f16x3(g, transA != 0, transB != 0, planes, st, &reduced, &used));
+    g.splits = used;              // the launcher may have taken fewer, fuller slices
   } else if (use_v2) {
     launch_gemm_x6v2(g, transA != 0, transB != 0, cu_count(), st);
   } else if (use_bx6) {
