@@ -274,6 +274,44 @@ def graph_replay(step, dev, steps):
             "note": "same step, one hipGraphLaunch per step; no HIP events inside, so not the headline"}
 
 
+MFMA_F16_PEAK = 2.5e15      # dense f16 / bf16 MFMA peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def dense_roofline(step, steps=3):
+    """Secondary roofline of the dense mix (per-rating-level contraction + Dense layers), measured in `steps` EXTRA steps
+    outside the timed region (one HIP-event pair per GEMM call would cost the headline 0.3 ms per step): every
+    sg_gemm_f32_hip call bracketed on its stream inside the library, conversion passes and split-K reduce included.
+    peak = the f16 MFMA peak / 3: the default backend forms an fp32-accurate product from three f16 matrix instructions."""
+    import star_gcn_amd.ops as ops
+    step()
+    torch.cuda.synchronize()
+    ops.gemm_profile(True)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ops.gemm_profile(False)
+    recs = [r for r in ops.gemm_profile_read() if r[0] > 0]
+    if not recs:
+        return None
+    t = sum(r[0] for r in recs)
+    flops = sum(2.0 * r[1] * r[2] * r[3] for r in recs)
+    big = sorted(recs, key=lambda r: -r[0])[:len(recs) // steps or 1]
+    by_backend = dict()
+    for r in recs:
+        b = by_backend.setdefault({0: "fp32", 1: "bf16x6", 2: "x6v2", 3: "f16x3"}.get(r[4], str(r[4])), [0.0, 0.0])
+        b[0] += r[0]
+        b[1] += 2.0 * r[1] * r[2] * r[3]
+    return {"kernel": "sg_gemm_f32_hip (default backend f16x3: three f16 MFMAs per fp32-accurate product)", "bound": "mfma",
+            "achieved": flops / t / 1e12, "peak": MFMA_F16_PEAK / 3 / 1e12, "unit": "TFLOP/s", "frac": flops / t / (MFMA_F16_PEAK / 3),
+            "gemm_ms_per_step": t / steps * 1e3, "gemm_calls_per_step": len(recs) / steps, "gflop_per_step": flops / steps / 1e9,
+            "by_backend": {k: {"ms_per_step": v[0] / steps * 1e3, "tflops": (v[1] / v[0] / 1e12) if v[0] else None}
+                           for k, v in by_backend.items()},
+            "slowest_calls": [{"M": r[1], "N": r[2], "K": r[3], "ms": r[0] * 1e3,
+                               "tflops": 2.0 * r[1] * r[2] * r[3] / r[0] / 1e12} for r in big[:6]],
+            "note": "extra steps after the timed region; flops = 2 M N K of every GEMM call, time incl. operand conversion "
+                    "and split-K reduction"}
+
+
 def gather_roofline(timeline, E_local, D, steps):
     """average HIP-event time of the aggregation launches (width D over all local edges) -> algorithmic rate"""
     agg = [(t, sb) for t, nnz, C, sb in timeline if C == D and nnz == max(E_local, 1) and t > 0]
@@ -402,8 +440,9 @@ def hbm_leg(args, dev):
         roof.pop("_classes", None)
         out["roofline"] = roof
         out["step_roofline_frac"] = out["edges_per_s"] * 8 * (8 + 4 * D) / HBM_PEAK
+    loss = None
+    out["dense_roofline"] = dense_roofline(step, 2)
     if not args.no_verify:
-        del loss
         out["verify"] = verify_leg(net, step, (dg.ind_ptr, dg.end_points, dg.level, ni, R, None), y, 1.0 / E)
     out["init"] = "embeddings U(-0.1, 0.1), Xavier-in weights, zero biases, then layer-sequential scale calibration " \
                   "(model.calibrate_output_scale); pre-calibration rms per stage: %s" % json.dumps(
@@ -764,6 +803,9 @@ def run_rank(args):
         except Exception as e:      # capture support is a property of the torch build, not of the path
             out["graph_replay"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         loss = None
+    if world == 1 and not dist_on:
+        loss = None
+        out["dense_roofline"] = dense_roofline(step, 3)
     if world == 1 and not dist_on and not args.no_verify:
         loss = None
         out["verify"] = verify_leg(net, step, (dgraph.ind_ptr, dgraph.end_points, dgraph.level, n_item, R, None), y,

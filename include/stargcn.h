@@ -378,6 +378,10 @@ int sg_gather_tuning(int slices, int slices_force);
  * product, per-term error <= 7e-7, used from K = 96 on; needs the workspace sg_gemm_f32_workspace_bytes reports);
  * -1 = SG_GEMM_BACKEND / build default.  Returns 0. */
 int sg_gemm_backend(int backend);
+/* measurement aid (bench.py `dense_roofline`): HIP events around every sg_gemm_f32_hip call (conversion passes and split-K
+ * reduce included) on its own stream; read returns one record per call: ms, (M, N, K) at mnk[3 i ..], backend used */
+int sg_gemm_profile_enable(int on);
+int64_t sg_gemm_profile_read(float* ms, int64_t* mnk, int* backend, int64_t capacity);
 /* tuning aid for backend 3 (f16x3): 0 automatic; 1-3 and 6 force a plane-kernel geometry (6 = the default one); 4 never use the in-kernel split of a
  * huge fp32 operand ("hybrid"); 5 use it whenever the layout allows, whatever the size (tests).  -1 = SG_X3_VARIANT / 0. */
 int sg_gemm_x3_variant(int variant);

@@ -88,6 +88,8 @@ _SIGS = {
     "sg_gather_tuning": (_INT, [_INT, _INT]),
     "sg_gemm_backend": (_INT, [_INT]),
     "sg_gemm_x3_variant": (_INT, [_INT]),
+    "sg_gemm_profile_enable": (_INT, [_INT]),
+    "sg_gemm_profile_read": (_I64, [_P, _P, _P, _I64]),
     "sg_stream_read_hip": (_INT, [_P, _I64, _INT, _I64, _P, _P]),
     "sg_build_transpose_workspace_bytes": (_SZ, [_I64] * 3),
     "sg_build_transpose_hip": (_INT, [_P] * 5 + [_I64] * 3 + [_P, _SZ, _P]),

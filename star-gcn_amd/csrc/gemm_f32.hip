@@ -25,6 +25,9 @@
 
 #include "common.hpp"
 
+#include <mutex>
+#include <vector>
+
 namespace sg {
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -103,6 +106,33 @@ static int cu_count() {
     return c;
   }();
   return n;
+}
+
+// ---- measurement aid (bench.py `dense_roofline`): when enabled, every sg_gemm_f32_hip call -- direct or from inside the
+// fused aggregator entries -- is bracketed with HIP events on its own stream (conversion passes and split-K reduce
+// included).  Off by default.
+struct GemmProfRecord {
+  hipEvent_t a, b;
+  int64_t M, N, K;
+  int backend;
+};
+static std::mutex g_gprof_mu;
+static bool g_gprof_on = false;
+static std::vector<GemmProfRecord> g_gprof;
+static long gprof_begin(hipStream_t st, int64_t M, int64_t N, int64_t K, int backend) {
+  std::lock_guard<std::mutex> lk(g_gprof_mu);
+  if (!g_gprof_on) return -1;
+  GemmProfRecord r{};
+  r.M = M; r.N = N; r.K = K; r.backend = backend;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+  (void)hipEventRecord(r.a, st);
+  g_gprof.push_back(r);
+  return static_cast<long>(g_gprof.size()) - 1;
+}
+static void gprof_end(long rec, hipStream_t st) {
+  if (rec < 0) return;
+  std::lock_guard<std::mutex> lk(g_gprof_mu);
+  if (rec < static_cast<long>(g_gprof.size())) (void)hipEventRecord(g_gprof[rec].b, st);
 }
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -574,6 +604,7 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
     if (tm == 128) hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, 128>), grid, dim3(kThreads), 0, st, g); \
     else hipLaunchKernelGGL((gemm_f32_kernel<TA_, TB_, 64>), grid, dim3(kThreads), 0, st, g);            \
   } while (0)
+  const long prof = gprof_begin(st, M, N, K, backend);
   bool reduced = false;
   if (use_x3) {
     int used = g.splits;
@@ -593,7 +624,39 @@ SG_API int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, i
     const long long total = static_cast<long long>(M) * N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, g);
   }
+  gprof_end(prof, st);
   return check_launch("gemm_f32");
+}
+
+SG_API int sg_gemm_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(sg::g_gprof_mu);
+  const int was = sg::g_gprof_on ? 1 : 0;
+  if (on && !was) {
+    for (auto& r : sg::g_gprof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    sg::g_gprof.clear();
+  }
+  sg::g_gprof_on = on != 0;
+  return was;
+}
+// one record per sg_gemm_f32_hip call since the profile was enabled: milliseconds, (M, N, K) as mnk[3 i .. 3 i + 2], backend
+SG_API int64_t sg_gemm_profile_read(float* ms, int64_t* mnk, int* backend, int64_t capacity) {
+  std::lock_guard<std::mutex> lk(sg::g_gprof_mu);
+  int64_t n = 0;
+  for (auto& r : sg::g_gprof) {
+    if (n < capacity) {
+      float t = 0.f;
+      (void)hipEventSynchronize(r.b);
+      if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) t = -1.f;
+      if (ms) ms[n] = t;
+      if (mnk) { mnk[3 * n] = r.M; mnk[3 * n + 1] = r.N; mnk[3 * n + 2] = r.K; }
+      if (backend) backend[n] = r.backend;
+      ++n;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  sg::g_gprof.clear();
+  return n;
 }
 
 // tuning aid (tests, benchmarks): GEMM backend 0 exact-fp32 MFMA, 1 bf16x6, 2 x6v2, 3 f16x3; -1 = environment / build default

@@ -28,6 +28,21 @@ def gather_profile_read(capacity=1 << 16, with_src_bytes=False):
     return [(ms[i] * 1e-3, int(nnz[i]), int(fd[i])) for i in range(n)]
 
 
+def gemm_profile(enable):
+    """bench.py: HIP-event bracketing of every GEMM call on/off (sg_gemm_profile_enable)."""
+    return L.lib().sg_gemm_profile_enable(int(bool(enable)))
+
+
+def gemm_profile_read(capacity=1 << 16):
+    """-> list of (seconds, M, N, K, backend) per sg_gemm_f32_hip call since the profile was enabled."""
+    import ctypes
+    ms = (ctypes.c_float * capacity)()
+    mnk = (ctypes.c_int64 * (3 * capacity))()
+    be = (ctypes.c_int * capacity)()
+    n = L.lib().sg_gemm_profile_read(ms, mnk, be, capacity)
+    return [(ms[i] * 1e-3, int(mnk[3 * i]), int(mnk[3 * i + 1]), int(mnk[3 * i + 2]), int(be[i])) for i in range(n)]
+
+
 def _act_id(act):
     if isinstance(act, int):
         return act
