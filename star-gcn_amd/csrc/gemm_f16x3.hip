@@ -184,6 +184,9 @@ struct PlaneArgs {
   int KS;               // 16-k steps per row block = Kp / 16 (a multiple of 4)
 };
 
+#ifndef SG_X3_ABLATE
+#define SG_X3_ABLATE 0      // development (timing only): 1 no MFMAs, 2 no fragment reads, 3 no DMA
+#endif
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 typedef const __attribute__((address_space(4))) int cst_int;      // constant address space: scalar (s_load) access
@@ -315,8 +318,13 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
   // DMA of one K tile: UNITS units of 1 KiB, UPW per wave.  unit u: row block u / UPB (A blocks first), part u % UPB of the
   // block's contiguous UPB KiB (k step x plane)
   const long long rb_stride = static_cast<long long>(pl.KS) * 2 * UNIT;
+#ifdef SG_X3_EXP_SAME_TILE      // experiment: every workgroup loads panel 0 (operands L2-hot): is the kernel memory-latency bound?
+  const char* a_base = pl.pa + static_cast<long long>(s0) * 2 * UNIT + lane * 16;
+  const char* b_base = pl.pb + static_cast<long long>(s0) * 2 * UNIT + lane * 16;
+#else
   const char* a_base = pl.pa + static_cast<long long>(tm) * RBA * rb_stride + static_cast<long long>(s0) * 2 * UNIT + lane * 16;
   const char* b_base = pl.pb + static_cast<long long>(tn) * RBB * rb_stride + static_cast<long long>(s0) * 2 * UNIT + lane * 16;
+#endif
   auto issue = [&](int kt) {
     char* dst = smem + (kt % NST) * STAGE_B;
 #pragma unroll
@@ -352,7 +360,9 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
         else wait_vm<0>();                                  // tail: fewer tiles in flight than the count assumes
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#if SG_X3_ABLATE != 3
         if (kt + NST - 1 < T) issue(kt + NST - 1);
+#endif
         const char* st = smem + (kt % NST) * STAGE_B;
 #pragma unroll
         for (int ks = 0; ks < BKS; ++ks) {
@@ -361,9 +371,23 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
+#if SG_X3_ABLATE == 2
+              a[i][p] = __builtin_bit_cast(f16x8, make_uint4(kt, ks, i, p));
+              b[i][p] = __builtin_bit_cast(f16x8, make_uint4(p, i, ks, kt));
+#else
               a[i][p] = *reinterpret_cast<const f16x8*>(st + ((wm * 2 + i) * UPB + ks * 2 + p) * UNIT + lane * 16);
               b[i][p] = *reinterpret_cast<const f16x8*>(st + ((RBA + wn * 2 + i) * UPB + ks * 2 + p) * UNIT + lane * 16);
+#endif
             }
+#if SG_X3_ABLATE == 1
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int p = 0; p < 2; ++p)
+                P[i][j][p] = ((tt == 0 && ks == 0) ? 0.f : P[i][j][p]) + static_cast<float>(a[i][p][0]) + static_cast<float>(b[j][p][1]);
+#else
           // corrections first, leading product last; the four tiles interleave so consecutive MFMAs never depend on each other
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -378,6 +402,7 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], P[i][j], 0, 0, 0);
+#endif
         }
       }
     }
