@@ -281,7 +281,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, f32x16 (&acc)[2][2
 //   <4, 2, 3>  256 x 128 x 32, 144 KiB: one workgroup per CU, 25 % fewer operand bytes per flop, one to two K tiles in flight
 // What bounds these kernels is bytes in flight: at the matrix-core rate a CU consumes 31-43 B / clk of planes, the loaded
 // L2 / Infinity-Cache latency is ~2 us, and LDS (160 KiB) is the only place in-flight DMA data can land.
-template <int WM, int BKS, int NST, int MINW = 2>
+template <int WM, int BKS, int NST, int MINW = 2, bool PIPE = false>
 __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmArgs g, const PlaneArgs pl) {
   constexpr int RBA = 2 * WM, RBB = 4;                 // 32-row blocks of A / B per tile
   constexpr int UPB = 2 * BKS;                         // units per row block and K tile (k step x plane)
@@ -351,6 +351,83 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
   for (int i = 0; i < NST - 1; ++i)
     if (i < T) issue(i);
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (PIPE) {
+    // Software-pipelined form (BKS = 1, NST = 4): the fragments of tile t+1 are READ into the other register set while
+    // tile t multiplies, so the LDS latency and the matrix instructions of a wave overlap instead of alternating
+    // (ablations, DESIGN 3.3: each phase costs ~0.35 us per K tile and they ran back to back).  Invariants at the top of
+    // iteration t: F[t & 1] holds tile t; tile t+1 has landed and is visible (the barrier at the end of iteration t-1
+    // followed the wait for it); tiles t+2 (and t+3 after the issue below) are in flight.  The stage that receives tile
+    // t+3 held tile t-1, whose fragments were read during iteration t-2 -- two barriers ago.
+    static_assert(!PIPE || (BKS == 1 && NST == 4), "pipelined form: 16-k tiles, four stages");
+    f16x8 Fa[2][2][2], Fb[2][2][2];      // [set][row block i][plane]
+    auto read_frags = [&](int set, int kt) {
+      const char* st = smem + (kt % NST) * STAGE_B;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          Fa[set][i][p] = *reinterpret_cast<const f16x8*>(st + ((wm * 2 + i) * UPB + p) * UNIT + lane * 16);
+          Fb[set][i][p] = *reinterpret_cast<const f16x8*>(st + ((RBA + wn * 2 + i) * UPB + p) * UNIT + lane * 16);
+        }
+    };
+    if (T > 0) {
+      if (T > 2) wait_vm<2 * UPW>(); else if (T > 1) wait_vm<UPW>(); else wait_vm<0>();      // tile 0 landed
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      read_frags(0, 0);
+      if (T > 1) {
+        if (T > 2) wait_vm<UPW>(); else wait_vm<0>();                                        // tile 1 landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+    for (int kb = 0; kb * TPB < T; ++kb) {
+#pragma unroll
+      for (int tt = 0; tt < TPB; ++tt) {
+        const int kt = kb * TPB + tt;
+        if (kt < T) {
+          constexpr int dummy = 0; (void)dummy;
+          const int set = tt & 1;                           // TPB is even: the parity of kt
+          if (kt + 3 < T) issue(kt + 3);
+          if (kt + 1 < T) read_frags(set ^ 1, kt + 1);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fa[set][i][1], Fb[set][j][0], tt == 0 ? zero : P[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fa[set][i][0], Fb[set][j][1], P[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Fa[set][i][0], Fb[set][j][0], P[i][j], 0, 0, 0);
+          if (kt + 2 < T) {                                 // tile t+2 must be visible to the reads of the next iteration
+            if (kt + 3 < T) wait_vm<UPW>(); else wait_vm<0>();
+          }
+          if (kt + 1 < T) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ex = ea_p[i * kbs + kb] + eb_p[j * kbs + kb];
+          if (ex >= -126 && ex <= 127) {
+            const float sc = __uint_as_float(static_cast<unsigned>(127 + ex) << 23);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(P[i][j][e], sc, acc[i][j][e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] += ldexpf(P[i][j][e], ex);
+          }
+        }
+    }
+  } else
   for (int kb = 0; kb * TPB < T; ++kb) {
 #pragma unroll
     for (int tt = 0; tt < TPB; ++tt) {
@@ -797,7 +874,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
   // workgroup and the 256-row geometries on every plane-path shape by 4-14 %: the third workgroup's matrix work fills the
   // barrier / DMA-wait gaps of the other two
   (void)slice;
-  int v = ((variant >= 1 && variant <= 3) || variant == 6) ? variant : 6;
+  int v = ((variant >= 1 && variant <= 3) || variant == 6 || variant == 7) ? variant : 6;
   if (v == 3) {
     g.tiles_m = static_cast<int>((g.M + 255) / 256);
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
@@ -807,6 +884,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
     if (v == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 5>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
     else if (v == 6) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 3, 3>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
+    else if (v == 7) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 4, 2, true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
   }
   return SG_OK;
@@ -815,6 +893,6 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
 }  // namespace sg
 
 SG_API int sg_gemm_x3_variant(int variant) {
-  sg::g_x3_variant_override.store(variant < 0 || variant > 6 ? -1 : variant, std::memory_order_relaxed);
+  sg::g_x3_variant_override.store(variant < 0 || variant > 7 ? -1 : variant, std::memory_order_relaxed);
   return SG_OK;
 }

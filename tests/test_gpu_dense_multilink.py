@@ -121,7 +121,7 @@ def test_gemm_x6v2_persistent_multi_item_shapes():
         L.lib().sg_gemm_backend(-1)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 5, 6, 7])
 def test_gemm_f16x3_geometries_and_in_kernel_split(variant):
     """Backend 3 has four plane-kernel geometries (6 = the default, three workgroups per CU) and the "hybrid" forms that split a huge fp32 operand inside the kernel
     (variant 5 uses them at any size: A K-contiguous / row-contiguous, and the swapped-operand form of wide, short-M
