@@ -192,3 +192,17 @@ def test_drop_in_import_path():
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "star-gcn_amd"))
     out = subprocess.check_output([sys.executable, "-c", code], env=env, cwd="/tmp").decode()
     assert out.strip().endswith("ok")
+
+
+def test_bench_withholds_pmc_traffic_when_the_kernel_source_changed(monkeypatch):
+    """roofline.traffic comes from committed PMC passes (profiles/pmc_traffic.json); every record carries the sha of the
+    seg_gather.hip it was measured on and bench.py must not present it for another kernel source."""
+    import bench
+    rec = bench.profile_record("ml-10m:256")
+    assert rec and not rec.get("stale") and rec["traffic_bytes_per_launch_mean"] > 0       # committed record matches the tree
+    hbm = bench.profile_record("hbm-config5-shard:256")
+    assert hbm and not hbm.get("stale")
+    monkeypatch.setattr(bench, "_sha16", lambda path: "0123456789abcdef")
+    stale = bench.profile_record("ml-10m:256")
+    assert stale["stale"] and "traffic withheld" in stale["source"] and "traffic_bytes_per_launch_mean" not in stale
+    assert bench.profile_record("no-such-shape:1") is None
