@@ -61,7 +61,7 @@ struct GemmArgs {   // must match gemm_f32.hip
 
 namespace f16x3 {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BN = 128;
 constexpr int UNIT = 1024;                 // bytes one wave feeds to one MFMA operand: 64 lanes x 8 halves
 constexpr int CPITCH = 68;                 // floats per row of a wave's private C staging block (32 x 64 + pad)
 constexpr int CSTAGE = 32 * CPITCH * 4;    // 8704 B per wave
@@ -187,6 +187,23 @@ struct PlaneArgs {
 #ifndef SG_X3_ABLATE
 #define SG_X3_ABLATE 0      // development (timing only): 1 no MFMAs, 2 no fragment reads, 3 no DMA
 #endif
+#ifndef SG_X3_ISSUE_POS
+#define SG_X3_ISSUE_POS 3   // where a wave issues the DMA of tile t+NST-1 inside iteration t: 0 before its fragment reads,
+#endif                      // 1 after them (the reads then queue behind the DMA: -30 %), 2 after its matrix instructions,
+                            // 3 in two halves between the three groups of matrix instructions (+3..6 % over 0, measured)
+#ifndef SG_X3H_ISSUE_POS
+#define SG_X3H_ISSUE_POS 3  // the same choice for the B planes of the hybrid kernel (0 or 3; 3 measured +1 %)
+#endif
+#ifndef SG_X3_TIMING
+#define SG_X3_TIMING 0      // development: per-phase cycle counters of wave 0 of every workgroup (sg_x3_timing_read)
+#endif
+#if SG_X3_TIMING
+// [0] vmcnt wait  [1] barrier  [2] DMA issue  [3] fragment reads (issue -> data)  [4] MFMAs (issue -> last result)  [5] K tiles
+__device__ unsigned long long g_x3_timing[6];
+#define X3_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define X3_T(var)
+#endif
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 typedef const __attribute__((address_space(4))) int cst_int;      // constant address space: scalar (s_load) access
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
   static_assert(NST * STAGE_B >= NW * CSTAGE, "epilogue staging aliases the stages");
   __shared__ __attribute__((aligned(16))) char smem[NST * STAGE_B];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
   // work item -> (tile, K slice); XCD-aware bijective remap of the tile index (workgroup b runs on XCD b % 8): the tiles of
   // one XCD are consecutive, consecutive tiles share their A panel
   const int nt = g.tiles_m * g.tiles_n;
@@ -314,6 +331,9 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#if SG_X3_TIMING
+  unsigned long long tq[6] = {0, 0, 0, 0, 0, 0};
+#endif
 
   // DMA of one K tile: UNITS units of 1 KiB, UPW per wave.  unit u: row block u / UPB (A blocks first), part u % UPB of the
   // block's contiguous UPB KiB (k step x plane)
@@ -325,16 +345,17 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
   const char* a_base = pl.pa + static_cast<long long>(tm) * RBA * rb_stride + static_cast<long long>(s0) * 2 * UNIT + lane * 16;
   const char* b_base = pl.pb + static_cast<long long>(tn) * RBB * rb_stride + static_cast<long long>(s0) * 2 * UNIT + lane * 16;
 #endif
-  auto issue = [&](int kt) {
+  auto issue_unit = [&](int kt, int i) {
     char* dst = smem + (kt % NST) * STAGE_B;
+    const int u = wave * UPW + i;
+    const int q = u / UPB, part = u - q * UPB;
+    const char* src = (q < RBA ? a_base + q * rb_stride : b_base + (q - RBA) * rb_stride) +
+                      static_cast<long long>(kt) * (UPB * UNIT) + part * UNIT;
+    __builtin_amdgcn_global_load_lds((glb_void*)(src), (lds_void*)(dst + u * UNIT), 16, 0, 0);
+  };
+  auto issue = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < UPW; ++i) {
-      const int u = wave * UPW + i;
-      const int q = u / UPB, part = u - q * UPB;
-      const char* src = (q < RBA ? a_base + q * rb_stride : b_base + (q - RBA) * rb_stride) +
-                        static_cast<long long>(kt) * (UPB * UNIT) + part * UNIT;
-      __builtin_amdgcn_global_load_lds((glb_void*)(src), (lds_void*)(dst + u * UNIT), 16, 0, 0);
-    }
+    for (int i = 0; i < UPW; ++i) issue_unit(kt, i);
   };
   // block exponents of this wave's two A row blocks and two B row blocks (wave-uniform: scalar loads)
   const int kbs = pl.KS >> 2;
@@ -433,13 +454,17 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
     for (int tt = 0; tt < TPB; ++tt) {
       const int kt = kb * TPB + tt;
       if (kt < T) {                                         // wave-uniform; only the last block of a slice can be short
+        X3_T(t0);
         if (kt + NST - 2 < T) wait_vm<UPW * (NST - 2)>();   // in order: everything up to tile kt has landed
         else wait_vm<0>();                                  // tail: fewer tiles in flight than the count assumes
+        X3_T(t1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-#if SG_X3_ABLATE != 3
+        X3_T(t2);
+#if SG_X3_ABLATE != 3 && SG_X3_ISSUE_POS == 0
         if (kt + NST - 1 < T) issue(kt + NST - 1);
 #endif
+        X3_T(t3);
         const char* st = smem + (kt % NST) * STAGE_B;
 #pragma unroll
         for (int ks = 0; ks < BKS; ++ks) {
@@ -456,6 +481,14 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
               b[i][p] = *reinterpret_cast<const f16x8*>(st + ((RBA + wn * 2 + i) * UPB + ks * 2 + p) * UNIT + lane * 16);
 #endif
             }
+#if SG_X3_ISSUE_POS == 1
+          asm volatile("" ::: "memory");
+          if (ks == BKS - 1 && kt + NST - 1 < T) issue(kt + NST - 1);
+#endif
+#if SG_X3_TIMING
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+          X3_T(t4);
 #if SG_X3_ABLATE == 1
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -471,14 +504,38 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
 #pragma unroll
             for (int j = 0; j < 2; ++j)
               P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], (tt == 0 && ks == 0) ? zero : P[i][j], 0, 0, 0);
+#if SG_X3_ISSUE_POS == 3
+          asm volatile("" ::: "memory");
+          if (ks == BKS - 1 && kt + NST - 1 < T) {
+#pragma unroll
+            for (int u = 0; u < UPW / 2; ++u) issue_unit(kt + NST - 1, u);
+          }
+          asm volatile("" ::: "memory");
+#endif
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], P[i][j], 0, 0, 0);
+#if SG_X3_ISSUE_POS == 3
+          asm volatile("" ::: "memory");
+          if (ks == BKS - 1 && kt + NST - 1 < T) {
+#pragma unroll
+            for (int u = UPW / 2; u < UPW; ++u) issue_unit(kt + NST - 1, u);
+          }
+          asm volatile("" ::: "memory");
+#endif
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], P[i][j], 0, 0, 0);
+#if SG_X3_ISSUE_POS == 2
+          asm volatile("" ::: "memory");
+          if (ks == BKS - 1 && kt + NST - 1 < T) issue(kt + NST - 1);
+#endif
+#endif
+#if SG_X3_TIMING
+          asm volatile("s_nop 0" :: "v"(P[1][1][0]));       // the last MFMA result: the section's time is its execution time
+          { X3_T(t5); tq[0] += t1 - t0; tq[1] += t2 - t1; tq[2] += t3 - t2; tq[3] += t4 - t3; tq[4] += t5 - t4; tq[5] += 1; }
 #endif
         }
       }
@@ -499,6 +556,12 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
         }
       }
   }
+#if SG_X3_TIMING
+  if (lane == 0 && wave == 0) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) atomicAdd(&g_x3_timing[q], tq[q]);
+  }
+#endif
   __syncthreads();       // every wave is done with the stages: they become the epilogue's staging blocks
 
   store_tile(g, acc, smem, wave, lane, tm * (64 * WM), tn * BN, z);
@@ -520,7 +583,7 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
 // the K-contiguous form) instead of sixteen dword loads.
 template <bool ARC, bool AV4 = false>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, const PlaneArgs pl) {
-  constexpr int UPB = 4, RBA = 4, UNITS_B = 16, STAGE_B = 32 * UNIT;      // per stage: A units 0..15, B units 16..31
+  constexpr int UPB = 4, RBA = 4, STAGE_B = 32 * UNIT;      // per stage: A units 0..15, B units 16..31
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B + 64];
   int* exp_lds = reinterpret_cast<int*>(smem + 2 * STAGE_B);               // [stage][row block]
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -546,15 +609,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
   // ---- B planes by DMA: 16 units per K tile, 4 per wave ----
   const long long rb_stride = static_cast<long long>(pl.KS) * 2 * UNIT;
   const char* b_base = pl.pb + static_cast<long long>(tn) * 4 * rb_stride + static_cast<long long>(kt0) * (UPB * UNIT) + lane * 16;
-  auto issue_b = [&](int kt) {
+  auto issue_b_unit = [&](int kt, int i) {
     char* dst = smem + (kt & 1) * STAGE_B + 16 * UNIT;
+    const int u = wave * 4 + i;
+    const int q = u >> 2, part = u & 3;
+    const char* src = b_base + q * rb_stride + static_cast<long long>(kt) * (UPB * UNIT) + part * UNIT;
+    __builtin_amdgcn_global_load_lds((glb_void*)(src), (lds_void*)(dst + u * UNIT), 16, 0, 0);
+  };
+  auto issue_b = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int u = wave * 4 + i;
-      const int q = u >> 2, part = u & 3;
-      const char* src = b_base + q * rb_stride + static_cast<long long>(kt) * (UPB * UNIT) + part * UNIT;
-      __builtin_amdgcn_global_load_lds((glb_void*)(src), (lds_void*)(dst + u * UNIT), 16, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i) issue_b_unit(kt, i);
   };
   const int kbs = pl.KS >> 2;
   cst_int* eb_p = (cst_int*)(pl.exp_b + static_cast<long long>(tn * 4 + wn * 2) * kbs);
@@ -668,7 +732,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
   for (int kt = 0; kt < T; ++kt) {
     const bool more = kt + 1 < T;                          // wave-uniform
     if (more) {
+#if SG_X3H_ISSUE_POS == 0
       issue_b(kt + 1);                                     // the other stage was released by the barrier just passed
+#endif
       load_a(kt + 1);
     }
     const char* st = smem + (kt & 1) * STAGE_B;
@@ -687,10 +753,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], ks == 0 ? zero : P[i][j], 0, 0, 0);
+#if SG_X3H_ISSUE_POS == 3
+      asm volatile("" ::: "memory");
+      if (more) issue_b_unit(kt + 1, ks * 2);
+      asm volatile("" ::: "memory");
+#endif
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], P[i][j], 0, 0, 0);
+#if SG_X3H_ISSUE_POS == 3
+      asm volatile("" ::: "memory");
+      if (more) issue_b_unit(kt + 1, ks * 2 + 1);
+      asm volatile("" ::: "memory");
+#endif
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -896,3 +972,14 @@ SG_API int sg_gemm_x3_variant(int variant) {
   sg::g_x3_variant_override.store(variant < 0 || variant > 7 ? -1 : variant, std::memory_order_relaxed);
   return SG_OK;
 }
+
+#if SG_X3_TIMING
+// development build only (not declared in include/stargcn.h): read and reset the phase counters
+extern "C" __attribute__((visibility("default"))) int sg_x3_timing_read(unsigned long long* out6) {
+  unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out6, HIP_SYMBOL(sg::f16x3::g_x3_timing), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(sg::f16x3::g_x3_timing), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
