@@ -194,6 +194,9 @@ struct PlaneArgs {
 #ifndef SG_X3H_ISSUE_POS
 #define SG_X3H_ISSUE_POS 3  // the same choice for the B planes of the hybrid kernel (0 or 3; 3 measured +1 %)
 #endif
+#ifndef SG_X3_PRIO
+#define SG_X3_PRIO 0        // s_setprio 1 over a K tile's matrix instructions: 1 including the DMA issue between them, 2 not
+#endif
 #ifndef SG_X3_TIMING
 #define SG_X3_TIMING 0      // development: per-phase cycle counters of wave 0 of every workgroup (sg_x3_timing_read)
 #endif
@@ -499,6 +502,10 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
                 P[i][j][p] = ((tt == 0 && ks == 0) ? 0.f : P[i][j][p]) + static_cast<float>(a[i][p][0]) + static_cast<float>(b[j][p][1]);
 #else
           // corrections first, leading product last; the four tiles interleave so consecutive MFMAs never depend on each other
+#if SG_X3_PRIO
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -507,8 +514,14 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
 #if SG_X3_ISSUE_POS == 3
           asm volatile("" ::: "memory");
           if (ks == BKS - 1 && kt + NST - 1 < T) {
+#if SG_X3_PRIO == 2
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
             for (int u = 0; u < UPW / 2; ++u) issue_unit(kt + NST - 1, u);
+#if SG_X3_PRIO == 2
+            __builtin_amdgcn_s_setprio(1);
+#endif
           }
           asm volatile("" ::: "memory");
 #endif
@@ -519,8 +532,14 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
 #if SG_X3_ISSUE_POS == 3
           asm volatile("" ::: "memory");
           if (ks == BKS - 1 && kt + NST - 1 < T) {
+#if SG_X3_PRIO == 2
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
             for (int u = UPW / 2; u < UPW; ++u) issue_unit(kt + NST - 1, u);
+#if SG_X3_PRIO == 2
+            __builtin_amdgcn_s_setprio(1);
+#endif
           }
           asm volatile("" ::: "memory");
 #endif
@@ -528,6 +547,9 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], P[i][j], 0, 0, 0);
+#if SG_X3_PRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
 #if SG_X3_ISSUE_POS == 2
           asm volatile("" ::: "memory");
           if (ks == BKS - 1 && kt + NST - 1 < T) issue(kt + NST - 1);

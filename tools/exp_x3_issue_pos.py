@@ -28,8 +28,12 @@ for (M, N, K) in [(4096, 4096, 4096), (262144, 4096, 1024), (262144, 256, 4160)]
             out.append("%%dx%%dx%%d v%%d %%.3f ms %%.0f TF err %%.1e" %% (M, N, K, v, t * 1e3, 2.0 * M * N * K / t / 1e12, err))
 print(" | ".join(out))
 ''' % ROOT
-for tag, lib, tim in [("pos0", None, 0), ("pos1", "p1t0", 0), ("pos2", "p2t0", 0), ("pos3", "p3t0", 0),
-                      ("pos0 t", "x3timing", 1), ("pos1 t", "p1t1", 1), ("pos2 t", "p2t1", 1), ("pos3 t", "p3t1", 1)]:
+CASES = [("default", None, 0), ("pos1", "p1t0", 0), ("pos2", "p2t0", 0), ("pos3", "p3t0", 0),
+         ("pos0 t", "x3timing", 1), ("pos1 t", "p1t1", 1), ("pos2 t", "p2t1", 1), ("pos3 t", "p3t1", 1),
+         ("prio1", "pr1", 0), ("prio2", "pr2", 0)]
+if len(sys.argv) > 1:
+    CASES = [c for c in CASES if c[0] in sys.argv[1:]]
+for tag, lib, tim in CASES:
     env = dict(os.environ)
     if lib:
         env["SG_LIB_OVERRIDE"] = os.path.join(ROOT, "tools", "ablate", "libstargcn_%s.so" % lib)
