@@ -194,6 +194,9 @@ struct PlaneArgs {
 #ifndef SG_X3H_ISSUE_POS
 #define SG_X3H_ISSUE_POS 3  // the same choice for the B planes of the hybrid kernel (0 or 3; 3 measured +1 %)
 #endif
+#ifndef SG_X3_NOFOLD
+#define SG_X3_NOFOLD 0      // development (timing only, wrong results): no block-local accumulator and no fold; variant 2 then
+#endif                      // runs <2,1,2,4> (four workgroups per CU)
 #ifndef SG_X3_PRIO
 #define SG_X3_PRIO 0        // s_setprio 1 over a K tile's matrix instructions: 1 including the DMA issue between them, 2 not
 #endif
@@ -308,8 +311,8 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
   constexpr int UNITS = (RBA + RBB) * UPB, NW = 2 * WM, UPW = UNITS / NW;
   constexpr int STAGE_B = UNITS * UNIT;
   static_assert(UNITS % NW == 0, "units must divide over the waves");
-  static_assert(NST * STAGE_B >= NW * CSTAGE, "epilogue staging aliases the stages");
-  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE_B];
+  constexpr int SMEM_B = NST * STAGE_B > NW * CSTAGE ? NST * STAGE_B : NW * CSTAGE;   // the epilogue's staging aliases the stages
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_B];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   // work item -> (tile, K slice); XCD-aware bijective remap of the tile index (workgroup b runs on XCD b % 8): the tiles of
@@ -327,7 +330,12 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
   const int T = (s1 - s0 + BKS - 1) / BKS;             // K tiles of this slice (planes are zero-padded to 64 k)
 
   // acc: running result (true scale); P: products of the current 64-k block (block scale)
+#if SG_X3_NOFOLD
+  f32x16 acc[2][2];
+  f32x16 (&P)[2][2] = acc;
+#else
   f32x16 acc[2][2], P[2][2];
+#endif
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], (tt == 0 && ks == 0) ? zero : P[i][j], 0, 0, 0);
+              P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], (!SG_X3_NOFOLD && tt == 0 && ks == 0) ? zero : P[i][j], 0, 0, 0);
 #if SG_X3_ISSUE_POS == 3
           asm volatile("" ::: "memory");
           if (ks == BKS - 1 && kt + NST - 1 < T) {
@@ -563,6 +571,7 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
       }
     }
     // end of the 64-k block: fold it into the running result at its true scale 2^ex (exact)
+#if !SG_X3_NOFOLD
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -577,6 +586,7 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
           for (int e = 0; e < 16; ++e) acc[i][j][e] += ldexpf(P[i][j][e], ex);
         }
       }
+#endif
   }
 #if SG_X3_TIMING
   if (lane == 0 && wave == 0) {
@@ -980,7 +990,11 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
   } else {
     g.tiles_m = tm128;
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
+#if SG_X3_NOFOLD
+    if (v == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 2, 4>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
+#else
     if (v == 2) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 5>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
+#endif
     else if (v == 6) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 3, 3>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
     else if (v == 7) hipLaunchKernelGGL((gemm_f16x3_kernel<2, 1, 4, 2, true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
     else hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2, 2>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);

@@ -1,53 +1,57 @@
-"""Can the matrix-core GEMM (x6v2: one 8-wave workgroup per CU) hide under the L1-miss-bound gather (28 single-wave
-workgroups per CU)?  Same work serial on one stream vs on two streams (GEMM stream with high priority / launched first)."""
+"""Does a dense mix overlap with a gather when both are in flight on two HIP streams?  (ML-10M shapes.)
+python tools/exp_overlap.py"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from star_gcn_amd import ops, _lib as L
-rng = np.random.default_rng(0)
-nnz, C, S, T = 10_000_000, 256, 69878, 106770
-lens = rng.multinomial(nnz, rng.dirichlet(np.ones(S) * 2.0))
-indptr = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).cuda()
-seg = np.repeat(np.arange(S), lens)
-pop = rng.lognormal(0.0, 1.5, T); rng.shuffle(pop)
-idx = rng.choice(T, size=nnz, p=pop / pop.sum()).astype(np.int64)
-idx_d = torch.from_numpy(idx[np.lexsort((idx, seg))].astype(np.int32)).cuda()
-w = torch.rand(nnz).cuda(); x = torch.randn(T, C, device="cuda"); out = torch.empty(S, C, device="cuda")
-L.lib().sg_gather_tuning(-1, 4)
-a = torch.randn(10677, 2624, device="cuda"); b = torch.randn(256, 2624, device="cuda")
-a2 = torch.randn(69878, 256, device="cuda"); b2 = torch.randn(256, 256, device="cuda")
-cbuf = torch.empty(10677, 256, device="cuda"); c2 = torch.empty(69878, 256, device="cuda")
+from star_gcn_amd import ops
 
-def gather():
-    ops.gather_sum(out, x, idx_d, indptr, w, S, C)
+g = torch.Generator().manual_seed(0)
+def gather_case(S, T, nnz, C=256):
+    lens = torch.distributions.Multinomial(nnz, torch.rand(S, generator=g) ** 2 + 1e-3).sample().long()
+    indptr = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)]).int().cuda()
+    idx = torch.randint(0, T, (nnz,), generator=g).int().cuda()
+    w = torch.rand(1, nnz, generator=g).cuda()
+    x = torch.randn(1, T, C, device="cuda"); out = torch.empty(1, S, C, device="cuda")
+    return lambda: ops.seg_weighted_pool(x, w, idx, indptr, out=out)
 
-def gemms(n):
+def gemm_case(M, N, K, reps):
+    a = torch.randn(M, K, device="cuda"); b = torch.randn(N, K, device="cuda"); c = torch.empty(M, N, device="cuda")
+    def run():
+        for _ in range(reps):
+            ops.gemm(a, b, trans_b=True, out=c)
+    return run
+
+def wall(fn, n=15, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); ts = []
     for _ in range(n):
-        ops.gemm(a, b, trans_b=True, out=cbuf)
-        ops.gemm(a2, b2, trans_b=True, out=c2)
-
-def timed(fn, reps=10):
-    fn(); torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     return float(np.median(ts))
 
-for n in (1, 2, 3):
-    tg = timed(gather); tm = timed(lambda: gemms(n))
-    ser = timed(lambda: (gather(), gemms(n)))
-    for prio, first in ((0, "gather"), (-1, "gemm"), (-1, "gather")):
-        sa, sb = torch.cuda.Stream(), torch.cuda.Stream(priority=prio)
-        def both():
-            cur = torch.cuda.current_stream()
-            sa.wait_stream(cur); sb.wait_stream(cur)
-            order = ((sb, lambda: gemms(n)), (sa, gather)) if first == "gemm" else ((sa, gather), (sb, lambda: gemms(n)))
-            for st, f in order:
-                with torch.cuda.stream(st):
-                    f()
-            cur.wait_stream(sa); cur.wait_stream(sb)
-        t2 = timed(both)
-        print("gemms x%d: gather %.3f ms, gemm %.3f ms, serial %.3f ms | two streams (gemm prio %d, %s first) %.3f ms  -> hidden %.0f %% of the GEMM time"
-              % (n, tg, tm, ser, prio, first, t2, 100 * (ser - t2) / tm), flush=True)
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+def both(f1, f2):
+    def run():
+        cur = torch.cuda.current_stream()
+        e = torch.cuda.Event(); e.record(cur)
+        s1.wait_event(e); s2.wait_event(e)
+        with torch.cuda.stream(s1): f1()
+        with torch.cuda.stream(s2): f2()
+        cur.wait_stream(s1); cur.wait_stream(s2)
+    return run
+
+for gname, gat in [("users<-items (68 MB class)", gather_case(69878, 10677, 10_000_000)), ("items<-users", gather_case(10677, 69878, 10_000_000))]:
+    for mname, mm in [("10677x2560x256 x4", gemm_case(10677, 2560, 256, 4)), ("69878x256x2624 x1", gemm_case(69878, 256, 2624, 1)),
+                      ("4096^3 x1", gemm_case(4096, 4096, 4096, 1))]:
+        with torch.cuda.stream(s1): gat()
+        with torch.cuda.stream(s2): mm()
+        torch.cuda.synchronize()
+        tg, tm = wall(gat), wall(mm)
+        seq = wall(lambda: (gat(), mm()))
+        con = wall(both(gat, mm))
+        print("%-28s + %-20s gather %.3f  gemm %.3f  sequential %.3f  two streams %.3f ms  (max %.3f)" % (gname, mname, tg, tm, seq, con, max(tg, tm)), flush=True)
+g2 = gather_case(10677, 69878, 10_000_000)
+g1 = gather_case(69878, 10677, 10_000_000)
+with torch.cuda.stream(s2): g2()
+torch.cuda.synchronize()
+print("two gathers: %.3f + %.3f sequential %.3f, two streams %.3f ms" % (wall(g1), wall(g2), wall(lambda: (g1(), g2())), wall(both(g1, g2))))

@@ -15,7 +15,7 @@ out = []
 for (M, N, K) in [(4096, 4096, 4096), (262144, 4096, 1024), (262144, 256, 4160)]:
     a = torch.randn(M, K, device="cuda"); b = torch.randn(N, K, device="cuda")
     ref = (a[:256].double() @ b[:256].double().t())
-    for v in (1, 6):
+    for v in (1, 6, 2):
         lib.sg_gemm_x3_variant(v)
         c = ops.gemm(a, b, trans_b=True)
         err = float((c[:256, :256].double() - ref).abs().max() / ref.abs().max())
@@ -30,7 +30,7 @@ print(" | ".join(out))
 ''' % ROOT
 CASES = [("default", None, 0), ("pos1", "p1t0", 0), ("pos2", "p2t0", 0), ("pos3", "p3t0", 0),
          ("pos0 t", "x3timing", 1), ("pos1 t", "p1t1", 1), ("pos2 t", "p2t1", 1), ("pos3 t", "p3t1", 1),
-         ("prio1", "pr1", 0), ("prio2", "pr2", 0)]
+         ("prio1", "pr1", 0), ("prio2", "pr2", 0), ("nofold", "nf", 0)]
 if len(sys.argv) > 1:
     CASES = [c for c in CASES if c[0] in sys.argv[1:]]
 for tag, lib, tim in CASES:
