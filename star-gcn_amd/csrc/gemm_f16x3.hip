@@ -194,6 +194,9 @@ struct PlaneArgs {
 #ifndef SG_X3H_ISSUE_POS
 #define SG_X3H_ISSUE_POS 3  // the same choice for the B planes of the hybrid kernel (0 or 3; 3 measured +1 %)
 #endif
+#ifndef SG_X3H_ABLATE
+#define SG_X3H_ABLATE 0     // hybrid kernel, timing only: 1 A always read from the same 16 KB, 2 no conversion VALU (planes = raw bits)
+#endif
 #ifndef SG_X3_NOFOLD
 #define SG_X3_NOFOLD 0      // development (timing only, wrong results): no block-local accumulator and no fold; variant 2 then
 #endif                      // runs <2,1,2,4> (four workgroups per CU)
@@ -656,9 +659,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
   cst_int* eb_p = (cst_int*)(pl.exp_b + static_cast<long long>(tn * 4 + wn * 2) * kbs);
 
   // ---- A: this wave's 32-row block of a K tile, 16 fp32 per lane, loaded unconditionally from clamped coordinates ----
+#if SG_X3H_ABLATE == 1
+  const int m_blk = wave * 32;
+#else
   const int m_blk = tm * BM + wave * 32;
+#endif
   float va[16];
-  auto load_a = [&](int kt) {
+  auto load_a = [&](int kt_in) {
+#if SG_X3H_ABLATE == 1          // development (timing only): every load of A hits the same 16 KB (L2-hot): is A's latency what binds?
+    const int kt = (kt_in & 1) - kt0;
+#else
+    const int kt = kt_in;
+#endif
     const int k0 = (kt0 + kt) * 32;
     if (!ARC) {           // lane = (row lane / 8 + 8 i, k = 4 (lane % 8) .. + 3)
       const int k = min(k0 + (lane & 7) * 4, g.K - 4);
@@ -724,6 +736,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
     }
     const float sc = __uint_as_float(static_cast<unsigned>(127 + e) << 23);
     unsigned h1[8], h2[8];
+#if SG_X3H_ABLATE == 2
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h1[j] = __float_as_uint(x[2 * j]); h2[j] = __float_as_uint(x[2 * j + 1]); }
+    if (false)
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const f32x2 v = {x[2 * j] * sc, x[2 * j + 1] * sc};
