@@ -382,8 +382,9 @@ int sg_gemm_backend(int backend);
  * reduce included) on its own stream; read returns one record per call: ms, (M, N, K) at mnk[3 i ..], backend used */
 int sg_gemm_profile_enable(int on);
 int64_t sg_gemm_profile_read(float* ms, int64_t* mnk, int* backend, int64_t capacity);
-/* tuning aid for backend 3 (f16x3): 0 automatic; 1-3 and 6 force a plane-kernel geometry (6 = the default one); 4 never use the in-kernel split of a
- * huge fp32 operand ("hybrid"); 5 use it whenever the layout allows, whatever the size (tests).  -1 = SG_X3_VARIANT / 0. */
+/* tuning aid for backend 3 (f16x3): 0 automatic; 1-3, 6 and 7 force a plane-kernel geometry (6 = the default one, 7 = software-
+ * pipelined fragment reads); 4 never use the in-kernel split of a huge fp32 operand ("hybrid"); 5 use it whenever the layout
+ * allows, whatever the size (tests); 9 = 5 with one K tile of the fp32 operand in flight instead of two.  -1 = SG_X3_VARIANT / 0. */
 int sg_gemm_x3_variant(int variant);
 /* measurement aid: best-case streaming read with the gather's launch geometry: `workgroups` single-wave workgroups each
  * read `bursts` consecutive 1 KiB bursts (4 in flight) of a `bytes`-long buffer, wrapping around; bench.py uses it to

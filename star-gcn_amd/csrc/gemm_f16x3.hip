@@ -36,6 +36,7 @@
 // it is charged to this backend in every measurement.
 //
 // Epilogue / split-K contract identical to gemm_f32.hip (GemmArgs); selected by sg_gemm_f32_hip (backend 3).
+#include <type_traits>
 #include "common.hpp"
 
 #include <atomic>
@@ -70,6 +71,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ float act_fn(float v, int act, float slope) {
   switch (act) {
@@ -616,7 +618,10 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
 // ---------------------------------------------------------------------------------------------------------------------
 // AV4 (row-contiguous A only): M % 4 == 0 and 16-byte aligned k rows -> float4 loads along m (four per K tile and lane, like
 // the K-contiguous form) instead of sixteen dword loads.
-template <bool ARC, bool AV4 = false>
+// APF: K tiles of A in flight per wave.  1: tile t+1 is loaded while tile t multiplies (16 registers).  2: a second register
+// set -- tile t+2 is requested at the top of iteration t, right after the DMA of B's tile t+1, and the barrier at the end of
+// the iteration waits with a COUNTED vmcnt for everything but those youngest loads: A's HBM latency gets two tile times.
+template <bool ARC, bool AV4 = false, int APF = 1>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, const PlaneArgs pl) {
   constexpr int UPB = 4, RBA = 4, STAGE_B = 32 * UNIT;      // per stage: A units 0..15, B units 16..31
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B + 64];
@@ -649,7 +654,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
     const int u = wave * 4 + i;
     const int q = u >> 2, part = u & 3;
     const char* src = b_base + q * rb_stride + static_cast<long long>(kt) * (UPB * UNIT) + part * UNIT;
-    __builtin_amdgcn_global_load_lds((glb_void*)(src), (lds_void*)(dst + u * UNIT), 16, 0, 0);
+    if (APF == 2) {
+      // assembly, so that the compiler keeps no record of a pending LDS write: before the plane stores of the conversion it
+      // would otherwise wait with vmcnt(0) -- for this DMA, but also for A's younger loads, which it cannot see
+      const unsigned lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_void*)(dst + u * UNIT)));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // m0 is reserved: nothing else in this kernel uses it
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds) : "memory", "m0");
+#pragma clang diagnostic pop
+    } else {
+      __builtin_amdgcn_global_load_lds((glb_void*)(src), (lds_void*)(dst + u * UNIT), 16, 0, 0);
+    }
   };
   auto issue_b = [&](int kt) {
 #pragma unroll
@@ -664,8 +679,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
 #else
   const int m_blk = tm * BM + wave * 32;
 #endif
-  float va[16];
-  auto load_a = [&](int kt_in) {
+  constexpr int NA = (ARC && !AV4) ? 16 : 4;             // vector-memory instructions of one load_a
+  // APF == 2 (vector forms): the loads are inline assembly -- the compiler's own vmcnt before the conversion would be
+  // vmcnt(0) (it does not carry exact counts around the loop), draining the younger loads of tile kt+2 too.  The registers
+  // are pinned to the explicit counted wait (`wait_a`) as in/out operands, so no use can move above it.
+  constexpr bool ASM_A = APF == 2 && NA == 4;
+  f32x4 va0[4], va1[4];
+  auto ld4 = [&](f32x4& dst, const float* ptr) __attribute__((always_inline)) {
+    if (ASM_A) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+    else dst = *reinterpret_cast<const f32x4*>(ptr);
+  };
+  auto wait_a = [&](f32x4 (&va)[4], auto n) __attribute__((always_inline)) {      // n: younger vector-memory operations
+    constexpr int N = decltype(n)::value;
+    static_assert(N == 0 || N == 8, "add the immediate");
+    if (!ASM_A) return;
+    if (N == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]) : : "memory");
+  };
+  auto load_a = [&](int kt_in, f32x4 (&va)[4]) __attribute__((always_inline)) {
 #if SG_X3H_ABLATE == 1          // development (timing only): every load of A hits the same 16 KB (L2-hot): is A's latency what binds?
     const int kt = (kt_in & 1) - kt0;
 #else
@@ -677,27 +708,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = min(m_blk + (lane >> 3) + 8 * i, g.M - 1);
-        const float4 x = *reinterpret_cast<const float4*>(g.A + static_cast<long long>(row) * g.lda + k);
-        va[4 * i] = x.x; va[4 * i + 1] = x.y; va[4 * i + 2] = x.z; va[4 * i + 3] = x.w;
+        ld4(va[i], g.A + static_cast<long long>(row) * g.lda + k);
       }
     } else if (AV4) {     // lane = (4 op rows m = 4 (lane % 8) .., k = 4 (lane / 8) + i): 128-byte k-row segments, va[4 i + j] = (k i, m j)
       const int m = min(m_blk + (lane & 7) * 4, g.M - 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = min(k0 + (lane >> 3) * 4 + i, g.K - 1);
-        const float4 x = *reinterpret_cast<const float4*>(g.A + static_cast<long long>(k) * g.lda + m);
-        va[4 * i] = x.x; va[4 * i + 1] = x.y; va[4 * i + 2] = x.z; va[4 * i + 3] = x.w;
+        ld4(va[i], g.A + static_cast<long long>(k) * g.lda + m);
       }
     } else {              // lane = (op row m = lane % 32, k = 16 (lane / 32) + i): coalesced dword loads along m
       const int m = min(m_blk + (lane & 31), g.M - 1);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int k = min(k0 + (lane >> 5) * 16 + i, g.K - 1);
-        va[i] = g.A[static_cast<long long>(k) * g.lda + m];
+        va[i >> 2][i & 3] = g.A[static_cast<long long>(k) * g.lda + m];
       }
     }
   };
-  auto store_a = [&](int kt) {      // convert va (tile kt) and write its planes + exponent into stage kt & 1
+  auto store_a = [&](int kt, f32x4 (&va)[4]) __attribute__((always_inline)) {      // convert va (tile kt), write its planes + exponent into stage kt & 1
     const int k0 = (kt0 + kt) * 32;
     float x[16];
     float mx = 0.f;
@@ -707,7 +736,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
       for (int i = 0; i < 4; ++i) {
         const bool dead = kdead || (m_blk + (lane >> 3) + 8 * i >= g.M);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { x[4 * i + j] = dead ? 0.f : va[4 * i + j]; mx = fmaxf(mx, fabsf(x[4 * i + j])); }
+        for (int j = 0; j < 4; ++j) { x[4 * i + j] = dead ? 0.f : va[i][j]; mx = fmaxf(mx, fabsf(x[4 * i + j])); }
       }
     } else if (AV4) {     // transpose in registers: x[4 j + i] = (m j, k i) -> four consecutive k per op row, as in the K-contiguous form
       const bool mdead = m_blk + (lane & 7) * 4 >= g.M;       // M % 4 == 0: four rows are in or out together
@@ -715,13 +744,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
       for (int i = 0; i < 4; ++i) {
         const bool dead = mdead || (k0 + (lane >> 3) * 4 + i >= g.K);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { x[4 * j + i] = dead ? 0.f : va[4 * i + j]; mx = fmaxf(mx, fabsf(x[4 * j + i])); }
+        for (int j = 0; j < 4; ++j) { x[4 * j + i] = dead ? 0.f : va[i][j]; mx = fmaxf(mx, fabsf(x[4 * j + i])); }
       }
     } else {
       const bool mdead = m_blk + (lane & 31) >= g.M;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        x[i] = (mdead || k0 + (lane >> 5) * 16 + i >= g.K) ? 0.f : va[i];
+        x[i] = (mdead || k0 + (lane >> 5) * 16 + i >= g.K) ? 0.f : va[i >> 2][i & 3];
         mx = fmaxf(mx, fabsf(x[i]));
       }
     }
@@ -773,18 +802,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
 
   if (T > 0) {
     issue_b(0);
-    load_a(0);
-    store_a(0);
+    load_a(0, va0);
+    wait_a(va0, std::integral_constant<int, 0>{});
+    store_a(0, va0);
   }
+  if (APF == 2 && T > 1) load_a(1, va1);
   __syncthreads();
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int kt = 0; kt < T; ++kt) {
-    const bool more = kt + 1 < T;                          // wave-uniform
-    if (more) {
+  // one K tile.  APF == 1: `vnext` receives tile kt+1 now and is converted at the end.  APF == 2: `vnext` already holds
+  // tile kt+1 (requested one iteration ago), `vnew` receives tile kt+2.
+  // `steady` (compile time): tiles kt+1 and kt+2 exist -- no branch around a vector-memory instruction, so the compiler's
+  // own vmcnt before the conversion of `vnext` is exact (behind a branch it falls back to vmcnt(0), which would drain the
+  // loads of tile kt+2 as well).
+  auto body = [&](int kt, f32x4 (&vnew)[4], f32x4 (&vnext)[4], auto steady) __attribute__((always_inline)) {
+    constexpr bool ST = decltype(steady)::value;
+    const bool more = ST || kt + 1 < T;                    // wave-uniform
+    const bool more2 = ST || (APF == 2 && kt + 2 < T);
+    if (APF == 2) {
+      if (more) issue_b(kt + 1);                           // program order: B's DMA first, A's loads after it (counted wait)
+      asm volatile("" ::: "memory");
+      if (more2) load_a(kt + 2, vnew);
+    } else if (more) {
 #if SG_X3H_ISSUE_POS == 0
       issue_b(kt + 1);                                     // the other stage was released by the barrier just passed
 #endif
-      load_a(kt + 1);
+      load_a(kt + 1, vnext);
     }
     const char* st = smem + (kt & 1) * STAGE_B;
 #pragma unroll
@@ -803,18 +845,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
         for (int j = 0; j < 2; ++j)
           P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], ks == 0 ? zero : P[i][j], 0, 0, 0);
 #if SG_X3H_ISSUE_POS == 3
-      asm volatile("" ::: "memory");
-      if (more) issue_b_unit(kt + 1, ks * 2);
-      asm volatile("" ::: "memory");
+      if (APF == 1) {
+        asm volatile("" ::: "memory");
+        if (more) issue_b_unit(kt + 1, ks * 2);
+        asm volatile("" ::: "memory");
+      }
 #endif
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], P[i][j], 0, 0, 0);
 #if SG_X3H_ISSUE_POS == 3
-      asm volatile("" ::: "memory");
-      if (more) issue_b_unit(kt + 1, ks * 2 + 1);
-      asm volatile("" ::: "memory");
+      if (APF == 1) {
+        asm volatile("" ::: "memory");
+        if (more) issue_b_unit(kt + 1, ks * 2 + 1);
+        asm volatile("" ::: "memory");
+      }
 #endif
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -839,8 +885,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
         }
       }
     }
-    if (more) store_a(kt + 1);       // the loads had the whole multiplication to land
-    __syncthreads();                 // planes + exponent of tile kt+1 visible, B DMA landed (vmcnt(0) precedes the barrier)
+    if (more) {                             // the loads had the whole multiplication (APF 2: two of them) to land
+      if (APF == 2) {                       // younger than vnext's loads: B's DMA of tile kt+1 (4) and A's loads of tile kt+2 (4)
+        if (ST) wait_a(vnext, std::integral_constant<int, 8>{}); else wait_a(vnext, std::integral_constant<int, 0>{});
+      }
+      store_a(kt + 1, vnext);
+    }
+    if (APF == 2) {
+      // planes + exponent of tile kt+1 written (lgkmcnt), B's DMA of tile kt+1 landed: everything but the NA youngest
+      // vector-memory operations -- the loads of tile kt+2 stay in flight across the barrier
+      if (more2) wait_vm<NA>(); else wait_vm<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      __syncthreads();               // planes + exponent of tile kt+1 visible, B DMA landed (vmcnt(0) precedes the barrier)
+    }
+  };
+  if (APF == 2) {
+    int kt = 0;
+    for (; kt + 3 < T; kt += 2) {                          // steady state: both iterations see tiles kt+1, kt+2 (and kt+3)
+      body(kt, va0, va1, std::true_type{});
+      body(kt + 1, va1, va0, std::true_type{});
+    }
+    for (; kt < T; kt += 2) {                              // the last two to three tiles
+      body(kt, va0, va1, std::false_type{});
+      if (kt + 1 < T) body(kt + 1, va1, va0, std::false_type{});
+    }
+  } else {
+    for (int kt = 0; kt < T; ++kt) body(kt, va1, va0, std::false_type{});
   }
   store_tile(g, acc, smem, wave, lane, tm * BM, tn * BN, z);
 }
@@ -872,7 +945,7 @@ size_t f16x3_plane_bytes(long long M, long long N, long long K) {
 
 static std::atomic<int> g_x3_variant_override{-1};
 static int x3_variant() {      // tuning aid: SG_X3_VARIANT / sg_gemm_x3_variant = 0 auto, 1 <2,2,2>, 2 <2,1,5>, 3 <4,2,3>,
-                               // 4 never hybrid, 5 hybrid at any size
+                               // 4 never hybrid, 5 hybrid at any size, 9 hybrid at any size with ONE K tile of A in flight (round-3 first form)
   const int o = g_x3_variant_override.load(std::memory_order_relaxed);
   if (o >= 0) return o;
   static const int v = [] { const char* e = getenv("SG_X3_VARIANT"); return e ? atoi(e) : 0; }();
@@ -891,6 +964,22 @@ __global__ void reduce_t_kernel(float* __restrict__ C, long long ldc, const floa
   C[static_cast<long long>(m) * ldc + n] = v;
 }
 }  // namespace f16x3
+
+// the in-kernel-split kernel for A's layout (arc: row-contiguous in m; av4: float4 loads along m) and prefetch depth
+static void launch_hybrid(const GemmArgs& g, const f16x3::PlaneArgs& pl, long long items, bool arc, bool av4, bool deep,
+                          hipStream_t st) {
+  using namespace f16x3;
+  const dim3 grid(static_cast<unsigned>(items)), block(256);
+  if (deep) {
+    if (av4) hipLaunchKernelGGL((gemm_f16x3h_kernel<true, true, 2>), grid, block, 0, st, g, pl);
+    else if (arc) hipLaunchKernelGGL((gemm_f16x3h_kernel<true, false, 2>), grid, block, 0, st, g, pl);
+    else hipLaunchKernelGGL((gemm_f16x3h_kernel<false, false, 2>), grid, block, 0, st, g, pl);
+  } else {
+    if (av4) hipLaunchKernelGGL((gemm_f16x3h_kernel<true, true>), grid, block, 0, st, g, pl);
+    else if (arc) hipLaunchKernelGGL((gemm_f16x3h_kernel<true>), grid, block, 0, st, g, pl);
+    else hipLaunchKernelGGL((gemm_f16x3h_kernel<false>), grid, block, 0, st, g, pl);
+  }
+}
 
 // called by sg_gemm_f32_hip when backend 3 is selected; g.tiles_n is for 128-wide tiles (g.tiles_m is recomputed here for
 // the tile height chosen), g.tiles_per_split is EVEN when g.splits > 1 (a 64-k scale block = two K tiles must not straddle
@@ -942,7 +1031,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     g.tiles_per_split = per;
     g.splits = (ktiles + per - 1) / per;
   };
-  const long long big = variant == 5 ? 0 : 16ll << 20;  // elements: a 64 MB operand is worth keeping out of a split pass
+  const long long big = (variant == 5 || variant == 9) ? 0 : 16ll << 20;  // elements: a 64 MB operand is worth keeping out of a split pass
   // A may stay fp32 when its layout allows the in-kernel loads (K-contiguous rows need 16-byte vectors)
   const bool a_fly_ok = transA || (g.vecA && g.K % 4 == 0 && g.K >= 4);
   const bool b_fly_ok = !transB || (g.vecB && g.K % 4 == 0 && g.K >= 4);
@@ -955,10 +1044,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     fit_splits(static_cast<long long>(g.tiles_m) * g.tiles_n, 512);
     *splits_used = g.splits;
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
-    if (transA && g.vecA && g.M % 4 == 0)
-      hipLaunchKernelGGL((gemm_f16x3h_kernel<true, true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
-    else if (transA) hipLaunchKernelGGL((gemm_f16x3h_kernel<true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
-    else hipLaunchKernelGGL((gemm_f16x3h_kernel<false>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, g, pl);
+    launch_hybrid(g, pl, items, transA, transA && g.vecA && g.M % 4 == 0, variant != 9, st);
     return SG_OK;
   }
   if (variant != 4 && tm128 <= 2 && g.M <= 256 && static_cast<long long>(g.N) * g.K >= big && b_fly_ok && plain_epi) {
@@ -974,10 +1060,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     PlaneArgs pl{nullptr, pa, nullptr, ea, KS};
     const long long items = static_cast<long long>(h.tiles_m) * h.tiles_n * h.splits;
     // op(B)^T element (n, k): B stored (K x N) when !transB -> row-contiguous in n (ARC); (N x K) when transB -> K-contiguous
-    if (!transB && h.vecA && h.M % 4 == 0)
-      hipLaunchKernelGGL((gemm_f16x3h_kernel<true, true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, h, pl);
-    else if (!transB) hipLaunchKernelGGL((gemm_f16x3h_kernel<true>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, h, pl);
-    else hipLaunchKernelGGL((gemm_f16x3h_kernel<false>), dim3(static_cast<unsigned>(items)), dim3(256), 0, st, h, pl);
+    launch_hybrid(h, pl, items, !transB, !transB && h.vecA && h.M % 4 == 0, variant != 9, st);
     const long long total = static_cast<long long>(g.M) * g.N;
     if (g.splits > 1) {
       hipLaunchKernelGGL(reduce_t_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, g.C, g.ldc, g.ws,
@@ -1022,7 +1105,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
 }  // namespace sg
 
 SG_API int sg_gemm_x3_variant(int variant) {
-  sg::g_x3_variant_override.store(variant < 0 || variant > 7 ? -1 : variant, std::memory_order_relaxed);
+  sg::g_x3_variant_override.store(variant < 0 || variant > 9 ? -1 : variant, std::memory_order_relaxed);
   return SG_OK;
 }
 

@@ -121,11 +121,11 @@ def test_gemm_x6v2_persistent_multi_item_shapes():
         L.lib().sg_gemm_backend(-1)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 5, 6, 7])
+@pytest.mark.parametrize("variant", [1, 2, 3, 5, 6, 7, 9])
 def test_gemm_f16x3_geometries_and_in_kernel_split(variant):
     """Backend 3 has four plane-kernel geometries (6 = the default, three workgroups per CU) and the "hybrid" forms that split a huge fp32 operand inside the kernel
     (variant 5 uses them at any size: A K-contiguous / row-contiguous, and the swapped-operand form of wide, short-M
-    products incl. its split-K transposing reduction).  Every form, ragged edges, all layouts, same fp64-referenced bound."""
+    products incl. its split-K transposing reduction; 9 the same with one K tile of A in flight instead of two).  Every form, ragged edges, all layouts, same fp64-referenced bound."""
     from star_gcn_amd import _lib as L
     from star_gcn_amd import ops
     cases = [(130, 250, 96), (257, 64, 2570), (1000, 76, 252), (5, 300, 1028), (700, 2576, 256), (200, 130, 40000),
