@@ -621,8 +621,10 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
 // APF: K tiles of A in flight per wave.  1: tile t+1 is loaded while tile t multiplies (16 registers).  2: a second register
 // set -- tile t+2 is requested at the top of iteration t, right after the DMA of B's tile t+1, and the barrier at the end of
 // the iteration waits with a COUNTED vmcnt for everything but those youngest loads: A's HBM latency gets two tile times.
+// (a third set -- 252 VGPRs -- measured no faster than two.)
 template <bool ARC, bool AV4 = false, int APF = 1>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, const PlaneArgs pl) {
+  static_assert(APF == 1 || APF == 2, "one or two K tiles of A in flight");
   constexpr int UPB = 4, RBA = 4, STAGE_B = 32 * UNIT;      // per stage: A units 0..15, B units 16..31
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B + 64];
   int* exp_lds = reinterpret_cast<int*>(smem + 2 * STAGE_B);               // [stage][row block]
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
     const int u = wave * 4 + i;
     const int q = u >> 2, part = u & 3;
     const char* src = b_base + q * rb_stride + static_cast<long long>(kt) * (UPB * UNIT) + part * UNIT;
-    if (APF == 2) {
+    if (APF >= 2) {
       // assembly, so that the compiler keeps no record of a pending LDS write: before the plane stores of the conversion it
       // would otherwise wait with vmcnt(0) -- for this DMA, but also for A's younger loads, which it cannot see
       const unsigned lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_void*)(dst + u * UNIT)));
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
   // APF == 2 (vector forms): the loads are inline assembly -- the compiler's own vmcnt before the conversion would be
   // vmcnt(0) (it does not carry exact counts around the loop), draining the younger loads of tile kt+2 too.  The registers
   // are pinned to the explicit counted wait (`wait_a`) as in/out operands, so no use can move above it.
-  constexpr bool ASM_A = APF == 2 && NA == 4;
+  constexpr bool ASM_A = APF >= 2 && NA == 4;
   f32x4 va0[4], va1[4];
   auto ld4 = [&](f32x4& dst, const float* ptr) __attribute__((always_inline)) {
     if (ASM_A) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
@@ -691,9 +693,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
   };
   auto wait_a = [&](f32x4 (&va)[4], auto n) __attribute__((always_inline)) {      // n: younger vector-memory operations
     constexpr int N = decltype(n)::value;
-    static_assert(N == 0 || N == 8, "add the immediate");
+    static_assert(N == 0 || N == 8 || N == 16, "add the immediate");
     if (!ASM_A) return;
     if (N == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]) : : "memory");
+    else if (N == 16) asm volatile("s_waitcnt vmcnt(16)" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]) : : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]) : : "memory");
   };
   auto load_a = [&](int kt_in, f32x4 (&va)[4]) __attribute__((always_inline)) {
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
     wait_a(va0, std::integral_constant<int, 0>{});
     store_a(0, va0);
   }
-  if (APF == 2 && T > 1) load_a(1, va1);
+  if (APF >= 2 && T > 1) load_a(1, va1);
   __syncthreads();
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // one K tile.  APF == 1: `vnext` receives tile kt+1 now and is converted at the end.  APF == 2: `vnext` already holds
@@ -817,11 +820,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
   auto body = [&](int kt, f32x4 (&vnew)[4], f32x4 (&vnext)[4], auto steady) __attribute__((always_inline)) {
     constexpr bool ST = decltype(steady)::value;
     const bool more = ST || kt + 1 < T;                    // wave-uniform
-    const bool more2 = ST || (APF == 2 && kt + 2 < T);
-    if (APF == 2) {
+    const bool more2 = ST || (APF >= 2 && kt + APF < T);    // tile kt+APF exists: it is requested now
+    if (APF >= 2) {
       if (more) issue_b(kt + 1);                           // program order: B's DMA first, A's loads after it (counted wait)
       asm volatile("" ::: "memory");
-      if (more2) load_a(kt + 2, vnew);
+      if (more2) load_a(kt + APF, vnew);
     } else if (more) {
 #if SG_X3H_ISSUE_POS == 0
       issue_b(kt + 1);                                     // the other stage was released by the barrier just passed
@@ -886,12 +889,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
       }
     }
     if (more) {                             // the loads had the whole multiplication (APF 2: two of them) to land
-      if (APF == 2) {                       // younger than vnext's loads: B's DMA of tile kt+1 (4) and A's loads of tile kt+2 (4)
-        if (ST) wait_a(vnext, std::integral_constant<int, 8>{}); else wait_a(vnext, std::integral_constant<int, 0>{});
+      if (APF >= 2) {                       // younger than vnext's loads: per iteration since, B's DMA (4) and A's loads (4)
+        if (ST) wait_a(vnext, std::integral_constant<int, 8 * (APF - 1)>{}); else wait_a(vnext, std::integral_constant<int, 0>{});
       }
       store_a(kt + 1, vnext);
     }
-    if (APF == 2) {
+    if (APF >= 2) {
       // planes + exponent of tile kt+1 written (lgkmcnt), B's DMA of tile kt+1 landed: everything but the NA youngest
       // vector-memory operations -- the loads of tile kt+2 stay in flight across the barrier
       if (more2) wait_vm<NA>(); else wait_vm<0>();
@@ -966,11 +969,11 @@ __global__ void reduce_t_kernel(float* __restrict__ C, long long ldc, const floa
 }  // namespace f16x3
 
 // the in-kernel-split kernel for A's layout (arc: row-contiguous in m; av4: float4 loads along m) and prefetch depth
-static void launch_hybrid(const GemmArgs& g, const f16x3::PlaneArgs& pl, long long items, bool arc, bool av4, bool deep,
+static void launch_hybrid(const GemmArgs& g, const f16x3::PlaneArgs& pl, long long items, bool arc, bool av4, int deep,
                           hipStream_t st) {
   using namespace f16x3;
   const dim3 grid(static_cast<unsigned>(items)), block(256);
-  if (deep) {
+  if (deep == 2) {
     if (av4) hipLaunchKernelGGL((gemm_f16x3h_kernel<true, true, 2>), grid, block, 0, st, g, pl);
     else if (arc) hipLaunchKernelGGL((gemm_f16x3h_kernel<true, false, 2>), grid, block, 0, st, g, pl);
     else hipLaunchKernelGGL((gemm_f16x3h_kernel<false, false, 2>), grid, block, 0, st, g, pl);
@@ -1044,7 +1047,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     fit_splits(static_cast<long long>(g.tiles_m) * g.tiles_n, 512);
     *splits_used = g.splits;
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
-    launch_hybrid(g, pl, items, transA, transA && g.vecA && g.M % 4 == 0, variant != 9, st);
+    launch_hybrid(g, pl, items, transA, transA && g.vecA && g.M % 4 == 0, variant == 9 ? 1 : 2, st);
     return SG_OK;
   }
   if (variant != 4 && tm128 <= 2 && g.M <= 256 && static_cast<long long>(g.N) * g.K >= big && b_fly_ok && plain_epi) {
@@ -1060,7 +1063,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     PlaneArgs pl{nullptr, pa, nullptr, ea, KS};
     const long long items = static_cast<long long>(h.tiles_m) * h.tiles_n * h.splits;
     // op(B)^T element (n, k): B stored (K x N) when !transB -> row-contiguous in n (ARC); (N x K) when transB -> K-contiguous
-    launch_hybrid(h, pl, items, !transB, !transB && h.vecA && h.M % 4 == 0, variant != 9, st);
+    launch_hybrid(h, pl, items, !transB, !transB && h.vecA && h.M % 4 == 0, variant == 9 ? 1 : 2, st);
     const long long total = static_cast<long long>(g.M) * g.N;
     if (g.splits > 1) {
       hipLaunchKernelGGL(reduce_t_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, g.C, g.ldc, g.ws,
