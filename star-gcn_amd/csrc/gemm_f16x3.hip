@@ -73,6 +73,28 @@ using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// maximum of a NON-NEGATIVE value over the 64 lanes of a wave, returned wave-uniform.  Six DPP steps on the vector ALU
+// (xor 1, xor 2 inside quads, mirrors inside 8 and 16 lanes, then lane 15 / 31 broadcasts into the following rows: lane 63
+// ends up with the maximum) instead of six dependent ds_bpermute round trips through the LDS pipe (~100+ cycles each
+// under load, and each `s_waitcnt lgkmcnt(0)` also waits for every other LDS operation of the wave).  fmaxf drops NaNs,
+// as the shuffle form did.
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  auto step = [&](auto ctrl, auto row_mask) __attribute__((always_inline)) {
+    const int y = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), decltype(ctrl)::value,
+                                              decltype(row_mask)::value, 0xf, false);
+    v = fmaxf(v, __int_as_float(y));
+  };
+  using std::integral_constant;
+  step(integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});     // quad_perm [1,0,3,2]
+  step(integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});     // quad_perm [2,3,0,1]
+  step(integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});    // row_half_mirror
+  step(integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});    // row_mirror: every lane holds its row's maximum
+  step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});    // row_bcast:15 into rows 1 and 3
+  step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});    // row_bcast:31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+
 __device__ __forceinline__ float act_fn(float v, int act, float slope) {
   switch (act) {
     case SG_ACT_LEAKY: return v > 0.f ? v : slope * v;
@@ -142,8 +164,7 @@ __global__ __launch_bounds__(256) void split_kernel(char* __restrict__ planes, i
   }
   // block maximum -> exponent e with max * 2^e in [2^14, 2^15) (fmaxf drops NaNs: a NaN / inf block is not scaled and
   // propagates through the planes)
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  m = wave_max_nonneg(m);
   if ((t & 63) == 0) wmax[t >> 6] = m;
   __syncthreads();
   m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
@@ -757,8 +778,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
         mx = fmaxf(mx, fabsf(x[i]));
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max_nonneg(mx);
     int e = 0;
     {
       const unsigned bits = __float_as_uint(mx);
