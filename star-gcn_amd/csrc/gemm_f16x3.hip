@@ -852,6 +852,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
       load_a(kt + 1, vnext);
     }
     const char* st = smem + (kt & 1) * STAGE_B;
+    // the tile's four block exponents are requested NOW (A's from LDS, written before the last barrier; B's from memory): at
+    // the fold they used to cost a ds_read and an s_load round trip each, back to back, per K tile
+    const int kb = (kt0 + kt) >> 1;
+    const int ea_v0 = exp_lds[(kt & 1) * 4 + wm * 2], ea_v1 = exp_lds[(kt & 1) * 4 + wm * 2 + 1];
+    const int eb_s[2] = {*(volatile cst_int*)(eb_p + kb), *(volatile cst_int*)(eb_p + kbs + kb)};   // volatile: not sunk to the fold
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       f16x8 a[2][2], b[2][2];
@@ -890,14 +895,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
 #pragma unroll
         for (int j = 0; j < 2; ++j) P[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], P[i][j], 0, 0, 0);
     }
-    // fold the K tile at its true scale: A block exponent from LDS (written before the last barrier), B from memory
-    const int kb = (kt0 + kt) >> 1;
+    // fold the K tile at its true scale
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int ea = __builtin_amdgcn_readfirstlane(exp_lds[(kt & 1) * 4 + wm * 2 + i]);
+      const int ea = __builtin_amdgcn_readfirstlane(i == 0 ? ea_v0 : ea_v1);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int ex = ea + eb_p[j * kbs + kb];
+        const int ex = ea + eb_s[j];
         if (ex >= -126 && ex <= 127) {
           const float sc = __uint_as_float(static_cast<unsigned>(127 + ex) << 23);
 #pragma unroll
