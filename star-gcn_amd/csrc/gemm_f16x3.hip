@@ -487,6 +487,10 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
     }
   } else
   for (int kb = 0; kb * TPB < T; ++kb) {
+    // the block's four exponents are requested now (volatile: the compiler would sink the scalar loads to the fold, where
+    // their round trip is exposed)
+    const int ea_s[2] = {*(volatile cst_int*)(ea_p + kb), *(volatile cst_int*)(ea_p + kbs + kb)};
+    const int eb_s[2] = {*(volatile cst_int*)(eb_p + kb), *(volatile cst_int*)(eb_p + kbs + kb)};
 #pragma unroll
     for (int tt = 0; tt < TPB; ++tt) {
       const int kt = kb * TPB + tt;
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int ex = ea_p[i * kbs + kb] + eb_p[j * kbs + kb];
+        const int ex = ea_s[i] + eb_s[j];
         if (ex >= -126 && ex <= 127) {                      // wave-uniform
           const float sc = __uint_as_float(static_cast<unsigned>(127 + ex) << 23);
 #pragma unroll
