@@ -183,9 +183,10 @@ __global__ __launch_bounds__(256) void split_kernel(char* __restrict__ planes, i
   unsigned h1[4], h2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const f32x2 x = {tile[row][kk + 2 * j] * s, tile[row][kk + 2 * j + 1] * s};
+    const float t0 = tile[row][kk + 2 * j], t1 = tile[row][kk + 2 * j + 1];
+    const f32x2 x = {t0 * s, t1 * s};
     const f16x2 a = __builtin_convertvector(x, f16x2);
-    const f32x2 res = x - __builtin_convertvector(a, f32x2);
+    const f32x2 res = {__builtin_fmaf(t0, s, -static_cast<float>(a[0])), __builtin_fmaf(t1, s, -static_cast<float>(a[1]))};   // v_fma_mix_f32
     const f16x2 b = __builtin_convertvector(res, f16x2);
     h1[j] = __builtin_bit_cast(unsigned, a);
     h2[j] = __builtin_bit_cast(unsigned, b);
@@ -801,7 +802,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
     for (int j = 0; j < 8; ++j) {
       const f32x2 v = {x[2 * j] * sc, x[2 * j + 1] * sc};
       const f16x2 a = __builtin_convertvector(v, f16x2);
-      const f32x2 res = v - __builtin_convertvector(a, f32x2);
+      // residual x * sc - h1 in one mixed-precision FMA per element (v_fma_mix_f32 reads the f16 half directly): the same
+      // value as (x * sc) - float(h1) -- both are exact -- without the two conversions back to fp32
+      const f32x2 res = {__builtin_fmaf(x[2 * j], sc, -static_cast<float>(a[0])), __builtin_fmaf(x[2 * j + 1], sc, -static_cast<float>(a[1]))};
       const f16x2 b = __builtin_convertvector(res, f16x2);
       h1[j] = __builtin_bit_cast(unsigned, a);
       h2[j] = __builtin_bit_cast(unsigned, b);
