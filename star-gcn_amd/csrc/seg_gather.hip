@@ -158,6 +158,11 @@ __device__ __forceinline__ long long uniform_ll(long long v) {
 
 // Accumulate edges [ea, eb) (chunk-relative LDS positions) for the channel tile starting at ct; the
 // result (summed over edge groups) is returned in acc on every lane.
+// `c` is the lane's channel offset CLAMPED into the tile by the caller (min(c, c_hi - VEC)): every lane loads, lanes past the
+// row's end (`!chan_ok`) re-read its last vector and their accumulators are never stored.  With the loads under
+// `if (chan_ok)` -- a lane-divergent condition -- every one of the U unrolled row loads sat in its own exec-masked block,
+// and the compiler, unable to count outstanding loads across those blocks, put `s_waitcnt vmcnt(0)` in front of each: the
+// U loads of a wave ran one after the other (ISA of rounds 1-3; U = 2 / 4 / 8 "measured equal" for that reason).
 template <int VEC, bool GROUPED, bool UNI, int DLPR = 0>   // DLPR > 0: DOT mode with DLPR lanes per edge (compile time)
 __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const float* __restrict__ src, const long long* s_off,
                                                  const float* s_w, int ea, int eb, int c, bool chan_ok, int grp,
@@ -182,7 +187,7 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
         off = uniform_ll(off);
         wv[u] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wv[u])));
       }
-      if (chan_ok) ld_row<VEC>(x[u], src + off + c);
+      ld_row<VEC>(x[u], src + off + c);      // unconditional (c is clamped by the caller): see the note above the function
     }
     if (DOT) {   // the row is in registers: its inner product with the segment's vector gives the weight
 #pragma unroll
@@ -199,12 +204,10 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
         wv[u] = dscale * r;
       }
     }
-    if (chan_ok) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = fmaf(wv[u], x[u][v], acc[v]);
-    }
+      for (int v = 0; v < VEC; ++v) acc[v] = fmaf(wv[u], x[u][v], acc[v]);
   }
   for (; e < eb; e += epg) {
     long long off = s_off[e];
@@ -214,23 +217,21 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
       wv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wv)));
     }
     float x[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) x[v] = 0.f;
-    if (chan_ok) ld_row<VEC>(x, src + off + c);
+    ld_row<VEC>(x, src + off + c);
     if (DOT) {
       float d = 0.f;
+      if (chan_ok) {
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) d = fmaf(x[v], dvec[v], d);
+        for (int v = 0; v < VEC; ++v) d = fmaf(x[v], dvec[v], d);
+      }
 #pragma unroll
       for (int o = 1; o < DLPR; o <<= 1) d += __shfl_xor(d, o);
       const float r = d - wv;
       *lacc += r * r;
       wv = dscale * r;
     }
-    if (chan_ok) {
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[v] = fmaf(wv, x[v], acc[v]);
-    }
+    for (int v = 0; v < VEC; ++v) acc[v] = fmaf(wv, x[v], acc[v]);
   }
   if (!UNI) {
     if (DOT) {
@@ -326,13 +327,14 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
     for (int ct = c_lo; ct < c_hi; ct += ctile) {
       const int c = ct + slot * VEC;
       const bool chan_ok = c < c_hi;
+      const int cl = min(c, c_hi - VEC);      // clamped: the loads of accumulate_piece are unconditional
       float acc[VEC];
       if (DOT) {
         float dv[VEC];
         load_dvec(dv, s_lo - 1, c, chan_ok);       // the segment that holds edge cb
-        accumulate_piece<VEC, GROUPED, UNI, DLPR>(a, src, s_off, s_w, 0, hb - cb, c, chan_ok, grp, epg, acc, dv, dscale, &lacc);
+        accumulate_piece<VEC, GROUPED, UNI, DLPR>(a, src, s_off, s_w, 0, hb - cb, cl, chan_ok, grp, epg, acc, dv, dscale, &lacc);
       } else {
-        accumulate_piece<VEC, GROUPED, UNI>(a, src, s_off, s_w, 0, hb - cb, c, chan_ok, grp, epg, acc);
+        accumulate_piece<VEC, GROUPED, UNI>(a, src, s_off, s_w, 0, hb - cb, cl, chan_ok, grp, epg, acc);
       }
       if (grp == 0 && chan_ok) st_vec<VEC>(a.ws_head + wsrow + c, acc);
     }
@@ -365,14 +367,15 @@ __global__ __launch_bounds__(kWave) void seg_gather_kernel(const GatherArgs a) {
       for (int ct = c_lo; ct < c_hi; ct += ctile) {
         const int c = ct + slot * VEC;
         const bool chan_ok = c < c_hi;
+        const int cl = min(c, c_hi - VEC);    // clamped: the loads of accumulate_piece are unconditional
         float acc[VEC];
         if (DOT) {
           float dv[VEC];
           load_dvec(dv, s, c, chan_ok);
-          accumulate_piece<VEC, GROUPED, UNI, DLPR>(a, src, s_off, s_w, pb - cb, eb - cb, c, chan_ok, grp, epg, acc, dv, dscale,
+          accumulate_piece<VEC, GROUPED, UNI, DLPR>(a, src, s_off, s_w, pb - cb, eb - cb, cl, chan_ok, grp, epg, acc, dv, dscale,
                                                     &lacc);
         } else {
-          accumulate_piece<VEC, GROUPED, UNI>(a, src, s_off, s_w, pb - cb, eb - cb, c, chan_ok, grp, epg, acc);
+          accumulate_piece<VEC, GROUPED, UNI>(a, src, s_off, s_w, pb - cb, eb - cb, cl, chan_ok, grp, epg, acc);
         }
         if (grp == 0 && chan_ok) {
           if (whole) {
