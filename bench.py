@@ -313,21 +313,27 @@ def dense_roofline(step, steps=3):
 
 
 def gather_roofline(timeline, E_local, D, steps):
-    """average HIP-event time of the aggregation launches (width D over all local edges) -> algorithmic rate"""
-    agg = [(t, sb) for t, nnz, C, sb in timeline if C == D and nnz == max(E_local, 1) and t > 0]
-    if not agg:
+    """HIP-event times of the aggregation launches (width D) -> algorithmic rate.  An aggregation over all local edges is
+    ONE launch, or TWO source-range phases of one launch each whose edge counts add up to E_local; a launch's
+    algorithmic bytes are (8 + 4 D) x ITS edges (idx + support + one fp32 row per edge visit)."""
+    E = max(E_local, 1)
+    agg = [(t, nnz, sb) for t, nnz, C, sb in timeline if C == D and E // 64 <= nnz <= E and t > 0]
+    edges = sum(n for _, n, _ in agg)
+    if not agg or edges % E != 0:                     # something else of width D ran: do not guess
         return None
-    avg = sum(t for t, _ in agg) / len(agg)
-    bytes_per_launch = (8 + 4 * D) * E_local          # SURVEY 8(d): idx + support + one fp32 row per edge visit
-    classes = dict()                                  # launches by footprint of the gathered matrix
-    for t, sb in agg:
-        c = classes.setdefault(sb, [0, 0.0])
+    total_t = sum(t for t, _, _ in agg)
+    classes = dict()                                  # launches by (footprint of the gathered matrix, phased or not)
+    for t, n, sb in agg:
+        c = classes.setdefault((sb, n < E), [0, 0.0, 0])
         c[0] += 1
         c[1] += t
-    return {"kernel": "seg_gather_kernel", "achieved": bytes_per_launch / avg / 1e9, "unit": "GB/s",
-            "launches_per_step": len(agg) / steps, "avg_launch_ms": avg * 1e3,
-            "algorithmic_bytes_per_launch": bytes_per_launch,
-            "_classes": {sb: (n, tt / n) for sb, (n, tt) in classes.items()}}
+        c[2] += n
+    return {"kernel": "seg_gather_kernel", "achieved": (8 + 4 * D) * edges / total_t / 1e9, "unit": "GB/s",
+            "launches_per_step": len(agg) / steps, "aggregations_per_step": edges / E / steps,
+            "avg_launch_ms": total_t / len(agg) * 1e3, "avg_aggregation_ms": total_t / (edges / E) * 1e3,
+            "algorithmic_bytes_per_launch": (8 + 4 * D) * edges / len(agg),
+            "algorithmic_bytes_per_aggregation": (8 + 4 * D) * E,
+            "_classes": {k: (n, tt / n, ne / n) for k, (n, tt, ne) in classes.items()}}
 
 
 def measure_stream_ceiling(dev, n_bytes, workgroups, bursts=256):
@@ -708,7 +714,14 @@ def run_rank(args):
         roof["gathered_matrices_mb"] = src_mb
         rec = profile_record("%s:%d" % (args.shape, D)) if world == 1 else None
         live = rec and not rec.get("stale")
-        roof["traffic"] = rec["traffic_bytes_per_launch_mean"] * (E_local / rec["edges_per_launch"]) if live else None
+        # the record describes launches of a given structure (single launches or source-range phases): it only applies
+        # when this run issued the same number of launches per aggregation
+        same = live and abs(rec.get("launches_per_aggregation", 1) - roof["launches_per_step"] / roof["aggregations_per_step"]) < 1e-9
+        roof["traffic"] = (rec["traffic_bytes_per_launch_mean"] * (roof["algorithmic_bytes_per_launch"] / (8 + 4 * D)) /
+                           rec["edges_per_launch"]) if same else None
+        if live and not same:
+            roof["traffic_note"] = "PMC record is for %s launch(es) per aggregation; this run issued %.3g" % (
+                rec.get("launches_per_aggregation", 1), roof["launches_per_step"] / roof["aggregations_per_step"])
         roof["traffic_source"] = rec.get("source") if rec else None
         if cache_resident and not args.no_ceiling and world == 1:
             # ceiling of every launch class = the same bytes at the rate of a best-case streaming read, measured NOW, of
@@ -716,14 +729,19 @@ def run_rank(args):
             n_wg = (E_local + 255) // 256
             t_ceiling = t_actual = 0.0
             per_class = []
-            for sb, (n, t_avg) in sorted(roof["_classes"].items()):
-                rate = measure_stream_ceiling(dev, max(1 << 20, (sb >> 20) << 20), n_wg)
-                t_c = roof["algorithmic_bytes_per_launch"] / (rate * 1e9)
+            for (sb, phased), (n, t_avg, e_avg) in sorted(roof["_classes"].items()):
+                # a source-range phase addresses HALF of the gathered matrix: its ceiling is the streaming rate over a
+                # resident buffer of that half, with that launch's own grid
+                touched = sb // 2 if phased else sb
+                rate = measure_stream_ceiling(dev, max(1 << 20, (touched >> 20) << 20), (int(e_avg) + 255) // 256)
+                b_launch = (8 + 4 * D) * e_avg
+                t_c = b_launch / (rate * 1e9)
                 t_ceiling += n * t_c
                 t_actual += n * t_avg
-                per_class.append({"gathered_matrix_mb": sb >> 20, "launches_per_step": n / args.steps,
-                                  "avg_launch_ms": t_avg * 1e3, "achieved_gbs": roof["algorithmic_bytes_per_launch"] / t_avg / 1e9,
-                                  "stream_ceiling_gbs": rate, "frac": t_c / t_avg})
+                per_class.append({"gathered_matrix_mb": sb >> 20, "source_range_phase": bool(phased),
+                                  "addressed_mb": touched >> 20, "launches_per_step": n / args.steps,
+                                  "edges_per_launch": e_avg, "avg_launch_ms": t_avg * 1e3,
+                                  "achieved_gbs": b_launch / t_avg / 1e9, "stream_ceiling_gbs": rate, "frac": t_c / t_avg})
             roof.update(bound="infinity_cache+l2", peak=roof["achieved"] * t_actual / t_ceiling,
                         frac=t_ceiling / t_actual, per_class=per_class,
                         ceiling_method="sg_stream_read_hip in this run: one wave per workgroup, the gather's grid, 256 "

@@ -310,6 +310,36 @@ int sg_take_plan_cpu(int32_t* t_indptr, int32_t* t_pos, int32_t* inv_ids, int32_
 #define SG_ACCUM_SUM 0
 #define SG_ACCUM_STACK 1
 #define SG_MAX_LINKS 32
+/* Source-range phases of one gather view of the plan (optional).  A gather over a source matrix a few times
+ * the aggregate L2 is issued as num_phases = 2 launches, the second accumulating: phase 0 holds the view's edges whose
+ * source row lies in the first half of the rows, phase 1 the rest, each a CSR over the same segments.  Built by
+ * sg_gather_phases_build_hip; used by sg_multilink_agg_{fwd,bwd}_hip when present and the launch's source footprint is
+ * cache-resident (24 MB .. 256 MB).  The sum of a segment is then (low rows) + (high rows): deterministic, and equal to the
+ * single-launch value up to fp32 association. */
+typedef struct sg_gather_phases {
+  int32_t num_phases;                   /* 0: not phased; 2: phased */
+  int32_t reserved;
+  const int32_t* idx;                   /* (nnz) the view's source indices, phase 0's edges first */
+  const int32_t* wpos;                  /* (nnz) position of each of those edges in the view's weight array (c_w / t_w) */
+  const int32_t* indptr;                /* (2, segments + 1) CSR pointers of either phase, relative to its first edge */
+  int64_t nnz_p[2];                     /* edges of either phase */
+} sg_gather_phases;
+#define SG_VIEW_C_Q_D 0                 /* (c_q, d_indptr)   transform-first forward, 'sum'   */
+#define SG_VIEW_C_Q_C 1                 /* (c_q, c_indptr)   transform-first forward, 'stack' */
+#define SG_VIEW_C_IDX_C 2               /* (c_idx, c_indptr) aggregate-first forward          */
+#define SG_VIEW_T_IDX_T 3               /* (t_idx, t_indptr) transform-first backward, 'sum'  */
+#define SG_VIEW_T_Q_T 4                 /* (t_q, t_indptr)   transform-first backward, 'stack' */
+#define SG_VIEW_T_Q_S 5                 /* (t_q, s_indptr)   aggregate-first backward         */
+#define SG_NUM_VIEWS 6
+size_t sg_gather_phases_workspace_bytes(int64_t nnz);
+int sg_gather_phases_build_hip(int32_t* idx_p, int32_t* wpos_p, int32_t* indptr_p, int32_t* nnz_p, const int32_t* indices,
+                               const int32_t* indptr, int64_t seg_num, int64_t nnz, int64_t n_rows, void* workspace,
+                               size_t workspace_bytes, void* stream);
+/* dst (+)= act(sum) as sg_seg_gather_sum_hinted_hip, issued phase by phase (weights are read through ph->wpos) */
+int sg_seg_gather_sum_phased_hip(float* dst, int64_t dst_group, int64_t dst_ld, const float* src, int64_t src_group,
+                                 int64_t src_ld, const float* weights, const sg_gather_phases* ph, int64_t seg_num,
+                                 int64_t feat_dim, int req, int act, float slope, void* workspace, size_t workspace_bytes,
+                                 void* stream, int64_t src_bytes);
 typedef struct sg_multilink_plan {      /* all pointers are DEVICE pointers; see sg_multilink_fuse_cpu */
   const int32_t* c_indptr;              /* n_dst*R+1 */
   const int32_t* c_idx;                 /* nnz: source node */
@@ -324,6 +354,8 @@ typedef struct sg_multilink_plan {      /* all pointers are DEVICE pointers; see
   const float* rowsum;                  /* (n_dst, R) support sums per (node, level); needed by aggregate-first */
   int64_t n_dst, n_src, nnz;
   int32_t num_links;
+  int32_t reserved;
+  sg_gather_phases phases[SG_NUM_VIEWS]; /* optional (zero = absent): source-range phases of the views, by SG_VIEW_* */
 } sg_multilink_plan;
 int sg_multilink_agg_resolve_order(const sg_multilink_plan* plan, int order);
 size_t sg_multilink_agg_saved_bytes(const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level,

@@ -118,6 +118,10 @@ _SIGS = {
     "sg_bounds_from_sorted_hip": (_INT, [_P, _P, _I64, _I64, _P]),
     "sg_gather_i32_hip": (_INT, [_P, _P, _P, _I64, _P]),
     "sg_inverse_index_hip": (_INT, [_P, _P, _I64, _I64, _P]),
+    "sg_gather_phases_workspace_bytes": (_SZ, [_I64]),
+    "sg_gather_phases_build_hip": (_INT, [_P] * 6 + [_I64] * 3 + [_P, _SZ, _P]),
+    "sg_seg_gather_sum_phased_hip": (_INT, [_P, _I64, _I64, _P, _I64, _I64, _P, _P, _I64, _I64, _INT, _INT, _F32, _P, _SZ,
+                                            _P, _I64]),
     "sg_unique_inverse_workspace_bytes": (_SZ, [_I64, _I64]),
     "sg_unique_inverse_hip": (_INT, [_P] * 6 + [_I64, _I64, _P, _SZ, _P]),
     "sg_sample_fix_neighbor_workspace_bytes": (_SZ, [_I64]),
@@ -130,11 +134,22 @@ _SIGS = {
 }
 
 
+NUM_VIEWS = 6      # SG_VIEW_* of include/stargcn.h
+VIEW_C_Q_D, VIEW_C_Q_C, VIEW_C_IDX_C, VIEW_T_IDX_T, VIEW_T_Q_T, VIEW_T_Q_S = range(NUM_VIEWS)
+
+
+class GatherPhasesStruct(_c.Structure):
+    """`sg_gather_phases` of include/stargcn.h."""
+    _fields_ = [("num_phases", _c.c_int32), ("reserved", _c.c_int32), ("idx", _P), ("wpos", _P), ("indptr", _P),
+                ("nnz_p", _I64 * 2)]
+
+
 class MultiLinkPlanStruct(_c.Structure):
     """`sg_multilink_plan` of include/stargcn.h (device pointers of a resident MultiLinkPlan)."""
     _fields_ = [(n, _P) for n in ("c_indptr", "c_idx", "c_q", "c_w", "t_indptr", "t_idx", "t_q", "t_w", "d_indptr",
                                   "s_indptr", "rowsum")] + \
-               [("n_dst", _I64), ("n_src", _I64), ("nnz", _I64), ("num_links", _c.c_int32)]
+               [("n_dst", _I64), ("n_src", _I64), ("nnz", _I64), ("num_links", _c.c_int32), ("reserved", _c.c_int32),
+                ("phases", GatherPhasesStruct * NUM_VIEWS)]
 
 _lib = None
 

@@ -197,6 +197,21 @@ int zero_param_grads(const MutPtrTable& dw, const MutPtrTable& db, const Dims& d
   return SG_OK;
 }
 
+// one gather of the plan: as source-range phases when the plan carries them for this view and the source matrix is
+// cache-resident but larger than the L2s; SG_GATHER_PHASES=0 keeps the single launch
+int gather_view(const sg_multilink_plan* plan, int view, float* dst, int64_t dst_group, int64_t dst_ld, const float* src,
+                int64_t src_group, int64_t src_ld, const float* w, const int32_t* idx, const int32_t* indptr,
+                int64_t seg_num, int64_t nnz, int64_t C, int act, float slope, void* scratch, size_t scratch_bytes,
+                void* stream, int64_t src_bytes) {
+  static const int phases_on = [] { const char* e = getenv("SG_GATHER_PHASES"); return e ? atoi(e) : 1; }();
+  const sg_gather_phases* ph = &plan->phases[view];
+  if (phases_on && ph->num_phases == 2 && ph->idx && C >= 64 && src_bytes >= (24ll << 20) && src_bytes <= (256ll << 20))
+    return sg_seg_gather_sum_phased_hip(dst, dst_group, dst_ld, src, src_group, src_ld, w, ph, seg_num, C, SG_REQ_WRITE,
+                                        act, slope, scratch, scratch_bytes, stream, src_bytes);
+  return sg_seg_gather_sum_hinted_hip(dst, dst_group, dst_ld, src, src_group, src_ld, w, idx, indptr, seg_num, nnz, C,
+                                      SG_REQ_WRITE, act, slope, scratch, scratch_bytes, stream, src_bytes);
+}
+
 #define SG_TRY(expr)          \
   do {                        \
     int rc_ = (expr);         \
@@ -256,12 +271,10 @@ SG_API int sg_multilink_agg_fwd_hip(float* out, void* saved, const float* x, con
       SG_TRY(sg_gemm_f32_hip(h, d.RU, x, d.D, 0, wcat, d.D, 1, d.n_src, d.RU, d.D, bcat, SG_ACT_NONE, 0.f, 0, scratch,
                              L.scratch_bytes, stream));
     if (!d.stack)
-      return sg_seg_gather_sum_hinted_hip(out, 1, d.U, h, d.R, d.RU, plan->c_w, plan->c_q, plan->d_indptr, d.n_dst, d.nnz,
-                                          d.U, SG_REQ_WRITE, act, slope, scratch, L.scratch_bytes, stream,
-                                          d.n_src * d.RU * 4);
-    return sg_seg_gather_sum_hinted_hip(out, d.R, d.RU, h, d.R, d.RU, plan->c_w, plan->c_q, plan->c_indptr, d.n_dst * d.R,
-                                        d.nnz, d.U, SG_REQ_WRITE, act, slope, scratch, L.scratch_bytes, stream,
-                                        d.n_src * d.RU * 4);
+      return gather_view(plan, SG_VIEW_C_Q_D, out, 1, d.U, h, d.R, d.RU, plan->c_w, plan->c_q, plan->d_indptr, d.n_dst, d.nnz,
+                         d.U, act, slope, scratch, L.scratch_bytes, stream, d.n_src * d.RU * 4);
+    return gather_view(plan, SG_VIEW_C_Q_C, out, d.R, d.RU, h, d.R, d.RU, plan->c_w, plan->c_q, plan->c_indptr, d.n_dst * d.R,
+                       d.nnz, d.U, act, slope, scratch, L.scratch_bytes, stream, d.n_src * d.RU * 4);
   }
 
   if (!saved) return fail(SG_ERR_INVALID, "aggregate-first needs the `saved` buffer (sg_multilink_agg_saved_bytes)");
@@ -271,9 +284,8 @@ SG_API int sg_multilink_agg_fwd_hip(float* out, void* saved, const float* x, con
   hipLaunchKernelGGL(pack_ext_kernel, dim3(blocks_for(d.outw * d.ld)), dim3(256), 0, st, wext, w, b, d.R,
                      static_cast<int>(d.U), static_cast<int>(d.D), static_cast<int>(d.ld), d.stack);
   SG_TRY(check_launch("pack_ext_kernel"));
-  SG_TRY(sg_seg_gather_sum_hinted_hip(zext, d.R, d.ld, x, 1, d.D, plan->c_w, plan->c_idx, plan->c_indptr, d.n_dst * d.R,
-                                      d.nnz, d.D, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream,
-                                      d.n_src * d.D * 4));
+  SG_TRY(gather_view(plan, SG_VIEW_C_IDX_C, zext, d.R, d.ld, x, 1, d.D, plan->c_w, plan->c_idx, plan->c_indptr, d.n_dst * d.R,
+                     d.nnz, d.D, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream, d.n_src * d.D * 4));
   hipLaunchKernelGGL(fill_rowsum_kernel, dim3(blocks_for(d.n_dst * (d.ld - d.R * d.D))), dim3(256), 0, st, zext,
                      plan->rowsum, static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.D), static_cast<int>(d.ld));
   SG_TRY(check_launch("fill_rowsum_kernel"));
@@ -326,13 +338,13 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
     }
     // dH[(n, r), :] = sum over the transposed plan of t_w * dpre[dest (, level r block)]
     if (!d.stack)
-      SG_TRY(sg_seg_gather_sum_hinted_hip(dh, d.R, d.RU, dpre, 1, d.U, plan->t_w, plan->t_idx, plan->t_indptr,
-                                          d.n_src * d.R, d.nnz, d.U, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch,
-                                          L.scratch_bytes, stream, d.n_dst * d.outw * 4));
+      SG_TRY(gather_view(plan, SG_VIEW_T_IDX_T, dh, d.R, d.RU, dpre, 1, d.U, plan->t_w, plan->t_idx, plan->t_indptr,
+                         d.n_src * d.R, d.nnz, d.U, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream,
+                         d.n_dst * d.outw * 4));
     else
-      SG_TRY(sg_seg_gather_sum_hinted_hip(dh, d.R, d.RU, dpre, d.R, d.RU, plan->t_w, plan->t_q, plan->t_indptr,
-                                          d.n_src * d.R, d.nnz, d.U, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch,
-                                          L.scratch_bytes, stream, d.n_dst * d.outw * 4));
+      SG_TRY(gather_view(plan, SG_VIEW_T_Q_T, dh, d.R, d.RU, dpre, d.R, d.RU, plan->t_w, plan->t_q, plan->t_indptr,
+                         d.n_src * d.R, d.nnz, d.U, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream,
+                         d.n_dst * d.outw * 4));
     if (dx) {
       hipLaunchKernelGGL(pack_cat_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, wcat,
                          static_cast<float*>(nullptr), w, nob, d.R, static_cast<int>(d.U), static_cast<int>(d.D));
@@ -369,9 +381,8 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
     if (d.n_dst > 0)
       SG_TRY(sg_gemm_f32_hip(dz, d.ld, dpre, d.outw, 0, wext, d.ld, 0, d.n_dst, d.ld, d.outw, nullptr, SG_ACT_NONE, 0.f,
                              0, scratch, L.scratch_bytes, stream));
-    SG_TRY(sg_seg_gather_sum_hinted_hip(dx, 1, d.D, dz, d.R, d.ld, plan->t_w, plan->t_q, plan->s_indptr, d.n_src, d.nnz,
-                                        d.D, SG_REQ_WRITE, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream,
-                                        d.n_dst * d.ld * 4));
+    SG_TRY(gather_view(plan, SG_VIEW_T_Q_S, dx, 1, d.D, dz, d.R, d.ld, plan->t_w, plan->t_q, plan->s_indptr, d.n_src, d.nnz,
+                       d.D, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream, d.n_dst * d.ld * 4));
   }
   if ((want_w || want_b) && d.n_dst == 0) return zero_param_grads(dw, db, d, st);
   if (want_w || want_b) {

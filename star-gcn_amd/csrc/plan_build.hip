@@ -1098,3 +1098,71 @@ SG_API int sg_sample_fix_neighbor_hip(int32_t* sampled, int32_t* dst_ind_ptr, co
                        sel_indices, static_cast<long long>(sel_num), seed);
   return check_launch("sg_sample_fix_neighbor_hip");
 }
+
+// ---- source-range phases of a gather view --------------------------------------------------------------
+// A gather whose source matrix is a few times the aggregate L2 runs faster as TWO launches that each touch one half of the
+// source rows (the second accumulates): per XCD and column slice the working set halves and the L2 hit rate rises
+// (10 M edges over 68 MB of user rows: 1.02 -> 0.80 ms, over 104 MB of grouped rows 0.83 -> 0.69 ms).  The plan of such a
+// pair is a STABLE partition of the view's edges by phase(idx) = idx >= split: inside a phase the edges keep their
+// segment-major order, so each phase is a CSR over the same segments.
+namespace sg {
+namespace {
+__global__ void phase_flag_kernel(int32_t* __restrict__ flag, const int32_t* __restrict__ idx, long long n, int32_t split) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j < n) flag[j] = idx[j] < split ? 1 : 0;
+}
+// before[j] = edges of phase 0 among the first j (n + 1 entries).  Edge j goes to before[j] (phase 0) or
+// before[n] + j - before[j] (phase 1); wpos = its position in the view's weight array
+__global__ void phase_scatter_kernel(int32_t* __restrict__ idx_p, int32_t* __restrict__ wpos_p, const int32_t* __restrict__ idx,
+                                     const int32_t* __restrict__ before, long long n, int32_t split) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int32_t q = idx[j], b = before[j];
+  const long long pos = q < split ? b : static_cast<long long>(before[n]) + (j - b);
+  idx_p[pos] = q;
+  wpos_p[pos] = static_cast<int32_t>(j);
+}
+__global__ void phase_indptr_kernel(int32_t* __restrict__ indptr_p, int32_t* __restrict__ nnz_p,
+                                    const int32_t* __restrict__ indptr, const int32_t* __restrict__ before, long long seg_num,
+                                    long long n) {
+  const long long s = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s <= seg_num) {
+    const int32_t p = indptr[s], b = before[p];
+    indptr_p[s] = b;
+    indptr_p[seg_num + 1 + s] = p - b;
+  }
+  if (s == 0) { nnz_p[0] = before[n]; nnz_p[1] = static_cast<int32_t>(n - before[n]); }
+}
+}  // namespace
+}  // namespace sg
+
+SG_API size_t sg_gather_phases_workspace_bytes(int64_t nnz) {
+  return nnz < 0 ? 0 : sg::al256((static_cast<size_t>(nnz) + 1) * sizeof(int32_t)) + sg::scan_ws_bytes(nnz + 1) + 256;
+}
+// two source-range phases of the view (indices, indptr) whose indices address n_rows source rows: phase 0 = rows
+// [0, ceil(n_rows / 2)), phase 1 = the rest.  idx_p / wpos_p: (nnz) each, phase 0's edges first; indptr_p: (2, seg_num + 1);
+// nnz_p: (2) on the device -- the caller reads it back once at plan time.
+SG_API int sg_gather_phases_build_hip(int32_t* idx_p, int32_t* wpos_p, int32_t* indptr_p, int32_t* nnz_p,
+                                      const int32_t* indices, const int32_t* indptr, int64_t seg_num, int64_t nnz,
+                                      int64_t n_rows, void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace sg;
+  if (seg_num < 0 || nnz < 0 || n_rows < 0 || nnz >= (1ll << 31) - 1 || seg_num >= (1ll << 31) - 1 || n_rows >= (1ll << 31))
+    return fail(SG_ERR_INVALID, "bad dimension");
+  if (!indptr_p || !nnz_p || !indptr || (nnz > 0 && (!idx_p || !wpos_p || !indices))) return fail(SG_ERR_INVALID, "null argument");
+  if (!workspace || workspace_bytes < sg_gather_phases_workspace_bytes(nnz)) return fail(SG_ERR_WORKSPACE, "gather phases workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  int32_t* before = reinterpret_cast<int32_t*>(base);
+  void* scan_ws = base + al256((static_cast<size_t>(nnz) + 1) * sizeof(int32_t));
+  const int32_t split = static_cast<int32_t>((n_rows + 1) / 2);
+  if (nnz > 0)
+    hipLaunchKernelGGL(phase_flag_kernel, dim3(blocks(nnz)), dim3(256), 0, st, before, indices, static_cast<long long>(nnz), split);
+  int rc = exclusive_scan(before, before, nnz, true, scan_ws, st);
+  if (rc != SG_OK) return rc;
+  if (nnz > 0)
+    hipLaunchKernelGGL(phase_scatter_kernel, dim3(blocks(nnz)), dim3(256), 0, st, idx_p, wpos_p, indices, before,
+                       static_cast<long long>(nnz), split);
+  hipLaunchKernelGGL(phase_indptr_kernel, dim3(blocks(seg_num + 1)), dim3(256), 0, st, indptr_p, nnz_p, indptr, before,
+                     static_cast<long long>(seg_num), static_cast<long long>(nnz));
+  return check_launch("sg_gather_phases_build_hip");
+}

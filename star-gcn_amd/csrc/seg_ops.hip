@@ -650,3 +650,25 @@ SG_API int sg_seg_pool_bwd_hip(float* ddata, const float* ograd, const int32_t* 
                        nullptr, t_seg, t_indptr, batch, total_ind_num, nnz, feat_dim, req, 0, SG_ACT_NONE, 0.f, workspace, gbytes,
                        st, batch * seg_num * feat_dim * static_cast<int64_t>(sizeof(float)));
 }
+
+// ---- a gather issued as source-range phases (include/stargcn.h: sg_gather_phases; built by sg_gather_phases_build_hip) ----
+SG_API int sg_seg_gather_sum_phased_hip(float* dst, int64_t dst_group, int64_t dst_ld, const float* src, int64_t src_group,
+                                        int64_t src_ld, const float* weights, const sg_gather_phases* ph, int64_t seg_num,
+                                        int64_t feat_dim, int req, int act, float slope, void* workspace,
+                                        size_t workspace_bytes, void* stream, int64_t src_bytes) {
+  if (!ph || ph->num_phases != 2 || !ph->indptr) return sg::fail(SG_ERR_INVALID, "gather phases missing");
+  if (req != SG_REQ_NULL && req != SG_REQ_WRITE && req != SG_REQ_ADD) return sg::fail(SG_ERR_INVALID, "req must be 0, 1 or 3, got %d", req);
+  if (req == SG_REQ_NULL) return SG_OK;
+  int64_t off = 0;
+  for (int p = 0; p < 2; ++p) {
+    // every launch visits every segment once: phase 0 writes (or adds to) the destination, phase 1 adds and applies the
+    // activation to the finished sum
+    const int rc = sg::launch_gather(dst, dst_group, dst_ld, 0, src, src_group, src_ld, 0, weights, 0, ph->wpos + off,
+                                     ph->idx + off, ph->indptr + p * (seg_num + 1), 1, seg_num, ph->nnz_p[p], feat_dim,
+                                     p == 0 ? req : SG_REQ_ADD, 0, p == 1 ? act : SG_ACT_NONE, slope, workspace,
+                                     workspace_bytes, static_cast<hipStream_t>(stream), src_bytes);
+    if (rc != SG_OK) return rc;
+    off += ph->nnz_p[p];
+  }
+  return SG_OK;
+}

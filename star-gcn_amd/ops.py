@@ -318,6 +318,17 @@ def multilink_resolve_order(plan, order):
     return ("auto", "transform_first", "aggregate_first")[rc]
 
 
+def _gather_view(plan, order, accum, backward):
+    """SG_VIEW_* of the gather that sg_multilink_agg_{fwd,bwd}_hip issues for this order / accumulation."""
+    if order == "auto":
+        order = multilink_resolve_order(plan, order)
+    if order == "transform_first":
+        if backward:
+            return L.VIEW_T_Q_T if accum == "stack" else L.VIEW_T_IDX_T
+        return L.VIEW_C_Q_C if accum == "stack" else L.VIEW_C_Q_D
+    return L.VIEW_T_Q_S if backward else L.VIEW_C_IDX_C
+
+
 def _byref(struct):
     import ctypes
     return ctypes.cast(ctypes.pointer(struct), ctypes.c_void_p)
@@ -330,6 +341,7 @@ def multilink_agg_fwd(x, weights, biases, plan, accum, act, slope, order):
     lib = L.lib()
     D, upl = x.shape[1], weights[0].shape[0]
     o, a = _ORDER[order], _ACCUM[accum]
+    plan.ensure_phases(_gather_view(plan, order, accum, backward=False))
     st = plan.c_struct(order != "transform_first")
     outw = upl * (plan.R if accum == "stack" else 1)
     out = torch.empty((plan.n_dst, outw), dtype=torch.float32, device=x.device)
@@ -349,6 +361,7 @@ def multilink_agg_bwd(dout, out, saved, x, weights, plan, accum, act, slope, ord
     lib = L.lib()
     D, upl = x.shape[1], weights[0].shape[0]
     o, a = _ORDER[order], _ACCUM[accum]
+    plan.ensure_phases(_gather_view(plan, order, accum, backward=True))
     st = plan.c_struct(order != "transform_first")
     dx = torch.empty((plan.n_src, D), dtype=torch.float32, device=x.device) if need_dx else None
     dws = [torch.empty_like(w) for w in weights] if need_dw else None

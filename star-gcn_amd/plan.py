@@ -203,8 +203,58 @@ class MultiLinkPlan(object):
                 setattr(st, name, getattr(self, name).data_ptr())
             st.rowsum = self.rowsum.data_ptr() if need_rowsum else None
             st.n_dst, st.n_src, st.nnz, st.num_links = self.n_dst, self.n_src, self.nnz, self.R
+            for view, ph in getattr(self, "_phases", {}).items():
+                if ph is None:
+                    continue
+                idx_p, wpos_p, indptr_p, n0, n1 = ph
+                e = st.phases[view]
+                e.num_phases, e.idx, e.wpos, e.indptr = 2, idx_p.data_ptr(), wpos_p.data_ptr(), indptr_p.data_ptr()
+                e.nnz_p[0], e.nnz_p[1] = n0, n1
             self._struct = st
         return self._struct
+
+    # (index array, CSR pointers, segments, source rows) of the six gather views, by SG_VIEW_* (include/stargcn.h)
+    _VIEWS = {
+        L.VIEW_C_Q_D: ("c_q", "d_indptr", lambda p: p.n_dst, lambda p: p.n_src * p.R),
+        L.VIEW_C_Q_C: ("c_q", "c_indptr", lambda p: p.n_dst * p.R, lambda p: p.n_src * p.R),
+        L.VIEW_C_IDX_C: ("c_idx", "c_indptr", lambda p: p.n_dst * p.R, lambda p: p.n_src),
+        L.VIEW_T_IDX_T: ("t_idx", "t_indptr", lambda p: p.n_src * p.R, lambda p: p.n_dst),
+        L.VIEW_T_Q_T: ("t_q", "t_indptr", lambda p: p.n_src * p.R, lambda p: p.n_dst * p.R),
+        L.VIEW_T_Q_S: ("t_q", "s_indptr", lambda p: p.n_src, lambda p: p.n_dst * p.R),
+    }
+    PHASE_MIN_EDGES = 1 << 20          # below this a launch is too short for two
+    PHASE_MAX_ROWS = 1 << 20           # source matrices beyond the Infinity Cache (>= 256 B per row) gain nothing
+
+    def ensure_phases(self, view):
+        """Source-range phases of one gather view (sg_gather_phases_build_hip), built on the device at first use and kept
+        with the plan: the library then issues that view's gather as two launches over one half of the source rows each
+        when the source matrix is cache-resident but larger than the L2s.  A no-op for small plans, for
+        sources that cannot be cache-resident, and while a hipGraph is being captured (building allocates and reads two
+        counters back)."""
+        ph = self.__dict__.setdefault("_phases", {})
+        if view in ph:
+            return
+        idx_name, ip_name, segs, rows = self._VIEWS[view]
+        n_seg, n_rows = int(segs(self)), int(rows(self))
+        if (self.nnz < self.PHASE_MIN_EDGES or n_rows > self.PHASE_MAX_ROWS or n_rows < 2 or not self.c_idx.is_cuda
+                or torch.cuda.is_current_stream_capturing()):
+            if not torch.cuda.is_current_stream_capturing():
+                ph[view] = None
+            return
+        dev = self.c_idx.device
+        idx_p = torch.empty(self.nnz, dtype=torch.int32, device=dev)
+        wpos_p = torch.empty(self.nnz, dtype=torch.int32, device=dev)
+        indptr_p = torch.empty(2 * (n_seg + 1), dtype=torch.int32, device=dev)
+        nnz_p = torch.empty(2, dtype=torch.int32, device=dev)
+        lib = L.lib()
+        ws, wsn = L.workspace(lib.sg_gather_phases_workspace_bytes(self.nnz), dev)
+        L.check(lib.sg_gather_phases_build_hip(L.ptr(idx_p), L.ptr(wpos_p), L.ptr(indptr_p), L.ptr(nnz_p),
+                                               L.ptr(getattr(self, idx_name)), L.ptr(getattr(self, ip_name)), n_seg,
+                                               self.nnz, n_rows, L.ptr(ws), wsn, L.stream_ptr()),
+                "sg_gather_phases_build_hip")
+        n0, n1 = (int(v) for v in nnz_p.cpu())
+        ph[view] = (idx_p, wpos_p, indptr_p, n0, n1)
+        self._struct = None
 
     def refresh_rowsum(self):
         """Recompute `rowsum` IN PLACE after the weights were rewritten (resident edge masking); the tensor -- and

@@ -8,7 +8,9 @@ COMMON="--no-cpu-baseline --no-verify --no-minibatch-leg"
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | cut -d' ' -f1)
   timeout -s KILL 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_main_$tag -o run -- python bench.py --steps 2 --warmup 1 --no-ceiling --no-hbm-leg $COMMON > $O/pmc_main_$tag.log 2>&1
+  if [ "${2:-all}" = "all" ]; then
   timeout -s KILL 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_hbm_$tag -o run -- python bench.py --hbm-only --hbm-steps 1 $COMMON > $O/pmc_hbm_$tag.log 2>&1
+  fi
 done
 python tools/prof_summary.py $O > $O/summary.txt 2>&1
 find $O -name "*counter_collection.csv" -size +8M -delete
