@@ -21,6 +21,7 @@
 //     kernel adds the partials of each such segment in chunk order.
 //   * XCD column slicing (cache-resident sources): XCD i only touches the 256-byte column slice i % 4 of every source
 //     row, so its private 4 MB L2 faces a 4x smaller working set (L2 hit 7 % -> 25 % on a 109 MB source).
+#include <type_traits>
 #include "common.hpp"
 
 #include <atomic>
@@ -149,6 +150,22 @@ __device__ __forceinline__ long long src_row_off(const GatherArgs& a, int q) {
   return static_cast<long long>(hi) * a.src_ld + static_cast<long long>(lo) * a.C;
 }
 
+// sum over aligned groups of G lanes (G a power of two), result on every lane of the group.  Up to 16 lanes -- one DPP
+// row -- the butterfly runs on the vector ALU (xor 1 / xor 2 inside quads, then the mirrors inside 8 and 16 lanes) instead
+// of one ds_bpermute round trip through the LDS pipe per level; wider groups finish with shuffles.
+template <int G> __device__ __forceinline__ float group_sum(float d) {
+  auto step = [&](auto ctrl) __attribute__((always_inline)) {
+    d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  if (G >= 2) step(std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+  if (G >= 4) step(std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+  if (G >= 8) step(std::integral_constant<int, 0x141>{});     // row_half_mirror: the other quad of the 8
+  if (G >= 16) step(std::integral_constant<int, 0x140>{});    // row_mirror: the other 8 of the 16
+#pragma unroll
+  for (int off = 16; off < G; off <<= 1) d += __shfl_xor(d, off);
+  return d;
+}
+
 // wave-uniform 64-bit value -> SGPR pair (scalar address arithmetic for the row burst)
 __device__ __forceinline__ long long uniform_ll(long long v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
@@ -197,8 +214,7 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
 #pragma unroll
           for (int v = 0; v < VEC; ++v) d = fmaf(x[u][v], dvec[v], d);
         }
-#pragma unroll
-        for (int off = 1; off < DLPR; off <<= 1) d += __shfl_xor(d, off);
+        d = group_sum<DOT ? DLPR : 1>(d);
         const float r = d - wv[u];
         *lacc += r * r;
         wv[u] = dscale * r;
@@ -224,8 +240,7 @@ __device__ __forceinline__ void accumulate_piece(const GatherArgs& a, const floa
 #pragma unroll
         for (int v = 0; v < VEC; ++v) d = fmaf(x[v], dvec[v], d);
       }
-#pragma unroll
-      for (int o = 1; o < DLPR; o <<= 1) d += __shfl_xor(d, o);
+      d = group_sum<DOT ? DLPR : 1>(d);
       const float r = d - wv;
       *lacc += r * r;
       wv = dscale * r;
