@@ -341,7 +341,8 @@ def multilink_agg_fwd(x, weights, biases, plan, accum, act, slope, order):
     lib = L.lib()
     D, upl = x.shape[1], weights[0].shape[0]
     o, a = _ORDER[order], _ACCUM[accum]
-    plan.ensure_phases(_gather_view(plan, order, accum, backward=False))
+    if plan.nnz >= plan.PHASE_MIN_EDGES:
+        plan.ensure_phases(_gather_view(plan, order, accum, backward=False))
     st = plan.c_struct(order != "transform_first")
     outw = upl * (plan.R if accum == "stack" else 1)
     out = torch.empty((plan.n_dst, outw), dtype=torch.float32, device=x.device)
@@ -361,7 +362,8 @@ def multilink_agg_bwd(dout, out, saved, x, weights, plan, accum, act, slope, ord
     lib = L.lib()
     D, upl = x.shape[1], weights[0].shape[0]
     o, a = _ORDER[order], _ACCUM[accum]
-    plan.ensure_phases(_gather_view(plan, order, accum, backward=True))
+    if plan.nnz >= plan.PHASE_MIN_EDGES:
+        plan.ensure_phases(_gather_view(plan, order, accum, backward=True))
     st = plan.c_struct(order != "transform_first")
     dx = torch.empty((plan.n_src, D), dtype=torch.float32, device=x.device) if need_dx else None
     dws = [torch.empty_like(w) for w in weights] if need_dw else None
