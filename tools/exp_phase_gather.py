@@ -47,7 +47,7 @@ for name, (a, b) in {"users<-items": ("user", "movie"), "items<-users": ("movie"
         base = timeit(lambda: ops.gather_sum(dst, src, idx, indptr, w, nseg, 256, **kw))
         print("   1 phase   %7.3f ms" % base)
         ref = dst.clone()
-        for P in (2, 4):
+        for P in (2, 3, 4):
             ph = phases(idx, indptr, w, nrows, P)
             def run():
                 for p, (i_, ip_, w_) in enumerate(ph):
