@@ -140,7 +140,9 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------------------
 # N > 1 without a launcher: start the ranks ourselves
 # ---------------------------------------------------------------------------------------------------------------------
-def launch_ranks(args):
+def launch_ranks(args, script=None, argv=None):
+    """Start one process per rank and wait for all of them; `script` / `argv` default to this file and its own command line
+    (tests/test_abi_and_host.py starts a stand-in script to check the fail-fast behaviour without a GPU)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -152,17 +154,33 @@ def launch_ranks(args):
         env.pop("OMP_PROC_BIND", None)
         env.pop("OMP_PLACES", None)
         env["OMP_NUM_THREADS"] = str(max(1, _host_threads() // max(args.gpus, 1)))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv)), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     try:
-        for p in procs:
-            p.wait()
-            rc = rc or p.returncode
-            if p.returncode != 0:        # one rank died: the others would wait in a collective for ever
-                for q in procs:
-                    if q.poll() is None:
-                        q.terminate()
+        # poll ALL ranks: a rank that dies while the others sit in a collective must end the run at once, whichever
+        # rank it is (waiting on rank 0 first would block until the RCCL watchdog fires)
+        live = list(procs)
+        while live:
+            for q in list(live):
+                code = q.poll()
+                if code is None:
+                    continue
+                live.remove(q)
+                if code != 0 and rc == 0:
+                    rc = code
+                    sys.stderr.write("bench: rank %d exited with code %d; stopping the other ranks\n" % (procs.index(q), code))
+                    for o in live:
+                        o.terminate()
+            if live:
+                time.sleep(0.05)
+        if rc != 0:
+            deadline = time.time() + 10.0
+            for q in procs:
+                try:
+                    q.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    pass
     finally:
         for q in procs:
             if q.poll() is None:
@@ -641,10 +659,15 @@ def run_rank(args):
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # a short collective timeout: a benchmark run whose ranks fall out of step (one died, one is stuck) should fail
+        # in minutes, not after torch's 10-minute default; the slowest legitimate gap between two collectives is the
+        # generation + planning of a config-5 user block (tens of seconds)
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("SG_BENCH_COLLECTIVE_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -757,14 +780,15 @@ def run_rank(args):
     if roof:
         roof.pop("_classes", None)
     loss_total = loss.detach().clone()
-    edges_per_rank = [E_local]
+    edges_per_rank, users_per_rank = [E_local], [hi - lo]
     if dist_on:      # every rank holds its users' share of the loss; report the whole (outside the timed region)
         loss_total = SD.all_reduce_sum(loss_total.view(1))[0]
         gathered = [None] * world
-        dist.all_gather_object(gathered, (E_local, rank_ms[0], comm["exposed_ms"] / args.steps))
+        dist.all_gather_object(gathered, (E_local, rank_ms[0], comm["exposed_ms"] / args.steps, hi - lo))
         edges_per_rank = [int(e[0]) for e in gathered]
         rank_ms = [float(e[1]) for e in gathered]
         exposed_ms = [float(e[2]) for e in gathered]
+        users_per_rank = [int(e[3]) for e in gathered]
     ms = elapsed / args.steps * 1e3
     value = E_total / (elapsed / args.steps)
     out = {
@@ -785,7 +809,7 @@ def run_rank(args):
                    "rating_head": "loss and both projection gradients in two gather passes that form the pair scores in "
                                   "registers (sg_pair_l2_hip); same value / gradients as scores + L2 loss, no per-pair "
                                   "array is written",
-                   "loss": float(loss_total), "edges_per_rank": edges_per_rank,
+                   "loss": float(loss_total), "edges_per_rank": edges_per_rank, "users_per_rank": users_per_rank,
                    "init": "embeddings U(-0.1, 0.1), Xavier-in weights, zero biases (by parameter name), then "
                            "layer-sequential scale calibration (model.calibrate_output_scale: outputs rms 1, scores "
                            "O(1)) so that the loss depends on the scores; pre-calibration rms per stage: %s" % json.dumps(

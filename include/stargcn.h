@@ -194,10 +194,10 @@ size_t sg_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K, int transA);
 int sg_gemm_f32_hip(float* C, int64_t ldc, const float* A, int64_t lda, int transA, const float* B,
                     int64_t ldb, int transB, int64_t M, int64_t N, int64_t K, const float* bias, int act,
                     float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
-/* dpre = dout * act'(.) evaluated from the activation OUTPUT `out` (all supported activations allow it) */
 /* out = act(in) elementwise (reference common.py:32-57: leaky / relu / sigmoid / tanh), for the places where the
  * activation cannot ride on a GEMM / gather epilogue (after the all-reduce of a partitioned aggregate); out may alias in */
 int sg_act_hip(float* out, const float* in, int64_t n, int act, float slope, void* stream);
+/* dpre = dout * act'(.) evaluated from the activation OUTPUT `out` (all supported activations allow it) */
 int sg_act_bwd_hip(float* dpre, const float* dout, const float* out, int64_t n, int act, float slope,
                    void* stream);
 /* dst[N] (+)= column sums of X (M,N) with leading dim ldx (bias gradient) */
@@ -354,7 +354,11 @@ typedef struct sg_multilink_plan {      /* all pointers are DEVICE pointers; see
   const float* rowsum;                  /* (n_dst, R) support sums per (node, level); needed by aggregate-first */
   int64_t n_dst, n_src, nnz;
   int32_t num_links;
-  int32_t reserved;
+  int32_t struct_bytes;                 /* sizeof(sg_multilink_plan) of the CALLER's header, or 0.  The members below this
+                                         * line were added after the first ABI: the library reads them only when struct_bytes
+                                         * says the caller's struct has them, so a caller built against the older header (this
+                                         * field was `reserved`, documented as 0) or one that does not zero the struct can
+                                         * never make it read garbage pointers. */
   sg_gather_phases phases[SG_NUM_VIEWS]; /* optional (zero = absent): source-range phases of the views, by SG_VIEW_* */
 } sg_multilink_plan;
 int sg_multilink_agg_resolve_order(const sg_multilink_plan* plan, int order);
@@ -406,9 +410,16 @@ int64_t sg_gather_profile_read2(float* ms, int64_t* nnz, int64_t* feat_dim, int6
  * SG_GATHER_SLICES_FORCE give the initial values and are read once, at the first launch.  Returns 0. */
 int sg_gather_tuning(int slices, int slices_force);
 /* tuning aid: GEMM backend of sg_gemm_f32_hip -- 0 exact-fp32 MFMA, 1 bf16x6, 2 x6v2 (wave-specialised bf16x6; both
- * bf16 backends are fp32-accurate: dropped terms <= 2^-24 |a b|), 3 f16x3 (block-scaled f16 planes, three MFMAs per
- * product, per-term error <= 7e-7, used from K = 96 on; needs the workspace sg_gemm_f32_workspace_bytes reports);
- * -1 = SG_GEMM_BACKEND / build default.  Returns 0. */
+ * bf16 backends drop terms <= 2^-24 |a b|: fp32-roundoff class), 3 f16x3 (the DEFAULT from K = 96 on; needs the workspace
+ * sg_gemm_f32_workspace_bytes reports); -1 = SG_GEMM_BACKEND / build default.  Returns 0.
+ * ERROR MODEL of backend 3 (block floating point on two f16 planes, three MFMAs per product): an operand is cut into blocks
+ * of 32 rows of op(X) x 64 k (32 x 32 where a huge fp32 operand is split inside the kernel); a block is scaled by a power
+ * of two that brings its largest FINITE magnitude into [2^14, 2^15).  A product term then carries <= 3 * 2^-22 = 7.2e-7
+ * RELATIVE error as long as both factors lie within 2^18 of their block's maximum; an element further below keeps an
+ * ABSOLUTE error of 2^-40 of that maximum instead (a row 1e6 times smaller than a neighbour in the same 32-row block still
+ * comes out to ~1e-6 relative).  Over a dot product the errors are independent: ~7e-7 / sqrt(K) of sum |a||b|.  inf / NaN
+ * propagate as in fp32 (an inf does not disturb the scale of its finite block-mates).  Operands with a wider dynamic range
+ * inside a block, or callers that need <= 2^-24 per term, select the exact kernel: SG_GEMM_BACKEND=fp32 / sg_gemm_backend(0). */
 int sg_gemm_backend(int backend);
 /* measurement aid (bench.py `dense_roofline`): HIP events around every sg_gemm_f32_hip call (conversion passes and split-K
  * reduce included) on its own stream; read returns one record per call: ms, (M, N, K) at mnk[3 i ..], backend used */
@@ -422,6 +433,12 @@ int sg_gemm_x3_variant(int variant);
  * read `bursts` consecutive 1 KiB bursts (4 in flight) of a `bytes`-long buffer, wrapping around; bench.py uses it to
  * measure, in the same run, the Infinity-Cache and L2 ceilings that price cache-resident shapes */
 int sg_stream_read_hip(const void* buf, int64_t bytes, int bursts, int64_t workgroups, float* sink, void* stream);
+/* the same with a burst STRIDE per wave: wave w reads bursts w, w + stride, w + 2 stride, ... (mod bytes / 1024).  With
+ * stride = workgroups the resident waves sweep one contiguous window through the buffer and never ask for the same burst, so
+ * a buffer larger than the L2s is served by the Infinity Cache (or HBM) without sibling-wave L2 hits: the clean bandwidth of
+ * that level (tools/mall_sweep.py -> profiles/r4_mall_sweep.txt; bench.py's bound for cache-resident launch classes) */
+int sg_stream_read_strided_hip(const void* buf, int64_t bytes, int bursts, int64_t workgroups, int64_t stride, float* sink,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (11) DEVICE-side plan builders (csrc/plan_build.hip): hand-written wave64 exclusive scan + stable LSD radix sort.

@@ -91,6 +91,7 @@ _SIGS = {
     "sg_gemm_profile_enable": (_INT, [_INT]),
     "sg_gemm_profile_read": (_I64, [_P, _P, _P, _I64]),
     "sg_stream_read_hip": (_INT, [_P, _I64, _INT, _I64, _P, _P]),
+    "sg_stream_read_strided_hip": (_INT, [_P, _I64, _INT, _I64, _I64, _P, _P]),
     "sg_build_transpose_workspace_bytes": (_SZ, [_I64] * 3),
     "sg_build_transpose_hip": (_INT, [_P] * 5 + [_I64] * 3 + [_P, _SZ, _P]),
     "sg_seg_weighted_pool_bwd_data_dev_workspace_bytes": (_SZ, [_I64] * 5),
@@ -148,7 +149,7 @@ class MultiLinkPlanStruct(_c.Structure):
     """`sg_multilink_plan` of include/stargcn.h (device pointers of a resident MultiLinkPlan)."""
     _fields_ = [(n, _P) for n in ("c_indptr", "c_idx", "c_q", "c_w", "t_indptr", "t_idx", "t_q", "t_w", "d_indptr",
                                   "s_indptr", "rowsum")] + \
-               [("n_dst", _I64), ("n_src", _I64), ("nnz", _I64), ("num_links", _c.c_int32), ("reserved", _c.c_int32),
+               [("n_dst", _I64), ("n_src", _I64), ("nnz", _I64), ("num_links", _c.c_int32), ("struct_bytes", _c.c_int32),
                 ("phases", GatherPhasesStruct * NUM_VIEWS)]
 
 _lib = None

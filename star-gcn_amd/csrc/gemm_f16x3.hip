@@ -162,12 +162,30 @@ __global__ __launch_bounds__(256) void split_kernel(char* __restrict__ planes, i
       }
     }
   }
-  // block maximum -> exponent e with max * 2^e in [2^14, 2^15) (fmaxf drops NaNs: a NaN / inf block is not scaled and
-  // propagates through the planes)
+  // block maximum -> exponent e with max * 2^e in [2^14, 2^15) (fmaxf drops NaNs; a block holding an inf takes the slow
+  // path below)
   m = wave_max_nonneg(m);
   if ((t & 63) == 0) wmax[t >> 6] = m;
   __syncthreads();
   m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  bool nonfinite = false;
+  if (__builtin_expect(!(m <= 3.402823466e38f), 0)) {
+    // the block holds an inf (block-uniform, rare): scale by its largest FINITE magnitude instead, so that finite
+    // block-mates above 65504 do not overflow the f16 planes next to it; the inf itself stays inf in the leading plane and
+    // gets a zero residual (inf - inf would turn the product's inf into NaN)
+    nonfinite = true;
+    __syncthreads();                                   // everyone has read wmax
+    float mf = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = fabsf(tile[t >> 3][(t & 7) * 8 + j]);
+      mf = fmaxf(mf, a <= 3.402823466e38f ? a : 0.f);  // drops inf and NaN
+    }
+    mf = wave_max_nonneg(mf);
+    if ((t & 63) == 0) wmax[t >> 6] = mf;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  }
   int e = 0;
   {
     const unsigned b = __float_as_uint(m);
@@ -186,7 +204,11 @@ __global__ __launch_bounds__(256) void split_kernel(char* __restrict__ planes, i
     const float t0 = tile[row][kk + 2 * j], t1 = tile[row][kk + 2 * j + 1];
     const f32x2 x = {t0 * s, t1 * s};
     const f16x2 a = __builtin_convertvector(x, f16x2);
-    const f32x2 res = {__builtin_fmaf(t0, s, -static_cast<float>(a[0])), __builtin_fmaf(t1, s, -static_cast<float>(a[1]))};   // v_fma_mix_f32
+    f32x2 res = {__builtin_fmaf(t0, s, -static_cast<float>(a[0])), __builtin_fmaf(t1, s, -static_cast<float>(a[1]))};   // v_fma_mix_f32
+    if (nonfinite) {      // block-uniform
+      if (fabsf(x[0]) == __builtin_inff()) res[0] = 0.f;
+      if (fabsf(x[1]) == __builtin_inff()) res[1] = 0.f;
+    }
     const f16x2 b = __builtin_convertvector(res, f16x2);
     h1[j] = __builtin_bit_cast(unsigned, a);
     h2[j] = __builtin_bit_cast(unsigned, b);
@@ -784,6 +806,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
       }
     }
     mx = wave_max_nonneg(mx);
+    bool nonfinite = false;
+    if (__builtin_expect(!(mx <= 3.402823466e38f), 0)) {      // wave-uniform, rare: an inf in the block -- see split_kernel
+      nonfinite = true;
+      float mf = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float a = fabsf(x[i]); mf = fmaxf(mf, a <= 3.402823466e38f ? a : 0.f); }
+      mx = wave_max_nonneg(mf);
+    }
     int e = 0;
     {
       const unsigned bits = __float_as_uint(mx);
@@ -804,7 +834,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, c
       const f16x2 a = __builtin_convertvector(v, f16x2);
       // residual x * sc - h1 in one mixed-precision FMA per element (v_fma_mix_f32 reads the f16 half directly): the same
       // value as (x * sc) - float(h1) -- both are exact -- without the two conversions back to fp32
-      const f32x2 res = {__builtin_fmaf(x[2 * j], sc, -static_cast<float>(a[0])), __builtin_fmaf(x[2 * j + 1], sc, -static_cast<float>(a[1]))};
+      f32x2 res = {__builtin_fmaf(x[2 * j], sc, -static_cast<float>(a[0])), __builtin_fmaf(x[2 * j + 1], sc, -static_cast<float>(a[1]))};
+      if (nonfinite) {    // wave-uniform: an inf keeps a zero residual (inf - inf = NaN would poison the product's inf)
+        if (fabsf(v[0]) == __builtin_inff()) res[0] = 0.f;
+        if (fabsf(v[1]) == __builtin_inff()) res[1] = 0.f;
+      }
       const f16x2 b = __builtin_convertvector(res, f16x2);
       h1[j] = __builtin_bit_cast(unsigned, a);
       h2[j] = __builtin_bit_cast(unsigned, b);

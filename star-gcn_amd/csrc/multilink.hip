@@ -11,6 +11,7 @@
 // The per-level parameters keep the reference layout (R separate (U', D) weights and (U') biases); a pack kernel lays
 // them out as Wcat / Wext in the workspace and an unpack kernel scatters the packed gradient back, so a caller that
 // owns reference-shaped parameters (MXNet NDArrays, torch Parameters) needs no glue of its own.
+#include <cstddef>
 #include "common.hpp"
 
 namespace sg {
@@ -204,8 +205,10 @@ int gather_view(const sg_multilink_plan* plan, int view, float* dst, int64_t dst
                 int64_t seg_num, int64_t nnz, int64_t C, int act, float slope, void* scratch, size_t scratch_bytes,
                 void* stream, int64_t src_bytes) {
   static const int phases_on = [] { const char* e = getenv("SG_GATHER_PHASES"); return e ? atoi(e) : 1; }();
+  // `phases` exists only in callers built against the header that has it (struct_bytes says so; 0 / older = absent)
+  const bool has_phases = plan->struct_bytes >= static_cast<int32_t>(offsetof(sg_multilink_plan, phases) + sizeof(plan->phases));
   const sg_gather_phases* ph = &plan->phases[view];
-  if (phases_on && ph->num_phases == 2 && ph->idx && C >= 64 && src_bytes >= (24ll << 20) && src_bytes <= (256ll << 20))
+  if (phases_on && has_phases && ph->num_phases == 2 && ph->idx && C >= 64 && src_bytes >= (24ll << 20) && src_bytes <= (256ll << 20))
     return sg_seg_gather_sum_phased_hip(dst, dst_group, dst_ld, src, src_group, src_ld, w, ph, seg_num, C, SG_REQ_WRITE,
                                         act, slope, scratch, scratch_bytes, stream, src_bytes);
   return sg_seg_gather_sum_hinted_hip(dst, dst_group, dst_ld, src, src_group, src_ld, w, idx, indptr, seg_num, nnz, C,

@@ -866,53 +866,6 @@ SG_API int sg_seg_weighted_pool_bwd_data_hip(float* ddata, const float* weights,
                            batch * seg_num * feat_dim * static_cast<int64_t>(sizeof(float)));
 }
 
-// ---- measurement aid: best-case streaming read with the gather's launch geometry ---------------------------------------
-// One 64-lane wavefront per workgroup (as in the gather); wave w reads `bursts` consecutive 1 KiB bursts (float4 per
-// lane, 4 in flight -- the gather's row reads at width 256 with a perfectly regular index stream) starting at burst
-// w * bursts, wrapping around the buffer.  With a buffer inside the Infinity Cache but several times the aggregate L2
-// the waves in flight are spread over the whole buffer, so (almost) every burst misses L2 and hits the Infinity Cache;
-// with a buffer of a few MB every burst hits L2.  bench.py measures both IN THE SAME RUN to price cache-resident shapes.
-namespace sg {
-__global__ __launch_bounds__(kWave) void stream_read_kernel(const float4* __restrict__ buf, long long n_bursts, int bursts,
-                                                            float* __restrict__ sink) {
-  const int lane = threadIdx.x;
-  long long b = (static_cast<long long>(blockIdx.x) * bursts) % n_bursts;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  int k = 0;
-  for (; k + 3 < bursts; k += 4) {
-    long long b1 = b + 1, b2 = b + 2, b3 = b + 3;
-    if (b1 >= n_bursts) b1 -= n_bursts;
-    if (b2 >= n_bursts) b2 -= n_bursts;
-    if (b3 >= n_bursts) b3 -= n_bursts;
-    const float4 x0 = buf[b * kWave + lane], x1 = buf[b1 * kWave + lane], x2 = buf[b2 * kWave + lane],
-                 x3 = buf[b3 * kWave + lane];
-    acc.x += x0.x + x1.x + x2.x + x3.x; acc.y += x0.y + x1.y + x2.y + x3.y;
-    acc.z += x0.z + x1.z + x2.z + x3.z; acc.w += x0.w + x1.w + x2.w + x3.w;
-    b += 4;
-    if (b >= n_bursts) b -= n_bursts;
-  }
-  for (; k < bursts; ++k) {
-    const float4 x0 = buf[b * kWave + lane];
-    acc.x += x0.x; acc.y += x0.y; acc.z += x0.z; acc.w += x0.w;
-    if (++b >= n_bursts) b -= n_bursts;
-  }
-  const float v = acc.x + acc.y + acc.z + acc.w;
-  if (v == 12345.678f) sink[0] = v;   // keeps the loads alive without a store per wave
-}
-}  // namespace sg
-
-// `workgroups` single-wave workgroups each read `bursts` 1 KiB bursts of the `bytes`-long buffer (multiple of 1024,
-// 16-byte aligned): workgroups * bursts KiB in total.
-SG_API int sg_stream_read_hip(const void* buf, int64_t bytes, int bursts, int64_t workgroups, float* sink, void* stream) {
-  if (!buf || !sink || bytes < 1024 || bytes % 1024 || bursts < 1 || workgroups < 1 || workgroups >= (1ll << 31))
-    return sg::fail(SG_ERR_INVALID, "bad stream-read arguments");
-  if (!sg::aligned(buf, 16)) return sg::fail(SG_ERR_INVALID, "buffer must be 16-byte aligned");
-  hipLaunchKernelGGL(sg::stream_read_kernel, dim3(static_cast<unsigned>(workgroups)), dim3(sg::kWave), 0,
-                     static_cast<hipStream_t>(stream), static_cast<const float4*>(buf), static_cast<long long>(bytes / 1024),
-                     bursts, sink);
-  return sg::check_launch("stream_read");
-}
-
 SG_API int sg_gather_tuning(int slices, int slices_force) {
   if (slices >= 0) sg::g_slices.store(slices, std::memory_order_relaxed);
   if (slices_force >= 0) sg::g_slices_force.store(slices_force, std::memory_order_relaxed);

@@ -101,11 +101,12 @@ class _Pending(object):
     `users` counts the crossings that were given this handle in the forward pass: a replicated tensor that feeds MORE
     than one rank-local consumer must not hand out in-flight gradient buffers (autograd would add them on the compute
     stream before the wait), so `_CopyToLocalAsync` falls back to a blocking all-reduce in that case."""
-    __slots__ = ("events", "users")
+    __slots__ = ("events", "users", "exclusive")
 
-    def __init__(self):
+    def __init__(self, exclusive=False):
         self.events = []
         self.users = 0
+        self.exclusive = exclusive      # the tensor guarded by this handle is consumed through crossings ONLY
 
     def wait(self):
         if self.events:
@@ -190,11 +191,12 @@ class _ReduceStart(torch.autograd.Function):
     lands in (NOT valid on the compute stream before `_ReduceWait`); backward: identity."""
 
     @staticmethod
-    def forward(ctx, x, pending):
-        # IN PLACE: `x` is the aggregator's pre-activation partial, a fresh buffer that nothing else reads (the
-        # aggregator does not save an un-activated output, functional._MultiLinkAgg) -- no 1 GB clone per collective
-        # at config 5.  A view / non-contiguous input (never produced by the layers) still goes through a copy.
-        if x._base is not None or not x.is_contiguous():
+    def forward(ctx, x, pending, owned):
+        # owned=True (the layer's promise): `x` is the aggregator's pre-activation partial, a fresh buffer that nothing
+        # else reads (the aggregator does not save an un-activated output, functional._MultiLinkAgg) -- reduced IN PLACE,
+        # no 1 GB clone per collective at config 5.  Without that promise, or for a view / non-contiguous input, the
+        # sum lands in a copy and the caller's tensor is left alone.
+        if not owned or x._base is not None or not x.is_contiguous():
             y = x.detach().contiguous().clone()
             _launch_sum(y, pending)
             return y
@@ -204,7 +206,7 @@ class _ReduceStart(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g, None
+        return g, None, None
 
 
 class _ReduceWait(torch.autograd.Function):
@@ -237,23 +239,26 @@ class _GradWait(torch.autograd.Function):
 
 class _CopyToLocalAsync(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, pending):
-        ctx.pending = pending
+    def forward(ctx, x, pending, owned):
+        ctx.pending, ctx.owned = pending, owned
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        # `g` is the data gradient the rank-local aggregator (or its dropout) has just produced: a fresh buffer owned by
-        # this edge of the graph, so it is summed over the ranks IN PLACE (views / strided gradients are copied first)
-        y = g if (g._base is None and g.is_contiguous()) else g.detach().contiguous().clone()
+        # owned=True (the layer's promise): `g` is the data gradient the rank-local aggregator (or its dropout) has just
+        # produced, a fresh buffer that only this edge of the graph holds, so it is summed over the ranks IN PLACE.
+        # Autograd may hand one gradient tensor OBJECT to several edges (identity / add consumers, retain_grad, hooks):
+        # without the promise -- and for views / strided gradients -- the sum lands in a copy.
+        y = g if (ctx.owned and g._base is None and g.is_contiguous()) else g.detach().contiguous().clone()
         p = ctx.pending
-        if p.users > 1:
-            # more than one crossing shares this handle: autograd will ADD their gradients on the compute stream before
-            # `_GradWait` runs, so every buffer must be complete when it is returned -- blocking all-reduce
+        if p.users > 1 or not p.exclusive:
+            # several gradients meet at the replicated tensor (more than one crossing shares this handle, or the tensor
+            # has consumers that are not crossings): autograd ADDS them on the compute stream before `_GradWait` runs, so
+            # every buffer must be complete when it is returned -- blocking all-reduce
             _launch_sum(y)
         else:
             _launch_sum(y, p)
-        return y, None
+        return y, None, None
 
 
 def copy_to_local(x):
@@ -264,33 +269,41 @@ def reduce_from_local(x):
     return _ReduceFromLocal.apply(x) if _active() else x
 
 
-def reduce_start(x):
-    """-> (buffer, pending).  The all-reduce of `x` is in flight; call `reduce_wait(buffer, pending)` before use."""
+def reduce_start(x, owned=False):
+    """-> (buffer, pending).  The all-reduce of `x` is in flight; call `reduce_wait(buffer, pending)` before use.
+    owned=True: the caller guarantees that nothing else reads `x` (a fresh, unsaved buffer) -- it is then reduced in
+    place and returned; by default the sum lands in a copy."""
     if not _active():
         return x, None
     p = _Pending()
-    return _ReduceStart.apply(x, p), p
+    return _ReduceStart.apply(x, p, bool(owned)), p
 
 
 def reduce_wait(y, pending):
     return y if pending is None else _ReduceWait.apply(y, pending)
 
 
-def grad_wait(x):
-    """-> (x', pending) for a replicated tensor about to enter rank-local work through `copy_to_local_async`."""
+def grad_wait(x, exclusive=False):
+    """-> (x', pending) for a replicated tensor about to enter rank-local work through `copy_to_local_async`.
+    exclusive=True: the caller guarantees that x' is consumed by ONE `copy_to_local_async` crossing and by nothing else;
+    only then may the crossing return a gradient buffer whose all-reduce is still in flight (awaited by x' 's backward
+    node).  Any other consumer of x' would have its gradient ADDED to that in-flight buffer before the wait, so without
+    the guarantee the crossing falls back to a blocking all-reduce."""
     if not _active() or not x.requires_grad:
         return x, None
-    p = _Pending()
+    p = _Pending(exclusive=bool(exclusive))
     return _GradWait.apply(x, p), p
 
 
-def copy_to_local_async(x, pending):
+def copy_to_local_async(x, pending, owned=False):
+    """owned=True: the gradient that will arrive at this crossing is a fresh buffer no other graph edge holds (the data
+    gradient of the consuming aggregator): it is all-reduced in place; by default it is copied first."""
     if not _active():
         return x
     if pending is None:
         return copy_to_local(x)
     pending.users += 1
-    return _CopyToLocalAsync.apply(x, pending)
+    return _CopyToLocalAsync.apply(x, pending, bool(owned))
 
 
 def allreduce_grads(params):

@@ -82,7 +82,8 @@ class HeterGCNLayer(nn.Module):
             defer = False
             if part is not None:   # node-partitioned run (dist.py): wrap the two kinds of crossing
                 if part.crossing_in(key, dst_key):
-                    feas = D.copy_to_local_async(feas, None if grad_pending is None else grad_pending.get(dst_key))
+                    feas = D.copy_to_local_async(feas, None if grad_pending is None else grad_pending.get(dst_key),
+                                                 owned=True)   # gradient = the aggregator's fresh dx (or its dropout's)
                 defer = part.crossing_out(key, dst_key)
             if len(item) == 2:
                 out = agg(feas, item[1], defer_act=defer)
@@ -91,7 +92,7 @@ class HeterGCNLayer(nn.Module):
                 out = agg(feas, end_points, indptr, support, defer_act=defer)
             pending = None
             if defer:   # partial sums over this rank's sources -> all-reduce (in flight), THEN the aggregator activation
-                out, pending = D.reduce_start(out)
+                out, pending = D.reduce_start(out, owned=True)   # fresh, unsaved pre-activation partial (functional.py)
             started.append((out, pending, agg, defer))
         return started
 
@@ -250,7 +251,7 @@ class StackedHeterGCNLayers(nn.Module):
                 for rkey in part.replicated_keys:
                     users = [s for s in agg_args if rkey in agg_args[s][2] and part.crossing_in(s, rkey)]
                     if rkey in input_dict and len(users) == 1:
-                        input_dict[rkey], pend = D.grad_wait(input_dict[rkey])
+                        input_dict[rkey], pend = D.grad_wait(input_dict[rkey], exclusive=True)   # one crossing, no other reader
                         if pend is not None:
                             grad_pending[rkey] = pend
             order = list(agg_args)

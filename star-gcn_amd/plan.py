@@ -203,6 +203,7 @@ class MultiLinkPlan(object):
                 setattr(st, name, getattr(self, name).data_ptr())
             st.rowsum = self.rowsum.data_ptr() if need_rowsum else None
             st.n_dst, st.n_src, st.nnz, st.num_links = self.n_dst, self.n_src, self.nnz, self.R
+            st.struct_bytes = ctypes.sizeof(L.MultiLinkPlanStruct)
             for view, ph in getattr(self, "_phases", {}).items():
                 if ph is None:
                     continue

@@ -7,15 +7,17 @@ mxgraph/iterators.py DataIterator, mxgraph/layers/layers.py StackedHeterGCNLayer
 
 How the reference code is executed
 ----------------------------------
-`graph.py` imports `mxnet` (absent) and the compiled extension `mxgraph._graph_sampler` (needs google/sparsehash,
-absent -> unbuildable here) at its top.  This script parses the two reference files with `ast` where they lie,
-drops exactly those two import statements (and iterators.py's `from mxgraph.graph import ...`), and executes the
-remaining, unmodified reference definitions.  The 8 C++ primitives the Python glue calls through `_graph_sampler`
-are supplied by the `Primitives` class below: `get_support` and `multi_link_split` by the oracle's C restatement
-(oracle/seg_oracle.c), the others by numpy one-liners restated from the cited C++ lines.  So what these vectors
-PIN is the reference's Python glue -- id<->index mapping, CSR transposition, both-direction edge removal, per-level
-neighbour lists (`sample_neighbors`), node merging / re-indexing, and the samplers' RNG call sequence -- i.e. the
-integer plan arrays that enter the hot path.  The primitives themselves stay "parity unpinned" (DESIGN.md section 5).
+`graph.py` imports `mxnet` (absent) and the compiled extension `mxgraph._graph_sampler` at its top.  This script parses
+the reference files with `ast` where they lie, drops exactly those two import statements (and iterators.py's
+`from mxgraph.graph import ...`), and executes the remaining, unmodified reference definitions.  `_graph_sampler` is
+the REFERENCE's OWN C++ core (GraphSampler/graph_sampler.{h,cpp}) compiled from its sources by `make -C oracle _ref`
+(oracle/_ref/libgs_ref.so; -D_WIN32 selects the std::unordered_* branches the reference carries, so google/sparsehash
+is not needed and no stand-in is written) behind `oracle/gs_ref.GraphSamplerRef`, a ctypes twin of the method table of
+py_ext.cpp:612-627 (the CPython binding itself does not compile against NumPy 2).  Until round 3 the eight primitives
+were builder-written numpy stand-ins; swapping in the compiled reference left all 380 arrays bit-identical.
+So these vectors PIN, against the reference's Python AND C++: id<->index mapping, CSR transposition, both-direction
+edge removal, per-level neighbour lists (`sample_neighbors`), support values, node merging / re-indexing, sub-matrix
+selection, and the samplers' RNG call sequence -- i.e. the integer plan arrays that enter the hot path.
 No reference text is copied into this repository: the committed artefact is data.
 """
 import ast
@@ -26,92 +28,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle import seg as O  # noqa: E402
+from oracle.gs_ref import GraphSamplerRef  # noqa: E402
 
 REF_GRAPH = "/root/reference/mxgraph/graph.py"
 REF_ITER = "/root/reference/mxgraph/iterators.py"
 REF_LAYERS = "/root/reference/mxgraph/layers/layers.py"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_glue_golden.npz")
-
-
-class Primitives(object):
-    """Stand-in for `mxgraph._graph_sampler` (py_ext.cpp:612-627)."""
-
-    @staticmethod
-    def _first_occurrence(data):
-        data = np.asarray(data)
-        uniq, first, inv, cnt = np.unique(data, return_index=True, return_inverse=True, return_counts=True)
-        order = np.argsort(first, kind="stable")
-        rank = np.empty_like(order)
-        rank[order] = np.arange(order.size)
-        return uniq[order].astype(np.int32), rank[inv].astype(np.int32), cnt[order].astype(np.int32)
-
-    def unique_cnt(self, data):                       # graph_sampler.h:441-463
-        u, _, c = self._first_occurrence(data)
-        return u, c
-
-    def unique_inverse(self, data):                   # graph_sampler.h:465-534
-        u, i, _ = self._first_occurrence(data)
-        return u, i
-
-    @staticmethod
-    def gen_row_indices_by_indptr(ind_ptr, nnz):      # graph.py:83-99 docstring
-        return np.repeat(np.arange(ind_ptr.size - 1, dtype=np.int32), np.diff(ind_ptr)).astype(np.int32)
-
-    @staticmethod
-    def get_support(row_degrees, col_degrees, ind_ptr, end_points, symm):   # graph_sampler.cpp:393-420
-        return O.get_support(row_degrees, col_degrees, end_points, ind_ptr, symm=bool(symm))
-
-    @staticmethod
-    def random_sample_fix_neighbor(ind_ptr, sel_indices, neighbor_num):     # graph_sampler.cpp:742-779
-        lens = ind_ptr[sel_indices + 1] - ind_ptr[sel_indices]
-        if neighbor_num >= 0 and np.any(lens > neighbor_num):
-            raise NotImplementedError("the random branch is thread-dependent in the reference; not used for goldens")
-        dst = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-        pos = np.concatenate([np.arange(ind_ptr[s], ind_ptr[s + 1]) for s in sel_indices] + [np.zeros(0, np.int64)])
-        return pos.astype(np.int32), dst
-
-    @staticmethod
-    def remove_edges_by_indices(end_points, values, ind_ptr, rows, cols):   # graph_sampler.cpp:154-201
-        drop = set(zip(rows.tolist(), cols.tolist()))
-        ep, va, ip = [], [], [0]
-        for i in range(ind_ptr.size - 1):
-            for j in range(ind_ptr[i], ind_ptr[i + 1]):
-                if (i, int(end_points[j])) not in drop:
-                    ep.append(end_points[j])
-                    va.append(values[j])
-            ip.append(len(ep))
-        return np.array(ep, np.int32), np.array(va, np.float32), np.array(ip, np.int32)
-
-    @staticmethod
-    def multi_link_split(edge_values, ind_ptr, multi_link):                 # graph_sampler.cpp:277-376
-        pos, ips = O.multi_link_split(np.ascontiguousarray(edge_values, np.float32),
-                                      np.ascontiguousarray(ind_ptr, np.int32),
-                                      np.ascontiguousarray(multi_link, np.float32))
-        return list(pos), list(ips)
-
-    @staticmethod
-    def take_1d_omp(data, sel):
-        return np.take(data, sel)
-
-    @staticmethod
-    def csr_submat(end_points, values, ind_ptr, row_ids, col_ids, row_indices, col_indices):   # graph_sampler.cpp:31-152
-        rows = np.arange(ind_ptr.size - 1) if row_indices is None else np.asarray(row_indices)
-        cmap = None if col_indices is None else {int(c): k for k, c in enumerate(col_indices)}
-        ep, va, ip = [], [], [0]
-        for r in rows:
-            for j in range(ind_ptr[r], ind_ptr[r + 1]):
-                c = int(end_points[j])
-                if cmap is None:
-                    ep.append(c)
-                    va.append(values[j])
-                elif c in cmap:
-                    ep.append(cmap[c])
-                    va.append(values[j])
-            ip.append(len(ep))
-        return (np.array(ep, np.int32), np.array(va, np.float32), np.array(ip, np.int32),
-                np.asarray(row_ids)[rows].astype(np.int32),
-                (np.asarray(col_ids) if col_indices is None else np.asarray(col_ids)[np.asarray(col_indices)]).astype(np.int32))
 
 
 def load_reference():
@@ -122,7 +44,7 @@ def load_reference():
             return node.module != "mxgraph.graph"
         return True
 
-    ns = {"_graph_sampler": Primitives(), "mx": None, "__name__": "reference_graph"}
+    ns = {"_graph_sampler": GraphSamplerRef(), "mx": None, "__name__": "reference_graph"}
     with open(REF_GRAPH) as f:
         tree = ast.parse(f.read(), REF_GRAPH)
     exec(compile(ast.Module(body=[n for n in tree.body if keep(n)], type_ignores=[]), REF_GRAPH, "exec"), ns)
@@ -206,7 +128,7 @@ def main():
     item_ids = np.arange(n_item, dtype=np.int32)
     out.update(g_ru=ru, g_ci=ci, g_vals=vals, g_ind_ptr=ind_ptr, g_levels=np.asarray(levels, np.float32))
     CSRMat, HeterGraph = ref["CSRMat"], ref["HeterGraph"]
-    mat = CSRMat(ci, ind_ptr, user_ids, item_ids, values=vals, multi_link=levels)
+    mat = CSRMat(ci, ind_ptr, user_ids, item_ids, values=vals, multi_link=np.asarray(levels, np.float32))  # the binding insists on float32 (py_ext.cpp:513)
     graph = HeterGraph({"user": np.zeros((n_user, 1), np.float32), "movie": np.zeros((n_item, 1), np.float32)},
                        {"user": user_ids, "movie": item_ids}, {("user", "movie"): mat})
 

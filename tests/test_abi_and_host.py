@@ -206,3 +206,30 @@ def test_bench_withholds_pmc_traffic_when_the_kernel_source_changed(monkeypatch)
     stale = bench.profile_record("ml-10m:256")
     assert stale["stale"] and "traffic withheld" in stale["source"] and "traffic_bytes_per_launch_mean" not in stale
     assert bench.profile_record("no-such-shape:1") is None
+
+
+@pytest.mark.parametrize("bad_rank", [0, 2])
+def test_bench_launcher_fails_fast_when_any_rank_dies(tmp_path, bad_rank):
+    """`python bench.py --gpus N` starts its ranks itself (bench.launch_ranks).  If ONE rank dies -- whichever -- while the
+    others wait in a collective, the run must end at once with that rank's exit code instead of sitting in
+    `procs[0].wait()` until the RCCL watchdog fires.  Stand-in ranks: the bad one exits 5 after 0.3 s,
+    the others would sleep for two minutes."""
+    import time
+    import types
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if int(os.environ['RANK']) == int(sys.argv[1]):\n    time.sleep(0.3)\n    sys.exit(5)\n"
+                      "time.sleep(120)\n")
+    t0 = time.time()
+    rc = bench.launch_ranks(types.SimpleNamespace(gpus=4), script=str(script), argv=[str(bad_rank)])
+    assert rc == 5 and time.time() - t0 < 20
+
+
+def test_bench_launcher_returns_zero_when_all_ranks_finish(tmp_path):
+    import types
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text("import os, time\ntime.sleep(0.1 * int(os.environ['RANK']))\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n")
+    assert bench.launch_ranks(types.SimpleNamespace(gpus=3), script=str(script), argv=[]) == 0

@@ -1,4 +1,4 @@
-"""Multi-process CPU test (gloo, world_size 2) of the node-partition communication pattern in star-gcn_amd/dist.py:
+"""Multi-process CPU test (gloo, world_size 2 and 4 -- uneven user blocks) of the node-partition communication pattern in star-gcn_amd/dist.py:
 `copy_to_local` / `reduce_from_local` crossings + `allreduce_grads` must reproduce the single-process gradients of a
 2-layer bipartite GCN whose users are sharded and whose items are replicated.  The sparse/dense math here is plain
 torch-CPU (the HIP kernels need a GPU); what is under test is exactly the collective placement that bench.py uses
@@ -42,6 +42,10 @@ def _make(seed=0, nu=12, ni=7, d=5):
     return A, xu, xi, params
 
 
+# contiguous user blocks per world size; 4 ranks: uneven, one rank owns a single user
+BLOCKS = {2: [(0, 5), (5, 12)], 4: [(0, 2), (2, 3), (3, 9), (9, 12)]}
+
+
 def _flat(params):
     return [p for grp in params for p in (grp if isinstance(grp, list) else [grp])]
 
@@ -54,18 +58,19 @@ def _worker(rank, world, port, out_dir, split=False):
     assert SD.world() == world and SD.rank() == rank
     cross_in, cross_out = SD.copy_to_local, SD.reduce_from_local
     if split:   # the overlap-capable split forms used by heter_sage: launch / wait as separate autograd nodes
+        fast = split == "owned"     # the layer's promises (fresh buffers, one reader): in-place sums, in-flight gradients;
+                                    # the public defaults copy and block instead -- same numbers either way
         def cross_in(x):
-            xw, pend = SD.grad_wait(x)
-            return SD.copy_to_local_async(xw, pend)
+            xw, pend = SD.grad_wait(x, exclusive=fast)
+            return SD.copy_to_local_async(xw, pend, owned=fast)
 
         def cross_out(x):
-            y, pend = SD.reduce_start(x)
+            y, pend = SD.reduce_start(x, owned=fast)
             return SD.reduce_wait(y, pend)
     SD.STATS.reset()
     SD.STATS.enabled = True
     A, xu, xi, params = _make()
-    blocks = [(0, 5), (5, 12)]
-    lo, hi = blocks[rank]
+    lo, hi = BLOCKS[world][rank]
     leaky = lambda x: torch.where(x > 0, x, 0.1 * x)
     flat = _flat(params)
     for p in flat:
@@ -87,10 +92,10 @@ def _worker(rank, world, port, out_dir, split=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("split", [False, True])
-def test_partition_pattern_matches_single_process(tmp_path, split):
+@pytest.mark.parametrize("world,split", [(2, False), (2, "safe"), (2, "owned"), (4, "owned")])
+def test_partition_pattern_matches_single_process(tmp_path, world, split):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), split), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), split), nprocs=world, join=True)
     A, xu, xi, params = _make()
     flat = _flat(params)
     for p in flat:
@@ -100,7 +105,7 @@ def test_partition_pattern_matches_single_process(tmp_path, split):
     ident = lambda x: x
     loss = _model(A, xu, xi, params, ident, ident, lambda x: torch.where(x > 0, x, 0.1 * x))
     loss.backward()
-    for r in range(2):
+    for r in range(world):
         got = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
         assert torch.allclose(got["loss"], loss.detach(), rtol=1e-10, atol=1e-10)
         for g_ref, g in zip([p.grad for p in flat], got["grads"]):
@@ -135,12 +140,23 @@ def _worker_two_consumers(rank, world, port, out_dir):
     x = torch.randn(6, 4, generator=g).double().requires_grad_(True)           # replicated
     a = torch.randn(2, 5, 6, generator=g).double()[rank]                        # rank-local operators
     b = torch.randn(2, 3, 6, generator=g).double()[rank]
-    xw, pend = SD.grad_wait(x)
-    y1 = a @ SD.copy_to_local_async(xw, pend)
-    y2 = b @ SD.copy_to_local_async(xw, pend)
+    xw, pend = SD.grad_wait(x, exclusive=True)
+    y1 = a @ SD.copy_to_local_async(xw, pend, owned=True)
+    y2 = b @ SD.copy_to_local_async(xw, pend, owned=True)
     assert pend.users == 2
     (y1.sum() * 2.0 + (y2 ** 2).sum()).backward()
     torch.save({"gx": x.grad}, os.path.join(out_dir, "c%d.pt" % rank))
+    #  the public defaults: a gradient tensor object that autograd hands to several edges must not be summed
+    # in place, and a replicated tensor with a reader that is NOT a crossing must get completed buffers.  x2 feeds one
+    # crossing and, directly, a replicated-region term; the upstream gradient of the crossing is retained and re-read.
+    x2 = x.detach().clone().requires_grad_(True)
+    xw2, pend2 = SD.grad_wait(x2)                       # not exclusive
+    z = SD.copy_to_local_async(xw2, pend2)              # not owned
+    z.retain_grad()
+    y3 = (a @ z).sum() + 0.5 * (xw2 ** 2).sum() / world        # second term: identical on every rank (replicated region)
+    y3.backward()
+    assert torch.allclose(z.grad, a.sum(0).unsqueeze(1).expand(6, 4))          # the LOCAL gradient, untouched by the sum
+    torch.save({"gx2": x2.grad}, os.path.join(out_dir, "d%d.pt" % rank))
     # the seed of the replicated dropout stream: drawn on rank 0, identical everywhere, re-settable
     torch.manual_seed(100 + rank)
     s = SD.set_replicated_seed()
@@ -164,6 +180,13 @@ def test_replicated_tensor_with_two_local_consumers(tmp_path):
     got = [torch.load(os.path.join(str(tmp_path), "c%d.pt" % r)) for r in range(2)]
     for r in range(2):
         assert torch.allclose(got[r]["gx"], x.grad, rtol=1e-10, atol=1e-12)
+    x2 = x.detach().clone().requires_grad_(True)
+    (sum((a[r] @ x2).sum() for r in range(2)) + 0.5 * (x2 ** 2).sum()).backward()
+    for r in range(2):
+        # crossing gradient summed over the ranks + each rank's replicated-region share (x / world), reduced by the caller
+        d = torch.load(os.path.join(str(tmp_path), "d%d.pt" % r))["gx2"]
+        want = sum(a[q].sum(0) for q in range(2)).unsqueeze(1).expand(6, 4) + x2.detach() / 2
+        assert torch.allclose(d, want, rtol=1e-10, atol=1e-12)
     s = [torch.load(os.path.join(str(tmp_path), "s%d.pt" % r)) for r in range(2)]
     assert s[0]["seed"] == s[1]["seed"] and torch.equal(s[0]["mask"], s[1]["mask"])
 

@@ -88,6 +88,41 @@ def _bf16_backend_case(M, N, K, ta, tb, ops, L, reset_backend=None):
         L.lib().sg_gemm_backend(reset_backend)
 
 
+@pytest.mark.parametrize("variant", [4, 5])        # 4: operands pre-split by split_kernel, 5: A split inside the hybrid kernel
+@pytest.mark.parametrize("ta", [False, True])
+def test_gemm_f16x3_block_with_an_inf_keeps_its_finite_block_mates(variant, ta):
+    """the f16 planes are scaled per 32 x 64 block by the block's largest magnitude.  A block that holds an inf
+    used to get scale 1, so finite block-mates above 65504 overflowed to f16 inf and rows that fp32 computes as finite came
+    out inf / NaN.  Now the scale comes from the largest FINITE magnitude, the inf itself stays an inf (zero residual)."""
+    from star_gcn_amd import _lib as L
+    from star_gcn_amd import ops
+    M, N, K = 256, 256, 512
+    g = torch.Generator().manual_seed(17)
+    A = torch.randn(M, K, generator=g) * 3.0e5            # finite, far above the f16 range
+    B = torch.randn(N, K, generator=g)
+    A[3, 70] = float("inf")                               # shares its 32 x 64 block with rows 0..31, k 64..127
+    A[40, 5] = float("-inf")
+    B[9, 200] = float("inf")                              # and one in the other operand
+    ref = A.double() @ B.double().t()
+    try:
+        L.lib().sg_gemm_backend(3)
+        L.lib().sg_gemm_x3_variant(variant)
+        Ad = A.t().contiguous().cuda() if ta else A.cuda()
+        out = ops.gemm(Ad, B.cuda(), trans_a=ta, trans_b=True).cpu()
+    finally:
+        L.lib().sg_gemm_x3_variant(0)
+        L.lib().sg_gemm_backend(-1)
+    fin = torch.isfinite(ref)
+    assert fin[0].sum() >= N - 1 and not fin[3].any() and not fin[:, 9].any()
+    assert torch.isfinite(out[fin]).all()                 # every entry fp64 calls finite is finite
+    mag = (torch.where(torch.isfinite(A), A, torch.zeros(())).double().abs() @
+           torch.where(torch.isfinite(B), B, torch.zeros(())).double().abs().t())
+    assert float(((out.double() - ref).abs()[fin] / mag[fin]).max()) <= 4e-7 * K ** 0.5
+    both = ~fin & ~torch.isnan(ref)                       # +-inf in fp64: the same inf here, not NaN
+    assert torch.equal(out[both].double(), ref[both])
+    assert torch.isnan(out[torch.isnan(ref)]).all()       # inf - inf or inf * 0 stays NaN
+
+
 @pytest.mark.parametrize("backend", [0, 1, 2, 3])
 def test_gemm_split_k_and_strided_views(backend):
     from star_gcn_amd import _lib as L

@@ -1,0 +1,182 @@
+"""DEVICE twins of the graph primitives (csrc/plan_build.hip, csrc/edge_mask.hip) against the
+REFERENCE's own compiled C++ -- directly, not through the product's host builders:
+
+  tests/golden/graph_primitives_golden.npz holds outputs of GraphSampler/graph_sampler.{h,cpp} compiled from the
+  reference's sources (`make -C oracle _ref`; generator tests/golden/make_primitives_golden.py).  Every assertion below
+  compares an array produced on the GPU with an array of that fixture (or with numpy index arithmetic on fixture arrays).
+
+  sg_gen_row_indices_hip / sg_count_indices_hip / sg_get_support_hip   get_support, gen_row_indices_by_indptr
+  sg_level_index_hip + sg_multilink_fuse_csr_hip                       multi_link_split_by_value (serial and _omp sizes)
+  sg_mask_edges_hip                                                    remove_edges + degrees + get_support of the rest
+  sg_unique_inverse_hip                                                unique_inverse / unique_cnt
+  sg_sample_fix_neighbor_hip                                           random_sample_fix_neighbor (copy branches, row pointer)
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graph_primitives_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(GOLD))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("t", ["s", "l"])
+def test_device_support_row_indices_and_degrees_equal_the_compiled_reference(gold, t):
+    from star_gcn_amd import _lib as L
+    g = gold
+    ep, ip = g[t + "_ep"], g[t + "_ip"]
+    n_rows, n_cols = (int(x) for x in g[t + "_shape"])
+    lib, st = L.lib(), L.stream_ptr()
+    d_ep, d_ip = dev(ep), dev(ip)
+    row = torch.empty(ep.size, dtype=torch.int32, device="cuda")
+    L.check(lib.sg_gen_row_indices_hip(L.ptr(row), L.ptr(d_ip), n_rows, ep.size, st), "sg_gen_row_indices_hip")
+    assert np.array_equal(row.cpu().numpy(), g[t + "_row_idx"])
+    cd = torch.empty(n_cols, dtype=torch.int32, device="cuda")
+    L.check(lib.sg_count_indices_hip(L.ptr(cd), L.ptr(d_ep), ep.size, n_cols, st), "sg_count_indices_hip")
+    assert np.array_equal(cd.cpu().numpy(), np.bincount(ep, minlength=n_cols))
+    rd = (d_ip[1:] - d_ip[:-1]).contiguous()
+    out = torch.empty(ep.size, dtype=torch.float32, device="cuda")
+    for name, (r_, c_) in (("", (rd, cd)), ("z", (dev(g[t + "_rdz"]), dev(g[t + "_cdz"])))):
+        for symm in (1, 0):
+            L.check(lib.sg_get_support_hip(L.ptr(out), L.ptr(r_), L.ptr(c_), L.ptr(d_ep), L.ptr(row), ep.size, symm, st),
+                    "sg_get_support_hip")
+            key = "%s_sup%s_%s" % (t, name, "symm" if symm else "row")
+            assert np.array_equal(out.cpu().numpy(), g[key]), key          # IEEE build of the reference: bit for bit
+            fm = g[key + "_fastmath"]                                       # its -O3 -ffast-math build: within one ulp
+            got = out.cpu().numpy()
+            assert np.array_equal(got == 0, fm == 0)
+            nz = got != 0
+            assert (np.abs(got[nz] / fm[nz] - 1).max() <= 2.4e-7) if nz.any() else True
+
+
+@pytest.mark.parametrize("t", ["s", "l"])
+def test_device_level_split_equals_the_compiled_reference(gold, t):
+    """`s`: 2 600 nnz = the serial multi_link_split_by_value; `l`: 24 000 nnz = its _omp form.  The device keeps the R
+    per-level CSRs FUSED (segment i*R + r = level r of row i); un-fusing its arrays must give the reference's per-level
+    position lists and full-length row pointers."""
+    from star_gcn_amd import _lib as L
+    from star_gcn_amd.plan import MultiLinkPlan
+    g = gold
+    ep, ip, vals, ml = g[t + "_ep"], g[t + "_ip"], g[t + "_val"], g[t + "_ml"]
+    n_rows, n_cols = (int(x) for x in g[t + "_shape"])
+    R = ml.size
+    level = torch.empty(ep.size, dtype=torch.int32, device="cuda")
+    d_vals, d_ml = dev(vals), dev(ml)                      # named: a temporary's block would be recycled by the next one
+    L.check(L.lib().sg_level_index_hip(L.ptr(level), L.ptr(d_vals), L.ptr(d_ml), ep.size, R, L.stream_ptr()),
+            "sg_level_index_hip")
+    lev = level.cpu().numpy()
+    for r in range(R):                                     # the level of an edge = the list the reference put it in
+        assert np.all(lev[g["%s_split_pos%d" % (t, r)]] == r)
+    sup = dev(g[t + "_sup_symm"])
+    p = MultiLinkPlan.from_device_csr(dev(ip), dev(ep), level, sup, n_cols, R, True)
+    c_indptr, c_idx, c_w, c_from = (x.cpu().numpy() for x in (p.c_indptr, p.c_idx, p.c_w, p.c_from))
+    seg_len = np.diff(c_indptr).reshape(n_rows, R)
+    for r in range(R):
+        pos, ptr = g["%s_split_pos%d" % (t, r)], g["%s_split_ptr%d" % (t, r)]
+        assert np.array_equal(np.concatenate([[0], np.cumsum(seg_len[:, r])]), ptr)
+        starts = c_indptr[:-1].reshape(n_rows, R)[:, r]
+        take = np.repeat(starts - ptr[:-1], np.diff(ptr)) + np.arange(pos.size)        # slots of level r, row after row
+        assert np.array_equal(c_from[take], pos)           # the edge (CSR position) each slot came from
+        assert np.array_equal(c_idx[take], ep[pos]) and np.array_equal(c_w[take], g[t + "_sup_symm"][pos])
+    # the transposed half: segment n*R + r lists, in increasing row order, the rows that reach column n at level r
+    t_indptr, t_idx, t_from = (x.cpu().numpy() for x in (p.t_indptr, p.t_idx, p.t_from))
+    rows = g[t + "_row_idx"]
+    order = np.lexsort((rows, lev, ep))                    # by (column, level, row)
+    assert np.array_equal(t_from[:ep.size], order) and np.array_equal(t_idx[:ep.size], rows[order])
+    assert np.array_equal(np.diff(t_indptr), np.bincount(ep.astype(np.int64) * R + lev, minlength=n_cols * R))
+
+
+@pytest.mark.parametrize("t", ["s", "l"])
+@pytest.mark.parametrize("symm", [1, 0])
+def test_device_edge_removal_equals_the_compiled_reference(gold, t, symm):
+    """sg_mask_edges_hip rewrites the weight of EVERY edge of the resident graph for graph-minus-batch.  Expected values:
+    the reference's remove_edges (repeated pairs, non-edges, a row that loses everything) -> degrees of what is left ->
+    its get_support, in both directions; removed edges weigh 0."""
+    from star_gcn_amd import _lib as L
+    g = gold
+    ep, ip = g[t + "_ep"], g[t + "_ip"]
+    n_rows, n_cols = (int(x) for x in g[t + "_shape"])
+    nnz = ep.size
+    rows = g[t + "_row_idx"]
+    # edge ids of the removal pairs by numpy (rows are column-sorted: the CSR is sorted by row * n_cols + col)
+    key = rows.astype(np.int64) * n_cols + ep
+    want = g[t + "_rm_rows"].astype(np.int64) * n_cols + g[t + "_rm_cols"]
+    at = np.searchsorted(key, want)
+    hit = (at < nnz) & (key[np.minimum(at, nnz - 1)] == want)
+    ids = np.where(hit, at, -1).astype(np.int32)           # non-edges travel as -1 (ignored), repeats stay repeated
+    removed = np.zeros(nnz, bool)
+    removed[at[hit]] = True
+    # reference side: position of every surviving edge in the reduced CSR and in its transpose
+    new_pos = np.cumsum(~removed) - 1
+    assert int((~removed).sum()) == g[t + "_rm_ep"].size and np.array_equal(ep[~removed], g[t + "_rm_ep"])
+    exp = np.zeros(nnz, np.float32)
+    exp[~removed] = g[t + ("_rm_sup_symm" if symm else "_rm_sup_row")]
+    rm_rows = rows[~removed]
+    order = np.lexsort((rm_rows, g[t + "_rm_ep"]))         # transposed order of the reduced graph (generator: same lexsort)
+    exp_t = np.zeros(nnz, np.float32)
+    exp_t[np.nonzero(~removed)[0][order]] = g[t + ("_rm_t_sup_symm" if symm else "_rm_t_sup_row")]
+    lib = L.lib()
+    w = [torch.full((nnz,), -1.0, dtype=torch.float32, device="cuda") for _ in range(2)]
+    ident = torch.arange(nnz, dtype=torch.int32, device="cuda")
+    rd = dev(np.diff(ip).astype(np.int32))
+    cd = dev(np.bincount(ep, minlength=n_cols).astype(np.int32))
+    ws, wsn = L.workspace(lib.sg_mask_edges_workspace_bytes(n_rows, n_cols, nnz), torch.device("cuda"))
+    wp = (ctypes.c_void_p * 2)(*[x.data_ptr() for x in w])
+    pp = (ctypes.c_void_p * 2)(ident.data_ptr(), ident.data_ptr())
+    tr = (ctypes.c_int32 * 2)(0, 1)
+    d_ids, d_rows, d_ep = dev(ids), dev(rows), dev(ep)
+    L.check(lib.sg_mask_edges_hip(wp, pp, tr, 2, L.ptr(d_rows), L.ptr(d_ep), L.ptr(rd), L.ptr(cd), L.ptr(d_ids), ids.size,
+                                  n_rows, n_cols, nnz, symm, L.ptr(ws), wsn, L.stream_ptr()), "sg_mask_edges_hip")
+    assert np.array_equal(w[0].cpu().numpy(), exp)
+    assert np.array_equal(w[1].cpu().numpy(), exp_t)
+    # n_rm = 0 restores the full graph: the reference's support of the untouched matrix
+    L.check(lib.sg_mask_edges_hip(wp, pp, tr, 2, L.ptr(d_rows), L.ptr(d_ep), L.ptr(rd), L.ptr(cd), None, 0, n_rows, n_cols,
+                                  nnz, symm, L.ptr(ws), wsn, L.stream_ptr()), "sg_mask_edges_hip")
+    assert np.array_equal(w[0].cpu().numpy(), g[t + ("_sup_symm" if symm else "_sup_row")])
+
+
+@pytest.mark.parametrize("tag", ["s", "e", "l", "one"])
+def test_device_unique_inverse_equals_the_compiled_reference(gold, tag):
+    from star_gcn_amd.device_graph import unique_inverse_device
+    g = gold
+    d, u, inv = g["uq_%s_data" % tag], g["uq_%s_uniq" % tag], g["uq_%s_inv" % tag]
+    du, dinv, dcnt = (x.cpu().numpy() for x in unique_inverse_device(dev(d), int(d.max()), return_counts=True))
+    assert np.array_equal(du[dinv], d)
+    if d.size <= 10000:                      # first-occurrence order in the reference: bit for bit
+        assert np.array_equal(du, u) and np.array_equal(dinv, inv)
+    else:                                    # its _omp form: thread-chunk / hash order -> equal up to the relabelling
+        assert np.array_equal(np.sort(du), np.sort(u)) and np.array_equal(u[inv], d)
+    want = dict(zip(g["uq_%s_cnt_vals" % tag].tolist(), g["uq_%s_cnt" % tag].tolist()))
+    assert dict(zip(du.tolist(), dcnt.tolist())) == want
+
+
+@pytest.mark.parametrize("t", ["s", "l"])
+def test_device_fix_neighbor_sampler_equals_the_compiled_reference(gold, t):
+    from star_gcn_amd.device_graph import sample_fix_neighbor_device
+    g = gold
+    ip, sel = g[t + "_ip"], g[t + "_fix_sel"]
+    for k in g[t + "_fix_k_list"]:
+        pos, dptr = sample_fix_neighbor_device(dev(ip), dev(sel), int(k), 11)
+        assert np.array_equal(pos.cpu().numpy(), g["%s_fix_pos_k%d" % (t, k)])
+        assert np.array_equal(dptr.cpu().numpy(), g["%s_fix_ptr_k%d" % (t, k)])
+    for k in (0, 3, 17):
+        pos, dptr = (x.cpu().numpy() for x in sample_fix_neighbor_device(dev(ip), dev(sel), k, 11))
+        assert np.array_equal(dptr, g["%s_fix_mt_ptr_k%d" % (t, k)])
+        ref_pos = g["%s_fix_mt_pos_k%d" % (t, k)]
+        lo, hi = np.repeat(ip[sel], np.diff(dptr)), np.repeat(ip[sel + 1], np.diff(dptr))
+        assert np.all((pos >= lo) & (pos < hi)) and np.all((ref_pos >= lo) & (ref_pos < hi))
+        rowtag = np.repeat(np.arange(sel.size), np.diff(dptr)).astype(np.int64) << 32
+        assert np.unique(rowtag + pos).size == pos.size           # no position twice within a row's draw
+        full = np.repeat((np.diff(dptr) == (ip[sel + 1] - ip[sel])), np.diff(dptr))
+        assert np.array_equal(pos[full], ref_pos[full])            # rows not longer than k are copied by both
