@@ -362,6 +362,12 @@ typedef struct sg_multilink_plan {      /* all pointers are DEVICE pointers; see
   sg_gather_phases phases[SG_NUM_VIEWS]; /* optional (zero = absent): source-range phases of the views, by SG_VIEW_* */
 } sg_multilink_plan;
 int sg_multilink_agg_resolve_order(const sg_multilink_plan* plan, int order);
+/* Which gather view (SG_VIEW_*) the fused entries would issue as two source-range phases for these sizes (backward = 0 / 1),
+ * or -1 when they would not -- feature width below one 256-byte column slice, gathered matrix outside 24 MB .. 256 MB,
+ * SG_GATHER_PHASES=0.  The caller builds phases (sg_gather_phases_build_hip) for THAT view only: a view that can never be
+ * phased costs neither 8 bytes per edge of resident memory nor a build.  Negative codes below -1: invalid arguments. */
+int sg_multilink_agg_phased_view(const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level, int order, int accum,
+                                 int backward);
 size_t sg_multilink_agg_saved_bytes(const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level,
                                     int order, int accum);
 size_t sg_multilink_agg_workspace_bytes(const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level,
@@ -417,8 +423,9 @@ int sg_gather_tuning(int slices, int slices_force);
  * of two that brings its largest FINITE magnitude into [2^14, 2^15).  A product term then carries <= 3 * 2^-22 = 7.2e-7
  * RELATIVE error as long as both factors lie within 2^18 of their block's maximum; an element further below keeps an
  * ABSOLUTE error of 2^-40 of that maximum instead (a row 1e6 times smaller than a neighbour in the same 32-row block still
- * comes out to ~1e-6 relative).  Over a dot product the errors are independent: ~7e-7 / sqrt(K) of sum |a||b|.  inf / NaN
- * propagate as in fp32 (an inf does not disturb the scale of its finite block-mates).  Operands with a wider dynamic range
+ * comes out to ~1e-6 relative).  Over a dot product the errors are independent: ~7e-7 / sqrt(K) of sum |a||b|.  An inf or
+ * NaN element makes every output it takes part in non-finite (an inf may come out as NaN: it meets both planes of the other
+ * operand) and does not disturb the scale of its finite block-mates.  Operands with a wider dynamic range
  * inside a block, or callers that need <= 2^-24 per term, select the exact kernel: SG_GEMM_BACKEND=fp32 / sg_gemm_backend(0). */
 int sg_gemm_backend(int backend);
 /* measurement aid (bench.py `dense_roofline`): HIP events around every sg_gemm_f32_hip call (conversion passes and split-K

@@ -14,7 +14,8 @@
  * (reference/seg_ops_cuda/mxnet_op/test_seg_ops.py:11-99) executed from
  * /root/reference by tests/golden/make_golden.py -> tests/golden/ (npz files).
  * The reference C++ (seg_op.cc) needs MXNet/mshadow/dmlc headers that are not in
- * this image, so it is unbuildable here and is NOT compiled (no oracle/_ref).
+ * this image, so it is unbuildable here and is NOT compiled (oracle/_ref holds the
+ * reference's GraphSampler core only, see oracle/Makefile).
  *
  * req follows MXNet OpReqType values: 0 = kNullOp, 1 = kWriteTo, 3 = kAddTo.
  */
@@ -296,10 +297,11 @@ EXPORT int oracle_seg_pool_bwd(float *dst, const float *ograd, const int32_t *po
 }
 
 /* ======================================================================================
- * Host graph helpers (reference/GraphSampler/graph_sampler.cpp).  PARITY UNPINNED: the
- * reference core needs google/sparsehash (graph_sampler.h:4-21), absent from this image, so it
- * is unbuildable here; these restate the published loops and are checked against hand-derived
- * cases only.
+ * Host graph helpers (reference/GraphSampler/graph_sampler.cpp).  PINNED (round 4) against the
+ * reference core itself, compiled from its own sources into oracle/_ref (oracle/Makefile `_ref`,
+ * -D_WIN32 = the std::unordered_* branches the reference carries; no stand-in headers):
+ * tests/golden/graph_primitives_golden.npz, tests/test_graph_primitives_ref.py -- bit-exact,
+ * serial and _omp forms.
  * ==================================================================================== */
 
 /* get_support : graph_sampler.cpp:393-420.  symm: sqrt(1/deg_row/deg_col) as

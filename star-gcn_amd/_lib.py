@@ -3,6 +3,7 @@
 There is deliberately NO fallback: if the shared library is missing, or a HIP device is not available when
 an operator is called, an exception is raised.  PyTorch is used only as plumbing (device memory, streams).
 """
+import collections
 import ctypes
 import os
 import subprocess
@@ -128,6 +129,7 @@ _SIGS = {
     "sg_sample_fix_neighbor_workspace_bytes": (_SZ, [_I64]),
     "sg_sample_fix_neighbor_hip": (_INT, [_P] * 4 + [_I64, _I64, _c.c_uint64, _P, _SZ, _P]),
     "sg_multilink_agg_resolve_order": (_INT, [_P, _INT]),
+    "sg_multilink_agg_phased_view": (_INT, [_P, _I64, _I64, _INT, _INT, _INT]),
     "sg_multilink_agg_saved_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT]),
     "sg_multilink_agg_workspace_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT, _INT]),
     "sg_multilink_agg_fwd_hip": (_INT, [_P] * 6 + [_I64, _I64, _INT, _INT, _INT, _F32, _P, _SZ, _P]),
@@ -198,20 +200,36 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_ws_cache = {}
+_ws_cache = collections.OrderedDict()
+_WS_CACHE_MAX = 4       # (device, stream) pairs that keep a scratch buffer; older ones are released
 
 
 def workspace(nbytes, device):
-    """Per-(device, stream) scratch buffer; kernels are stream-ordered so reuse across calls is safe."""
+    """Per-(device, stream) scratch buffer; kernels are stream-ordered so reuse across calls is safe.  At most
+    _WS_CACHE_MAX buffers are kept (least recently used first out): a process that creates many streams -- or one that ran
+    a config-5-sized step on a side stream once -- must not pin a multi-GB buffer per stream for ever.  Dropping an entry
+    only drops this module's reference: the block goes back to torch's allocator pool of the stream it was allocated on,
+    which re-issues it in that stream's order."""
     if nbytes <= 0:
         return None, 0
     key = (device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream().cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        buf = None
+        _ws_cache.pop(key, None)            # release the smaller buffer BEFORE allocating the larger one
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
+        while len(_ws_cache) > _WS_CACHE_MAX:
+            _ws_cache.popitem(last=False)
+    else:
+        _ws_cache.move_to_end(key)
     return buf, buf.numel()
+
+
+def release_workspaces():
+    """Drop every cached scratch buffer (after a one-off large problem: the next call allocates what IT needs)."""
+    _ws_cache.clear()
 
 
 def f32c(t):

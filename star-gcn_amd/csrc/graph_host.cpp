@@ -15,10 +15,38 @@
 // so small inputs stay serial and large ones use a bounded team.
 #define SG_HOST_THREADS 16
 #define SG_OMP_MIN_WORK (1 << 20)
+#include <thread>
+#include <vector>
 
 #include "common.hpp"
 
 namespace sg {
+// Host-side loops over rows run on plain std::threads, NOT on OpenMP (round 4).  hipcc's -fopenmp brings LLVM's libomp into
+// the process next to the libgomp a PyTorch host already runs; libomp initialises lazily, at the first parallel region, from
+// whatever OMP_* the environment holds AT THAT MOMENT -- with OMP_PROC_BIND / OMP_PLACES set it pins the calling thread (the
+// host application's main thread) to one core, and every thread created afterwards inherits the one-core mask.  That was the
+// "freeze" of round 3 (a test imported bench.py, which exported those variables for its CPU baseline).  A library must not
+// change its caller's affinity, whatever the environment says: std::thread workers inherit the caller's mask and leave it alone.
+template <class F>
+static void parallel_blocks(int64_t n, bool parallel, F body) {      // body(begin, end) over a static partition of [0, n)
+  int t = 1;
+  if (parallel) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    t = static_cast<int>(hw ? (hw < SG_HOST_THREADS ? hw : SG_HOST_THREADS) : 1);
+    if (n < t) t = 1;
+  }
+  if (t <= 1) { body(static_cast<int64_t>(0), n); return; }
+  std::vector<std::thread> team;
+  team.reserve(t - 1);
+  const int64_t per = (n + t - 1) / t;
+  for (int k = 1; k < t; ++k) {
+    const int64_t b = per * k, e = (b + per < n) ? b + per : n;
+    if (b < e) team.emplace_back([=] { body(b, e); });
+  }
+  body(static_cast<int64_t>(0), per < n ? per : n);
+  for (auto& th : team) th.join();
+}
+
 static thread_local std::string g_last_error;
 void set_error(const char* fmt, ...) {
   char buf[512];
@@ -74,18 +102,19 @@ SG_API int sg_build_transpose_cpu(int32_t* t_indptr, int32_t* t_pos, int32_t* t_
 SG_API int sg_get_support_cpu(float* support, const int32_t* row_degrees, const int32_t* col_degrees,
                               const int32_t* end_points, const int32_t* ind_ptr, int64_t row_num, int symm) {
   if (row_num < 0) return fail(SG_ERR_INVALID, "negative row_num");
-#pragma omp parallel for schedule(static) num_threads(SG_HOST_THREADS) if (ind_ptr[row_num] > SG_OMP_MIN_WORK)
-  for (int64_t i = 0; i < row_num; ++i) {
-    const int32_t dr = row_degrees[i];
-    for (int64_t j = ind_ptr[i]; j < ind_ptr[i + 1]; ++j) {
-      if (symm) {
-        const int32_t dc = col_degrees[end_points[j]];
-        support[j] = (dr == 0 || dc == 0) ? 0.0f : std::sqrt(1.0f / static_cast<float>(dr) / static_cast<float>(dc));
-      } else {
-        support[j] = (dr == 0) ? 0.0f : 1.0f / static_cast<float>(dr);
+  sg::parallel_blocks(row_num, row_num > 0 && ind_ptr[row_num] > SG_OMP_MIN_WORK, [=](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; ++i) {
+      const int32_t dr = row_degrees[i];
+      for (int64_t j = ind_ptr[i]; j < ind_ptr[i + 1]; ++j) {
+        if (symm) {
+          const int32_t dc = col_degrees[end_points[j]];
+          support[j] = (dr == 0 || dc == 0) ? 0.0f : std::sqrt(1.0f / static_cast<float>(dr) / static_cast<float>(dc));
+        } else {
+          support[j] = (dr == 0) ? 0.0f : 1.0f / static_cast<float>(dr);
+        }
       }
     }
-  }
+  });
   return SG_OK;
 }
 
@@ -240,29 +269,31 @@ SG_API int sg_csr_submat_cpu(int32_t* out_end_points, float* out_values, int32_t
     if (r < 0 || r >= row_num) return fail(SG_ERR_VALUE, "row index %lld out of range", static_cast<long long>(r));
   }
   out_ind_ptr[0] = 0;
-#pragma omp parallel for schedule(static) num_threads(SG_HOST_THREADS) if (n > SG_OMP_MIN_WORK)
-  for (int64_t i = 0; i < n; ++i) {
-    const int64_t r = sel_rows ? sel_rows[i] : i;
-    int32_t cnt = 0;
-    if (!col_map) cnt = ind_ptr[r + 1] - ind_ptr[r];
-    else
-      for (int64_t j = ind_ptr[r]; j < ind_ptr[r + 1]; ++j) cnt += col_map[end_points[j]] >= 0;
-    out_ind_ptr[i + 1] = cnt;
-  }
+  sg::parallel_blocks(n, n > SG_OMP_MIN_WORK, [=](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; ++i) {
+      const int64_t r = sel_rows ? sel_rows[i] : i;
+      int32_t cnt = 0;
+      if (!col_map) cnt = ind_ptr[r + 1] - ind_ptr[r];
+      else
+        for (int64_t j = ind_ptr[r]; j < ind_ptr[r + 1]; ++j) cnt += col_map[end_points[j]] >= 0;
+      out_ind_ptr[i + 1] = cnt;
+    }
+  });
   for (int64_t i = 0; i < n; ++i) out_ind_ptr[i + 1] += out_ind_ptr[i];
   *out_nnz = out_ind_ptr[n];
-#pragma omp parallel for schedule(static) num_threads(SG_HOST_THREADS) if (n > SG_OMP_MIN_WORK)
-  for (int64_t i = 0; i < n; ++i) {
-    const int64_t r = sel_rows ? sel_rows[i] : i;
-    int64_t w = out_ind_ptr[i];
-    for (int64_t j = ind_ptr[r]; j < ind_ptr[r + 1]; ++j) {
-      const int32_t c = col_map ? col_map[end_points[j]] : end_points[j];
-      if (c < 0) continue;
-      out_end_points[w] = c;
-      if (values && out_values) out_values[w] = values[j];
-      ++w;
+  sg::parallel_blocks(n, n > SG_OMP_MIN_WORK, [=](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; ++i) {
+      const int64_t r = sel_rows ? sel_rows[i] : i;
+      int64_t w = out_ind_ptr[i];
+      for (int64_t j = ind_ptr[r]; j < ind_ptr[r + 1]; ++j) {
+        const int32_t c = col_map ? col_map[end_points[j]] : end_points[j];
+        if (c < 0) continue;
+        out_end_points[w] = c;
+        if (values && out_values) out_values[w] = values[j];
+        ++w;
+      }
     }
-  }
+  });
   return SG_OK;
 }
 
@@ -292,8 +323,8 @@ SG_API int sg_sample_fix_neighbor_cpu(int32_t* sampled, int32_t* dst_ind_ptr, co
     dst_ind_ptr[i + 1] = static_cast<int32_t>(total);
   }
   if (!sampled) return SG_OK;
-#pragma omp parallel for schedule(dynamic, 256) num_threads(SG_HOST_THREADS) if (total > SG_OMP_MIN_WORK)
-  for (int64_t i = 0; i < sel_num; ++i) {
+  sg::parallel_blocks(sel_num, total > SG_OMP_MIN_WORK, [=](int64_t lo, int64_t hi) {
+  for (int64_t i = lo; i < hi; ++i) {
     const int32_t b = src_ind_ptr[sel_indices[i]], e = src_ind_ptr[sel_indices[i] + 1];
     const int32_t k = dst_ind_ptr[i + 1] - dst_ind_ptr[i], len = e - b;
     int32_t* out = sampled + dst_ind_ptr[i];
@@ -317,6 +348,7 @@ SG_API int sg_sample_fix_neighbor_cpu(int32_t* sampled, int32_t* dst_ind_ptr, co
       ++n;
     }
   }
+  });
   return SG_OK;
 }
 
@@ -325,9 +357,10 @@ SG_API int sg_gen_row_indices_cpu(int32_t* row_indices, const int32_t* ind_ptr, 
   if (row_num < 0 || nnz < 0) return fail(SG_ERR_INVALID, "negative dimension");
   if (row_num > 0 && ind_ptr[row_num] != nnz) return fail(SG_ERR_VALUE, "ind_ptr[-1] = %d but nnz = %lld", ind_ptr[row_num],
                                                          static_cast<long long>(nnz));
-#pragma omp parallel for schedule(static) num_threads(SG_HOST_THREADS) if (nnz > SG_OMP_MIN_WORK)
-  for (int64_t i = 0; i < row_num; ++i)
-    for (int32_t j = ind_ptr[i]; j < ind_ptr[i + 1]; ++j) row_indices[j] = static_cast<int32_t>(i);
+  sg::parallel_blocks(row_num, nnz > SG_OMP_MIN_WORK, [=](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; ++i)
+      for (int32_t j = ind_ptr[i]; j < ind_ptr[i + 1]; ++j) row_indices[j] = static_cast<int32_t>(i);
+  });
   return SG_OK;
 }
 
@@ -338,15 +371,16 @@ SG_API int sg_gen_row_indices_cpu(int32_t* row_indices, const int32_t* ind_ptr, 
 SG_API int sg_edge_positions_cpu(int32_t* pos, const int32_t* end_points, const int32_t* ind_ptr, int64_t row_num,
                                  const int32_t* rows, const int32_t* cols, int64_t n) {
   if (row_num < 0 || n < 0) return fail(SG_ERR_INVALID, "negative dimension");
-#pragma omp parallel for schedule(static) num_threads(SG_HOST_THREADS) if (n > SG_OMP_MIN_WORK)
-  for (int64_t k = 0; k < n; ++k) {
-    const int32_t r = rows[k];
-    if (r < 0 || r >= row_num) { pos[k] = -1; continue; }
-    const int32_t* b = end_points + ind_ptr[r];
-    const int32_t* e = end_points + ind_ptr[r + 1];
-    const int32_t* p = std::lower_bound(b, e, cols[k]);
-    pos[k] = (p != e && *p == cols[k]) ? static_cast<int32_t>(p - end_points) : -1;
-  }
+  sg::parallel_blocks(n, n > SG_OMP_MIN_WORK, [=](int64_t lo, int64_t hi) {
+    for (int64_t k = lo; k < hi; ++k) {
+      const int32_t r = rows[k];
+      if (r < 0 || r >= row_num) { pos[k] = -1; continue; }
+      const int32_t* b = end_points + ind_ptr[r];
+      const int32_t* e = end_points + ind_ptr[r + 1];
+      const int32_t* p = std::lower_bound(b, e, cols[k]);
+      pos[k] = (p != e && *p == cols[k]) ? static_cast<int32_t>(p - end_points) : -1;
+    }
+  });
   return SG_OK;
 }
 

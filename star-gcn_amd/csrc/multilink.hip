@@ -200,15 +200,23 @@ int zero_param_grads(const MutPtrTable& dw, const MutPtrTable& db, const Dims& d
 
 // one gather of the plan: as source-range phases when the plan carries them for this view and the source matrix is
 // cache-resident but larger than the L2s; SG_GATHER_PHASES=0 keeps the single launch
+// the ONE eligibility rule of source-range phases (also exported: sg_multilink_agg_phased_view): feature width of at
+// least one 256-byte column slice and a gathered matrix that is cache-resident but larger than the L2s
+bool phases_on() {
+  static const int on = [] { const char* e = getenv("SG_GATHER_PHASES"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+bool phase_shape_ok(int64_t C, int64_t src_bytes) { return C >= 64 && src_bytes >= (24ll << 20) && src_bytes <= (256ll << 20); }
+
 int gather_view(const sg_multilink_plan* plan, int view, float* dst, int64_t dst_group, int64_t dst_ld, const float* src,
                 int64_t src_group, int64_t src_ld, const float* w, const int32_t* idx, const int32_t* indptr,
                 int64_t seg_num, int64_t nnz, int64_t C, int act, float slope, void* scratch, size_t scratch_bytes,
                 void* stream, int64_t src_bytes) {
-  static const int phases_on = [] { const char* e = getenv("SG_GATHER_PHASES"); return e ? atoi(e) : 1; }();
+  const bool phases_on = sg::phases_on();
   // `phases` exists only in callers built against the header that has it (struct_bytes says so; 0 / older = absent)
   const bool has_phases = plan->struct_bytes >= static_cast<int32_t>(offsetof(sg_multilink_plan, phases) + sizeof(plan->phases));
   const sg_gather_phases* ph = &plan->phases[view];
-  if (phases_on && has_phases && ph->num_phases == 2 && ph->idx && C >= 64 && src_bytes >= (24ll << 20) && src_bytes <= (256ll << 20))
+  if (phases_on && has_phases && ph->num_phases == 2 && ph->idx && phase_shape_ok(C, src_bytes))
     return sg_seg_gather_sum_phased_hip(dst, dst_group, dst_ld, src, src_group, src_ld, w, ph, seg_num, C, SG_REQ_WRITE,
                                         act, slope, scratch, scratch_bytes, stream, src_bytes);
   return sg_seg_gather_sum_hinted_hip(dst, dst_group, dst_ld, src, src_group, src_ld, w, idx, indptr, seg_num, nnz, C,
@@ -225,6 +233,28 @@ int gather_view(const sg_multilink_plan* plan, int view, float* dst, int64_t dst
 }  // namespace sg
 
 using namespace sg;
+
+// Which gather view (SG_VIEW_*) sg_multilink_agg_{fwd,bwd}_hip would issue as source-range phases for these sizes, or -1
+// when it would not (width / footprint outside the rule, SG_GATHER_PHASES=0): callers build phases for that view only.
+SG_API int sg_multilink_agg_phased_view(const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level, int order,
+                                        int accum, int backward) {
+  Dims d;
+  const int rc = make_dims(&d, plan, in_dim, units_per_level, order, accum);
+  if (rc != SG_OK) return rc;
+  if (!sg::phases_on() || d.n_dst == 0 || d.n_src == 0) return -1;
+  int view;
+  int64_t C, src_bytes;
+  if (d.order == SG_ORDER_TRANSFORM_FIRST) {
+    C = d.U;
+    if (!backward) { view = d.stack ? SG_VIEW_C_Q_C : SG_VIEW_C_Q_D; src_bytes = d.n_src * d.RU * 4; }
+    else { view = d.stack ? SG_VIEW_T_Q_T : SG_VIEW_T_IDX_T; src_bytes = d.n_dst * d.outw * 4; }
+  } else {
+    C = d.D;
+    if (!backward) { view = SG_VIEW_C_IDX_C; src_bytes = d.n_src * d.D * 4; }
+    else { view = SG_VIEW_T_Q_S; src_bytes = d.n_dst * d.ld * 4; }
+  }
+  return phase_shape_ok(C, src_bytes) ? view : -1;
+}
 
 SG_API int sg_multilink_agg_resolve_order(const sg_multilink_plan* plan, int order) {
   if (!plan) return fail(SG_ERR_INVALID, "plan is null");

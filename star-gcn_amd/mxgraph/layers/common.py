@@ -22,12 +22,16 @@ class Activation(nn.Module):
     def fusable(self):
         return self.name in ("identity", "leaky", "relu", "sigmoid", "tanh")
 
-    def forward(self, x):
+    def forward(self, x, native=False):
+        """native=True (opt-in; the layers pass it for the activation that follows the all-reduce of a node-partitioned
+        aggregate): one native pass each way (sg_act_hip / sg_act_bwd_hip) whose derivative is evaluated from the OUTPUT --
+        no double backward, not traceable by torch.func / torch.compile.  The default is plain torch ops, so the module
+        behaves like any other nn.Module under gradgrad, functional transforms and tracing."""
         n = self.name
         if n == "identity":
             return x
-        if self.fused is not None and x.is_cuda and x.dtype == torch.float32:
-            return SF.activation(x, self.fused, self.slope)       # one native pass (sg_act_hip), output-based derivative
+        if native and self.fused is not None and x.is_cuda and x.dtype == torch.float32:
+            return SF.activation(x, self.fused, self.slope)
         if n == "leaky":
             return torch.where(x > 0, x, self.slope * x)
         if n == "relu":

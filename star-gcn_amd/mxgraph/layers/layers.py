@@ -17,7 +17,7 @@ from .._native import dist as D
 from .._native import functional as SF
 from .._native import plan as P
 from .aggregators import GCNAggregator, MultiLinkGCNAggregator
-from .common import Dense, LayerDictionary, get_activation
+from .common import Activation, Dense, LayerDictionary, get_activation
 
 
 class HeterGCNLayer(nn.Module):
@@ -101,7 +101,9 @@ class HeterGCNLayer(nn.Module):
         replicated = self.partition is not None and key in self.partition.replicated_keys
         for out, pending, agg, defer in started:
             if defer:
-                out = agg.activation(D.reduce_wait(out, pending))
+                out = D.reduce_wait(out, pending)
+                act = agg.activation        # after the sum over ranks; one native pass each way for the built-in activations
+                out = act(out, native=True) if isinstance(act, Activation) else act(out)
             outs.append(D.replicated_dropout(out, self.dropout.p, self.training) if replicated else self.dropout(out))
         if self._accum_self:
             outs.append(self._self_fcs[key](base_feas))

@@ -334,6 +334,20 @@ def _byref(struct):
     return ctypes.cast(ctypes.pointer(struct), ctypes.c_void_p)
 
 
+def _ensure_phases(plan, D, upl, o, a, backward):
+    """Build the source-range phases of the view THIS call gathers through, if the library would use them for these sizes
+    (sg_multilink_agg_phased_view: the C side's own rule -- width, footprint, SG_GATHER_PHASES) and the plan is large
+    enough for two launches to pay.  First use only; `MultiLinkPlan.prepare_phases` does the same ahead of time."""
+    if plan.nnz < plan.PHASE_MIN_EDGES or (o, a, backward, D, upl) in plan.__dict__.setdefault("_phase_checked", set()):
+        return
+    view = L.lib().sg_multilink_agg_phased_view(_byref(plan.c_struct(False)), D, upl, o, a, backward)
+    if view < -1:
+        L.check(view, "sg_multilink_agg_phased_view")
+    if view >= 0 and not plan.ensure_phases(view):
+        return              # not built now (stream capture in progress): ask again at the next eager call
+    plan._phase_checked.add((o, a, backward, D, upl))
+
+
 def multilink_agg_fwd(x, weights, biases, plan, accum, act, slope, order):
     """Fused aggregator forward (sg_multilink_agg_fwd_hip).  Returns (out, saved) -- `saved` is the opaque buffer
     the backward needs (None for transform-first)."""
@@ -341,8 +355,7 @@ def multilink_agg_fwd(x, weights, biases, plan, accum, act, slope, order):
     lib = L.lib()
     D, upl = x.shape[1], weights[0].shape[0]
     o, a = _ORDER[order], _ACCUM[accum]
-    if plan.nnz >= plan.PHASE_MIN_EDGES:
-        plan.ensure_phases(_gather_view(plan, order, accum, backward=False))
+    _ensure_phases(plan, D, upl, o, a, 0)
     st = plan.c_struct(order != "transform_first")
     outw = upl * (plan.R if accum == "stack" else 1)
     out = torch.empty((plan.n_dst, outw), dtype=torch.float32, device=x.device)
@@ -362,8 +375,7 @@ def multilink_agg_bwd(dout, out, saved, x, weights, plan, accum, act, slope, ord
     lib = L.lib()
     D, upl = x.shape[1], weights[0].shape[0]
     o, a = _ORDER[order], _ACCUM[accum]
-    if plan.nnz >= plan.PHASE_MIN_EDGES:
-        plan.ensure_phases(_gather_view(plan, order, accum, backward=True))
+    _ensure_phases(plan, D, upl, o, a, 1)
     st = plan.c_struct(order != "transform_first")
     dx = torch.empty((plan.n_src, D), dtype=torch.float32, device=x.device) if need_dx else None
     dws = [torch.empty_like(w) for w in weights] if need_dw else None

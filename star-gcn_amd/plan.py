@@ -224,24 +224,29 @@ class MultiLinkPlan(object):
         L.VIEW_T_Q_S: ("t_q", "s_indptr", lambda p: p.n_src, lambda p: p.n_dst * p.R),
     }
     PHASE_MIN_EDGES = 1 << 20          # below this a launch is too short for two
-    PHASE_MAX_ROWS = 1 << 20           # source matrices beyond the Infinity Cache (>= 256 B per row) gain nothing
 
     def ensure_phases(self, view):
-        """Source-range phases of one gather view (sg_gather_phases_build_hip), built on the device at first use and kept
-        with the plan: the library then issues that view's gather as two launches over one half of the source rows each
-        when the source matrix is cache-resident but larger than the L2s.  A no-op for small plans, for
-        sources that cannot be cache-resident, and while a hipGraph is being captured (building allocates and reads two
-        counters back)."""
+        """Source-range phases of one gather view (sg_gather_phases_build_hip), built on the device and kept with the plan:
+        the library then issues that view's gather as two launches over one half of the source rows each.
+        WHICH view is worth building is the library's decision (ops._ensure_phases asks sg_multilink_agg_phased_view with
+        the call's feature widths: the same width / footprint rule the launch applies), so a view that can never be phased
+        costs no resident memory and no build.  Returns True when the view is settled (built, or already there), False when
+        the build had to be skipped because a hipGraph is being captured on this stream (it allocates and reads two counters
+        back): a captured step must have run eagerly once before -- bench.py and examples/ do -- or it replays single
+        launches; a warning says so."""
         ph = self.__dict__.setdefault("_phases", {})
         if view in ph:
-            return
+            return True
+        if torch.cuda.is_current_stream_capturing():
+            import warnings
+            warnings.warn("MultiLinkPlan: source-range phases of gather view %d are not built yet and cannot be built during "
+                          "stream capture; this graph will replay single launches (run one eager step first)" % view)
+            return False
         idx_name, ip_name, segs, rows = self._VIEWS[view]
         n_seg, n_rows = int(segs(self)), int(rows(self))
-        if (self.nnz < self.PHASE_MIN_EDGES or n_rows > self.PHASE_MAX_ROWS or n_rows < 2 or not self.c_idx.is_cuda
-                or torch.cuda.is_current_stream_capturing()):
-            if not torch.cuda.is_current_stream_capturing():
-                ph[view] = None
-            return
+        if self.nnz < self.PHASE_MIN_EDGES or n_rows < 2 or not self.c_idx.is_cuda:
+            ph[view] = None
+            return True
         dev = self.c_idx.device
         idx_p = torch.empty(self.nnz, dtype=torch.int32, device=dev)
         wpos_p = torch.empty(self.nnz, dtype=torch.int32, device=dev)
@@ -256,6 +261,15 @@ class MultiLinkPlan(object):
         n0, n1 = (int(v) for v in nnz_p.cpu())
         ph[view] = (idx_p, wpos_p, indptr_p, n0, n1)
         self._struct = None
+        return True
+
+    def prepare_phases(self, in_dim, units_per_level, order="auto", accum="sum"):
+        """Build, NOW, the phases the forward and the backward call of an aggregator with these widths will use -- at plan
+        construction or warm-up instead of inside the first timed / captured step (the build reads two counters back)."""
+        from . import ops
+        o, a = ops._ORDER[order], ops._ACCUM[accum]
+        for backward in (0, 1):
+            ops._ensure_phases(self, int(in_dim), int(units_per_level), o, a, backward)
 
     def refresh_rowsum(self):
         """Recompute `rowsum` IN PLACE after the weights were rewritten (resident edge masking); the tensor -- and

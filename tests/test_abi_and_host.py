@@ -3,6 +3,8 @@ host-side (`_cpu`) plan/graph helpers match the oracle.  No compute kernels are 
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -233,3 +235,39 @@ def test_bench_launcher_returns_zero_when_all_ranks_finish(tmp_path):
     script.write_text("import os, time\ntime.sleep(0.1 * int(os.environ['RANK']))\n"
                       "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n")
     assert bench.launch_ranks(types.SimpleNamespace(gpus=3), script=str(script), argv=[]) == 0
+
+
+def test_importing_bench_and_calling_the_library_leave_the_process_environment_and_cpu_mask_alone():
+    """Root cause of round 3's "freeze" (DESIGN section 5): `import bench` exported OMP_PROC_BIND / OMP_PLACES into the running
+    process, the library's lazily initialised OpenMP runtime (LLVM libomp) picked them up at the next host builder call and
+    pinned the caller's main thread to one core; threads created later inherited the mask.  Three facts keep it fixed:
+    bench.py does not touch OMP_* at import, libstargcn_hip.so carries no OpenMP runtime, and a host builder call -- even
+    with the binding variables set under the running process -- leaves the CPU mask of the calling thread as it was."""
+    code = (
+        "import os, ctypes, subprocess, sys\n"
+        "import numpy as np\n"
+        "import torch\n"
+        "before = {k: os.environ.get(k) for k in ('OMP_NUM_THREADS', 'OMP_PROC_BIND', 'OMP_PLACES')}\n"
+        "mask = os.sched_getaffinity(0)\n"
+        "import bench\n"
+        "assert {k: os.environ.get(k) for k in before} == before, 'import bench changed the OpenMP environment'\n"
+        "os.environ['OMP_PROC_BIND'], os.environ['OMP_PLACES'] = 'close', 'cores'    # what round 3's import did\n"
+        "import star_gcn_amd._lib as L\n"
+        "lib = L.lib()\n"
+        "rng = np.random.default_rng(0)\n"
+        "S, T, nnz = 5000, 700, 1500000\n"
+        "idx = rng.integers(0, T, nnz).astype(np.int32)\n"
+        "ip = np.concatenate([[0], np.sort(rng.integers(0, nnz + 1, S - 1)), [nnz]]).astype(np.int32)\n"
+        "vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)\n"
+        "rd, cd = np.diff(ip).astype(np.int32), np.bincount(idx, minlength=T).astype(np.int32)\n"
+        "out, row = np.empty(nnz, np.float32), np.empty(nnz, np.int32)\n"
+        "assert lib.sg_get_support_cpu(vp(out), vp(rd), vp(cd), vp(idx), vp(ip), S, 1) == 0      # > 2^20 edges: the threaded path\n"
+        "assert lib.sg_gen_row_indices_cpu(vp(row), vp(ip), S, nnz) == 0\n"
+        "assert np.array_equal(row, np.repeat(np.arange(S), np.diff(ip)))\n"
+        "assert os.sched_getaffinity(0) == mask, 'a host builder changed the CPU mask of the calling thread'\n"
+        "print('ok')\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+    deps = subprocess.run(["ldd", L.SO_PATH], capture_output=True, text=True).stdout
+    assert "libomp" not in deps and "libgomp" not in deps, deps

@@ -1,38 +1,34 @@
 """The two workloads bench.py TIMES, checked at the size it times them: the 2-layer network with output
 Dense, rating head through sg_pair_l2_hip (incl. the source-partitioned `parts == 8` path of the full-batch head) and
-the full backward -- built by bench.py's own case builders (`bench.py --verify-only`) -- against the float64 evaluation
-of the network's DEFINITION over the whole graph (tools/f64_check.py; pinned against autograd in
-tests/test_f64_checker.py).
+the full backward -- built by bench.py's own case builders -- against the float64 evaluation of the network's
+DEFINITION over the whole graph (tools/f64_check.py; pinned against autograd in tests/test_f64_checker.py).
 
 Compared: loss, every output row of both layers and node types, both rating projections, every embedding-gradient row,
 every weight and bias gradient.  Tolerance: 1e-5 of each tensor's scale (north star).
 
-Each case runs in its own process, like the multi-rank bench tests: the config-5 case holds 140 GB of HBM at its peak
-and its process is gone, memory and all, when the next test starts."""
-import json
+IN-PROCESS again (round 4).  Round 3 moved these two cases into subprocesses because the pytest process "froze" in a later,
+unrelated test after they had run.  Root cause (tools/repro_freeze.py): `import bench` exported
+OMP_PROC_BIND=close / OMP_PLACES=cores into the RUNNING process for its CPU baseline; the library's own OpenMP runtime (LLVM
+libomp, initialised lazily by the next host-side builder call) then pinned pytest's main thread to core 0, and every thread
+created afterwards inherited the one-core mask -- the float64 CPU references of the later tests crawled on one core shared
+with the spinning OpenMP workers.  bench.py no longer touches the environment at import (its CPU baseline runs in a process
+of its own), the library's host builders use std::thread instead of OpenMP, and tests/test_abi_and_host.py holds both facts."""
 import os
-import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _run(leg, timeout):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--verify-only", leg], cwd=ROOT, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
-    assert p.returncode == 0, p.stderr[-2000:]
-    v = json.loads(p.stdout.strip().splitlines()[-1])["verify"]
-    print({k: v[k] for k in ("max_rel_err", "worst", "rows", "tensors", "score_rms", "loss_f64", "seconds",
-                             "peak_hbm_gb_incl_checker", "activation_derivative")})
-    return v
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
 def _check(v):
+    print({k: v[k] for k in ("max_rel_err", "worst", "rows", "tensors", "score_rms", "loss_f64", "seconds",
+                             "peak_hbm_gb_incl_checker", "activation_derivative")})
     bad = {k: e for k, e in v["per_tensor"].items() if e > v["tolerance"]}
     assert not bad, bad
     assert v["ok"] and v["max_rel_err"] <= 1e-5
@@ -44,17 +40,43 @@ def _check(v):
     assert ad["ambiguous_act_elements"] <= 1e-3 * ad["act_elements"]
 
 
+def _release():
+    from star_gcn_amd import _lib as L
+    L.release_workspaces()          # the config-5 step leaves a 40 GB scratch buffer cached for its stream
+    torch.cuda.empty_cache()
+
+
 def test_ml10m_bench_network_against_float64_definition():
-    v = _run("main", 600)
-    assert (v["n_user"], v["n_item"], v["levels"]) == (69878, 10677, 10) and v["edges"] >= 10000000
-    assert v["rating_head_item_side_parts"] == 8          # the source-partitioned path the bench times
-    assert v["deterministic"]                              # no atomics on the path: the loss repeats bit for bit
+    import bench
+    affinity = os.sched_getaffinity(0)
+    dev = torch.device("cuda", 0)
+    c = bench.main_case("ml-10m", 256, "auto", dev)
+    assert (c.n_user, c.n_item, c.R) == (69878, 10677, 10) and c.E_total >= 10000000
+    pp = c.plan["idx"][0]["pair"]
+    assert pp.item_side_partition(64) is not None and pp.item_side_partition(64).parts == 8     # the path the bench times
+    v = bench.verify_leg(c.net, c.step, (c.dgraph.ind_ptr, c.dgraph.end_points, c.dgraph.level, c.n_item, c.R, None),
+                         c.y, 1.0 / c.E_total)
+    assert float(c.step().detach()) == float(c.step().detach())      # deterministic: no atomics on the path
+    v.update(n_user=c.n_user, n_item=c.n_item)
     _check(v)
+    del c
+    _release()
+    assert os.sched_getaffinity(0) == affinity          # the library and bench left this process's CPU mask alone
 
 
 def test_config5_shard_bench_network_against_float64_definition():
     """1.25 M users x 1 M items, 125 M ratings, 16 levels, dim 256: the exact `hbm_bound` leg of bench.py."""
-    v = _run("hbm", 900)
-    assert v["edges"] >= 125000000 and v["levels"] == 16
+    import bench
+    affinity = os.sched_getaffinity(0)
+    dev = torch.device("cuda", 0)
+    torch.cuda.reset_peak_memory_stats(dev)
+    c = bench.hbm_case("1250000,1000000,125000000,16", 256, "auto", dev)
+    assert c.E >= 125000000 and c.R == 16
+    v = bench.verify_leg(c.net, c.step, (c.dg.ind_ptr, c.dg.end_points, c.dg.level, c.ni, c.R, None), c.y, 1.0 / c.E)
     assert v["peak_hbm_gb_incl_checker"] < 200             # far from the 288 GB of the device
+    v.update(n_user=c.nu, n_item=c.ni)
     _check(v)
+    del c
+    _release()
+    assert torch.cuda.memory_reserved(dev) < 8 << 30       # nothing of the 140 GB stays behind for the tests that follow
+    assert os.sched_getaffinity(0) == affinity

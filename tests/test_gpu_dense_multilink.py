@@ -93,7 +93,7 @@ def _bf16_backend_case(M, N, K, ta, tb, ops, L, reset_backend=None):
 def test_gemm_f16x3_block_with_an_inf_keeps_its_finite_block_mates(variant, ta):
     """the f16 planes are scaled per 32 x 64 block by the block's largest magnitude.  A block that holds an inf
     used to get scale 1, so finite block-mates above 65504 overflowed to f16 inf and rows that fp32 computes as finite came
-    out inf / NaN.  Now the scale comes from the largest FINITE magnitude, the inf itself stays an inf (zero residual)."""
+    out inf / NaN.  Now the scale comes from the largest FINITE magnitude; what the inf itself touches stays non-finite."""
     from star_gcn_amd import _lib as L
     from star_gcn_amd import ops
     M, N, K = 256, 256, 512
@@ -118,9 +118,10 @@ def test_gemm_f16x3_block_with_an_inf_keeps_its_finite_block_mates(variant, ta):
     mag = (torch.where(torch.isfinite(A), A, torch.zeros(())).double().abs() @
            torch.where(torch.isfinite(B), B, torch.zeros(())).double().abs().t())
     assert float(((out.double() - ref).abs()[fin] / mag[fin]).max()) <= 4e-7 * K ** 0.5
-    both = ~fin & ~torch.isnan(ref)                       # +-inf in fp64: the same inf here, not NaN
-    assert torch.equal(out[both].double(), ref[both])
-    assert torch.isnan(out[torch.isnan(ref)]).all()       # inf - inf or inf * 0 stays NaN
+    # entries an inf takes part in: non-finite here too.  (Not necessarily the SAME non-finite value: the inf meets both
+    # planes of the other operand, whose residual plane has either sign, so +inf can come out as inf - inf = NaN.  Callers
+    # that need IEEE inf arithmetic select the exact kernel, sg_gemm_backend(0); include/stargcn.h.)
+    assert not torch.isfinite(out[~fin]).any()
 
 
 @pytest.mark.parametrize("backend", [0, 1, 2, 3])

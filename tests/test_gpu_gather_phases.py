@@ -129,3 +129,29 @@ def test_phased_gather_entry_with_masked_weights_and_add():
             L.check(lib.sg_seg_gather_sum_phased_hip(L.ptr(dst), 1, C, L.ptr(src), 1, C, L.ptr(d_w), ref, n_seg, C, req, 0, 0.0,
                                                      L.ptr(ws2), wsn2, L.stream_ptr(), 0), "phased")
             torch.testing.assert_close(dst, want, rtol=2e-6, atol=2e-6)
+
+
+def test_phases_are_built_only_for_views_the_library_would_phase():
+    """the Python side used to gate on edge and row counts only and built 8 bytes per edge of phase arrays (plus a
+    blocking read-back) for views the C side can never phase.  Now ONE rule decides (sg_multilink_agg_phased_view): width
+    below a 256-byte column slice, or a gathered matrix outside 24 MB .. 256 MB -> nothing is built."""
+    from star_gcn_amd import ops
+    from star_gcn_amd import _lib as L
+    n_dst, n_src, nnz, R = 30000, 45000, 1_300_000, 3
+    g = torch.Generator().manual_seed(3)
+    for D, U, expect in ((32, 32, 0), (256, 256, 2)):       # 32-wide rows: never phased; 256-wide over 46 / 31 MB: both calls
+        plan = _plan(n_dst, n_src, nnz, R, seed=11)
+        x = torch.randn(n_src, D, generator=g).cuda()
+        ws = [(torch.randn(U, D, generator=g) / 16).cuda() for _ in range(R)]
+        bs = [torch.randn(U, generator=g).cuda() for _ in range(R)]
+        st = ops._byref(plan.c_struct(False))
+        views = [L.lib().sg_multilink_agg_phased_view(st, D, U, 2, 0, b) for b in (0, 1)]
+        assert (views == [-1, -1]) if expect == 0 else (views == [L.VIEW_C_IDX_C, L.VIEW_T_Q_S])
+        out, saved = ops.multilink_agg_fwd(x, ws, bs, plan, "sum", "leaky", 0.1, "aggregate_first")
+        ops.multilink_agg_bwd(torch.ones_like(out), out, saved, x, ws, plan, "sum", "leaky", 0.1, "aggregate_first", True, True, True)
+        built = [v for v, p in plan.__dict__.get("_phases", {}).items() if p is not None]
+        assert len(built) == expect
+    # ahead of time, outside any step
+    plan = _plan(n_dst, n_src, nnz, R, seed=11)
+    plan.prepare_phases(256, 256, "transform_first", "sum")
+    assert sorted(v for v, p in plan._phases.items() if p is not None) == [L.VIEW_C_Q_D, L.VIEW_T_IDX_T]

@@ -1,5 +1,6 @@
-"""The native graph primitives behind plan construction (csrc/graph_host.cpp), PINNED two ways that do
-not go through the builder's own restatement of them (tests/golden/make_graph_golden.py's `Primitives` stand-ins):
+"""The native graph primitives behind plan construction (csrc/graph_host.cpp), pinned two ways that need
+nothing of the reference at run time (round 3; since round 4 the primary pin is the reference's own compiled C++:
+tests/test_graph_primitives_ref.py / oracle/_ref):
 
   (1) hand-derived cases: inputs and expected outputs written out by hand from the cited reference lines
       (/root/reference/GraphSampler/graph_sampler.cpp, graph_sampler.h) -- every branch the C++ has;

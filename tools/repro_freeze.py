@@ -18,7 +18,10 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.chdir(ROOT)
-faulthandler.enable()
+import signal
+_FH = open(os.environ.get("SG_REPRO_FH", "/tmp/repro_fh.txt"), "w")
+faulthandler.enable(file=_FH)
+faulthandler.register(signal.SIGUSR1, file=_FH, all_threads=True)      # the watchdog samples the Python stacks with SIGUSR1
 
 
 def log(msg):
@@ -55,20 +58,66 @@ def do_verify():
     log("released, reserved now %.1f GB" % (torch.cuda.memory_reserved() / 2 ** 30))
 
 
+def micro():
+    """a few primitive host <-> runtime operations, timed: which of them degrades as the process ages?"""
+    import torch
+    from star_gcn_amd import ops
+    out = {}
+    a, b = torch.randn(130, 75, device="cuda"), torch.randn(250, 75, device="cuda")
+    torch.cuda.synchronize()
+
+    def t(fn, n):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+    out["gemm_small_us"] = t(lambda: ops.gemm(a, b, trans_b=True), 200)
+    # the same product through the raw ABI with its OWN small workspace (not the cached one, which after a config-5 step is
+    # tens of GB) and, separately, the Python-side pieces of ops.gemm
+    from star_gcn_amd import _lib as L
+    lib = L.lib()
+    c = torch.empty(130, 250, device="cuda")
+    small = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    st = L.stream_ptr()
+    out["gemm_raw_small_ws_us"] = t(lambda: lib.sg_gemm_f32_hip(L.ptr(c), 250, L.ptr(a), 75, 0, L.ptr(b), 75, 1, 130, 250, 75, None, 0,
+                                                                0.1, 0, L.ptr(small), small.numel(), st), 200)
+    big, bign = L.workspace(1 << 20, a.device)
+    out["ws_cached_mb"] = bign / 2 ** 20
+    out["gemm_raw_cached_ws_us"] = t(lambda: lib.sg_gemm_f32_hip(L.ptr(c), 250, L.ptr(a), 75, 0, L.ptr(b), 75, 1, 130, 250, 75, None, 0,
+                                                                 0.1, 0, L.ptr(big), bign, st), 200)
+    out["ws_query_us"] = t(lambda: lib.sg_gemm_f32_workspace_bytes(130, 250, 75, 0), 200)
+    out["py_workspace_us"] = t(lambda: L.workspace(1 << 20, a.device), 200)
+    out["torch_empty_out_us"] = t(lambda: torch.empty((130, 250), dtype=torch.float32, device="cuda"), 200)
+    out["torch_add_us"] = t(lambda: a.add_(1.0), 200)
+    out["sync_us"] = t(torch.cuda.synchronize, 200)
+    out["alloc_1mb_us"] = t(lambda: torch.empty(1 << 20, dtype=torch.uint8, device="cuda"), 200)
+    out["alloc_fresh_64mb_us"] = t(lambda: (torch.empty(64 << 20, dtype=torch.uint8, device="cuda"), torch.cuda.empty_cache()), 5)
+    out["event_us"] = t(lambda: torch.cuda.Event(enable_timing=True).record(), 200)
+    out["h2d_us"] = t(lambda: torch.zeros(1000).cuda(), 100)
+    out["d2h_us"] = t(lambda: a.cpu(), 100)
+    log("micro: " + "  ".join("%s %.0f" % kv for kv in out.items()))
+
+
 if __name__ == "__main__":
     T0 = time.perf_counter()
     mode = sys.argv[1] if len(sys.argv) > 1 else "alloc"
     loops = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     import pytest
+    if mode == "none":
+        pass
     if mode in ("verify", "both"):
         do_verify()
     if mode in ("alloc", "both"):
         do_alloc()
+    micro()
     for k in range(loops):
-        faulthandler.dump_traceback_later(300, exit=False)
+        faulthandler.dump_traceback_later(200, repeat=True, file=_FH)
         t = time.perf_counter()
-        rc = pytest.main(["-x", "-q", "-p", "no:cacheprovider", "tests/test_gpu_dense_multilink.py", "-k", "gemm or linear or fused"])
+        rc = pytest.main(["-x", "-q", "-p", "no:cacheprovider", "--durations=8", "tests/test_gpu_dense_multilink.py", "-k",
+                          os.environ.get("SG_REPRO_K", "gemm or linear or fused")])
         faulthandler.cancel_dump_traceback_later()
+        micro()
         log("pass %d: pytest rc %s in %.1f s" % (k, rc, time.perf_counter() - t))
         if rc != 0:
             sys.exit(3)
