@@ -258,3 +258,35 @@ def test_bwd_data_hip_matches_reference_derived_goldens():
         got = ops.seg_weighted_pool_bwd_data(og, e1, TransposePlan(ids, ip, M, "cuda"), M).cpu().numpy()
         want = g[p + "_dembed2"]
         assert np.abs(got - want).max() <= 1e-5 * max(1.0, float(np.abs(want).max())), p
+
+
+@pytest.mark.parametrize("K,S,T,nnz,C", [(30, 4000, 8000, 100000, 512), (4, 4000, 8000, 800000, 512)])
+def test_reference_standalone_harness_sizes(contrib, K, S, T, nnz, C):
+    """The sizes of the reference's own CUDA-vs-CPU harness (seg_ops_cuda/seg_ops.cu:1702-1718: K up to 30, N = 4000, M = 8000,
+    nnz = 800 k, C = 512; inputs uniform(-1, 1), abs tol 1e-4 there): batch 30 at a reduced edge count and the full edge
+    count at batch 4 (the C oracle finishes each in seconds), forward and the weight gradient."""
+    rng = np.random.default_rng(1000)
+    data = rng.uniform(-1, 1, (K, T, C)).astype(np.float32)
+    w = rng.uniform(-1, 1, (K, nnz)).astype(np.float32)
+    idx = rng.integers(0, T, nnz).astype(np.int32)
+    indptr = np.concatenate([[0], np.sort(rng.integers(0, nnz + 1, S - 1)), [nnz]]).astype(np.int32)
+    out = contrib.seg_weighted_pool(data=dev(data), weights=dev(w), indices=dev(idx), indptr=dev(indptr))
+    ref = O.seg_weighted_pool(data, w, idx, indptr)
+    scale = float(np.abs(ref).max())
+    assert float(np.abs(out.cpu().numpy() - ref).max()) <= 1e-5 * scale
+    e1 = rng.uniform(-1, 1, (K, S, C)).astype(np.float32)
+    corr = contrib.seg_take_k_corr(embed1=dev(e1), embed2=dev(data), neighbor_ids=dev(idx), neighbor_indptr=dev(indptr))
+    cref = O.seg_take_k_corr(e1, data, idx, indptr)
+    assert float(np.abs(corr.cpu().numpy() - cref).max()) <= 2e-5 * float(np.abs(cref).max())
+
+
+def test_reference_standalone_harness_seg_reduce_ten_million(contrib):
+    """seg_ops.cu:1694-1700: segment reduction over nnz = 10 M positions."""
+    rng = np.random.default_rng(1000)
+    B, S, nnz = 2, 500000, 10_000_000
+    x = rng.uniform(-1, 1, (B, nnz)).astype(np.float32)
+    indptr = np.concatenate([[0], np.sort(rng.integers(0, nnz + 1, S - 1)), [nnz]]).astype(np.int32)
+    got = contrib.seg_sum(data=dev(x), indptr=dev(indptr)).cpu().numpy()
+    cs = np.concatenate([np.zeros((B, 1)), np.cumsum(x.astype(np.float64), axis=1)], axis=1)
+    ref = cs[:, indptr[1:]] - cs[:, indptr[:-1]]
+    assert float(np.abs(got - ref).max()) <= 1e-5 * float(np.abs(ref).max())
