@@ -402,7 +402,10 @@ class NodePartition(object):
 
 
 def balanced_row_blocks(ind_ptr, n_parts):
-    """Contiguous row blocks with (almost) equal edge counts: boundaries by searching the CSR row pointer."""
+    """Contiguous row blocks with (almost) equal edge counts: boundaries by searching the CSR row pointer.  Every block
+    holds at least one row whenever there are at least `n_parts` rows (a hub row that alone carries several blocks' worth of
+    edges would otherwise leave its neighbours with EMPTY blocks -- a rank without users); with fewer rows than parts the
+    trailing blocks are empty."""
     ind_ptr = np.asarray(ind_ptr, dtype=np.int64)
     n_rows, nnz = ind_ptr.size - 1, int(ind_ptr[-1])
     cuts = [0]
@@ -410,4 +413,9 @@ def balanced_row_blocks(ind_ptr, n_parts):
         cuts.append(int(np.searchsorted(ind_ptr, nnz * p // n_parts, side="left")))
     cuts.append(n_rows)
     cuts = np.maximum.accumulate(np.minimum(cuts, n_rows))
+    if n_rows >= n_parts:
+        for p in range(1, n_parts):                      # strictly increasing from the left ...
+            cuts[p] = max(cuts[p], cuts[p - 1] + 1)
+        for p in range(n_parts - 1, 0, -1):              # ... leaving at least one row for every block to the right
+            cuts[p] = min(cuts[p], cuts[p + 1] - 1)
     return [(int(cuts[i]), int(cuts[i + 1])) for i in range(n_parts)]

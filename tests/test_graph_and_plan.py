@@ -381,3 +381,21 @@ dist.destroy_process_group()
         assert "RAISED True" in o and "NOERROR" not in o, o
         nnz = [int(x) for x in o.split("NNZ")[1].split()]
         assert nnz[0] == nnz[1] - 2
+
+
+def test_balanced_blocks_never_leave_a_rank_without_rows():
+    """A hub row carrying most of the edges used to produce EMPTY neighbouring blocks (searchsorted returns the same cut for
+    several parts): every block now has at least one row whenever there are at least as many rows as parts."""
+    from star_gcn_amd.dist import balanced_row_blocks
+    deg = np.array([1, 1, 5000, 1, 1, 1, 1, 1, 1, 1], np.int64)            # row 2 holds 99.8 % of the edges
+    ind_ptr = np.concatenate([[0], np.cumsum(deg)])
+    for n in (2, 3, 4, 8, 10):
+        blocks = balanced_row_blocks(ind_ptr, n)
+        assert blocks[0][0] == 0 and blocks[-1][1] == 10 and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+        assert all(hi > lo for lo, hi in blocks), (n, blocks)
+    blocks = balanced_row_blocks(ind_ptr, 12)                                # more parts than rows: the tail is empty
+    assert sum(hi - lo for lo, hi in blocks) == 10 and all(hi >= lo for lo, hi in blocks)
+    even = balanced_row_blocks(np.arange(0, 1001, 10), 4)                    # uniform degrees: untouched by the fix
+    assert even == [(0, 25), (25, 50), (50, 75), (75, 100)]
+    hub_first = balanced_row_blocks(np.concatenate([[0], np.cumsum([9000, 1, 1, 1])]), 4)
+    assert hub_first == [(0, 1), (1, 2), (2, 3), (3, 4)]
