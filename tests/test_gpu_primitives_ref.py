@@ -180,3 +180,63 @@ def test_device_fix_neighbor_sampler_equals_the_compiled_reference(gold, t):
         assert np.unique(rowtag + pos).size == pos.size           # no position twice within a row's draw
         full = np.repeat((np.diff(dptr) == (ip[sel + 1] - ip[sel])), np.diff(dptr))
         assert np.array_equal(pos[full], ref_pos[full])            # rows not longer than k are copied by both
+
+
+def test_device_twins_live_against_the_compiled_reference_on_a_random_graph():
+    """Where oracle/_ref/libgs_ref.so travelled with the snapshot (it is a build product like the library itself): the device
+    twins against the reference's compiled C++ CALLED HERE, on a fresh 200 k-edge graph -- support in both directions and
+    both normalisations, level lists, edge removal with repeats and non-edges."""
+    from oracle import gs_ref
+    if not gs_ref.available():
+        pytest.skip("oracle/_ref not in this snapshot")
+    from star_gcn_amd import _lib as L
+    from star_gcn_amd.plan import MultiLinkPlan
+    ref = gs_ref.GraphSamplerRef()
+    rng = np.random.default_rng(77)
+    n_rows, n_cols, nnz, R = 9000, 2500, 200000, 10
+    cells = np.sort(rng.choice(n_rows * n_cols, nnz, replace=False))
+    rows, cols = (cells // n_cols).astype(np.int32), (cells % n_cols).astype(np.int32)
+    ip = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n_rows))]).astype(np.int32)
+    ml = (np.arange(1, R + 1) * 0.5).astype(np.float32)
+    vals = ml[rng.integers(0, R, nnz)]
+    rd, cd = np.diff(ip).astype(np.int32), np.bincount(cols, minlength=n_cols).astype(np.int32)
+    lib, st = L.lib(), L.stream_ptr()
+    d_ip, d_ep, d_rows, d_rd, d_cd = dev(ip), dev(cols), dev(rows), dev(rd), dev(cd)
+    out = torch.empty(nnz, dtype=torch.float32, device="cuda")
+    for symm in (1, 0):
+        L.check(lib.sg_get_support_hip(L.ptr(out), L.ptr(d_rd), L.ptr(d_cd), L.ptr(d_ep), L.ptr(d_rows), nnz, symm, st), "support")
+        assert np.array_equal(out.cpu().numpy(), ref.get_support(rd, cd, ip, cols, symm))
+    level = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    d_vals, d_ml = dev(vals), dev(ml)
+    L.check(lib.sg_level_index_hip(L.ptr(level), L.ptr(d_vals), L.ptr(d_ml), nnz, R, st), "level")
+    pos, ptr = ref.multi_link_split(vals, ip, ml)                 # 200 k nnz: the reference's _omp form
+    p = MultiLinkPlan.from_device_csr(d_ip, d_ep, level, None, n_cols, R, True)
+    c_indptr, c_from = p.c_indptr.cpu().numpy(), p.c_from.cpu().numpy()
+    for r in range(R):
+        starts = c_indptr[:-1].reshape(n_rows, R)[:, r]
+        take = np.repeat(starts - ptr[r][:-1], np.diff(ptr[r])) + np.arange(pos[r].size)
+        assert np.array_equal(c_from[take], pos[r])
+        assert np.array_equal(np.concatenate([[0], np.cumsum(np.diff(c_indptr).reshape(n_rows, R)[:, r])]), ptr[r])
+    sel = rng.choice(nnz, 30000, replace=False)
+    rr = np.concatenate([rows[sel], rows[sel[:50]], rng.integers(0, n_rows, 100).astype(np.int32)]).astype(np.int32)
+    rc = np.concatenate([cols[sel], cols[sel[:50]], rng.integers(0, n_cols, 100).astype(np.int32)]).astype(np.int32)
+    ep2, _val2, ip2 = ref.remove_edges_by_indices(cols, vals, ip, rr, rc)
+    rd2, cd2 = np.diff(ip2).astype(np.int32), np.bincount(ep2, minlength=n_cols).astype(np.int32)
+    key = rows.astype(np.int64) * n_cols + cols
+    want = rr.astype(np.int64) * n_cols + rc
+    at = np.searchsorted(key, want)
+    hit = (at < nnz) & (key[np.minimum(at, nnz - 1)] == want)
+    removed = np.zeros(nnz, bool)
+    removed[at[hit]] = True
+    assert np.array_equal(cols[~removed], ep2)
+    for symm in (1, 0):
+        exp = np.zeros(nnz, np.float32)
+        exp[~removed] = ref.get_support(rd2, cd2, ip2, ep2, symm)
+        w = torch.full((nnz,), -1.0, dtype=torch.float32, device="cuda")
+        ident = torch.arange(nnz, dtype=torch.int32, device="cuda")
+        ws, wsn = L.workspace(lib.sg_mask_edges_workspace_bytes(n_rows, n_cols, nnz), torch.device("cuda"))
+        wp, pp, tr = (ctypes.c_void_p * 1)(w.data_ptr()), (ctypes.c_void_p * 1)(ident.data_ptr()), (ctypes.c_int32 * 1)(0)
+        d_ids = dev(np.where(hit, at, -1).astype(np.int32))
+        L.check(lib.sg_mask_edges_hip(wp, pp, tr, 1, L.ptr(d_rows), L.ptr(d_ep), L.ptr(d_rd), L.ptr(d_cd), L.ptr(d_ids), d_ids.numel(),
+                                      n_rows, n_cols, nnz, symm, L.ptr(ws), wsn, st), "mask")
+        assert np.array_equal(w.cpu().numpy(), exp)
