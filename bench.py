@@ -889,19 +889,25 @@ def run_rank(args):
         except Exception as e:      # capture support is a property of the torch build, not of the path
             out["graph_replay"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         loss = None
+    def guarded(fn, *a):      # a secondary leg must never cost the headline line: its failure becomes an "error" entry
+        try:
+            return fn(*a)
+        except Exception as e:
+            return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
     if world == 1 and not dist_on:
         loss = None
-        out["dense_roofline"] = dense_roofline(step, 3)
+        out["dense_roofline"] = guarded(dense_roofline, step, 3)
         # the same step with every dense product on the EXACT fp32 MFMA kernel (sg_gemm_backend(0); v_mfma_f32_32x32x2_f32,
         # no plane splitting): what `dtype: "f32"` costs without the three-f16-MFMA emulation of the default backend
-        out["ms_per_step_exact_fp32_gemm"] = exact_fp32_step_ms(step, 5)
+        out["ms_per_step_exact_fp32_gemm"] = guarded(exact_fp32_step_ms, step, 5)
         out["dense_mix_arithmetic"] = ("default: fp32 operands as two block-scaled f16 planes, three MFMAs per product, fp32 "
                                        "accumulation, per-term error <= 7.2e-7 (include/stargcn.h, sg_gemm_backend); "
                                        "ms_per_step_exact_fp32_gemm: the same step on the exact fp32 MFMA kernel")
     if world == 1 and not dist_on and not args.no_verify:
         loss = None
-        out["verify"] = verify_leg(net, step, (dgraph.ind_ptr, dgraph.end_points, dgraph.level, n_item, R, None), y,
-                                   1.0 / E_total)
+        out["verify"] = guarded(verify_leg, net, step, (dgraph.ind_ptr, dgraph.end_points, dgraph.level, n_item, R, None), y,
+                                1.0 / E_total)
     # free the main leg before the big one
     del net, plan, dgraph, y, step
     torch.cuda.empty_cache()
@@ -914,7 +920,7 @@ def run_rank(args):
     # the 140 GB leg and its float64 verification are the LAST device work of the process
     if rank == 0 and world == 1 and not args.no_hbm_leg:
         torch.cuda.reset_peak_memory_stats(dev)
-        out["hbm_bound"] = hbm_leg(args, dev)
+        out["hbm_bound"] = guarded(hbm_leg, args, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
@@ -1014,10 +1020,13 @@ def cpu_baseline(args):
         env.pop(k, None)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--shape", args.shape, "--dim", str(args.dim),
            "--cpu-sample-users", str(args.cpu_sample_users)]
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
-    if p.returncode != 0:
-        return {"error": "cpu baseline process failed (%d): %s" % (p.returncode, p.stderr[-400:])}
-    return json.loads(p.stdout.strip().splitlines()[-1])
+    try:        # a reported baseline must never cost the headline: every failure becomes an "error" entry
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        if p.returncode != 0:
+            return {"error": "cpu baseline process failed (%d): %s" % (p.returncode, p.stderr[-400:])}
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    except (subprocess.TimeoutExpired, ValueError, IndexError, OSError) as e:
+        return {"error": "cpu baseline: %s: %s" % (type(e).__name__, str(e)[:300])}
 
 
 def cpu_baseline_main(args):
