@@ -227,3 +227,21 @@ def test_partitioned_step_with_rccl_replays_as_one_hipgraph():
     assert len(r["ms_per_step_per_rank"]) == 1 and r["ms_per_step_per_rank"][0] > 0
     ex = r["collectives"]["exposed_ms_per_step_per_rank"]
     assert len(ex) == 1 and 0.0 <= ex[0] <= r["ms_per_step"]
+
+
+def test_bench_fails_fast_when_a_rank_cannot_start():
+    """`python bench.py --gpus 2` over RCCL on a box with ONE GPU: rank 1 has no device and exits; the launcher must stop
+    rank 0 (which would otherwise wait in the rendezvous / its first collective) and return non-zero within seconds."""
+    import time
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a single-GPU box")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SG_BENCH_BACKEND"):
+        env.pop(k, None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + COMMON, env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode != 0 and time.time() - t0 < 120
+    assert "stopping the other ranks" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]          # no result line from a broken run
