@@ -36,74 +36,14 @@
 // it is charged to this backend in every measurement.
 //
 // Epilogue / split-K contract identical to gemm_f32.hip (GemmArgs); selected by sg_gemm_f32_hip (backend 3).
-#include <type_traits>
-#include "common.hpp"
+#include "gemm_x3_shared.hpp"
 
 #include <atomic>
 #include <cstdlib>
 
 namespace sg {
 
-struct GemmArgs {   // must match gemm_f32.hip
-  float* C;
-  const float* A;
-  const float* B;
-  const float* bias;
-  float* ws;
-  long long lda, ldb, ldc;
-  int M, N, K;
-  int act;
-  float slope;
-  int accumulate;
-  int splits, tiles_per_split;
-  int tiles_m, tiles_n;
-  int vecA, vecB;
-};
-
 namespace f16x3 {
-
-constexpr int BM = 128, BN = 128;
-constexpr int UNIT = 1024;                 // bytes one wave feeds to one MFMA operand: 64 lanes x 8 halves
-constexpr int CPITCH = 68;                 // floats per row of a wave's private C staging block (32 x 64 + pad)
-constexpr int CSTAGE = 32 * CPITCH * 4;    // 8704 B per wave
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-// maximum of a NON-NEGATIVE value over the 64 lanes of a wave, returned wave-uniform.  Six DPP steps on the vector ALU
-// (xor 1, xor 2 inside quads, mirrors inside 8 and 16 lanes, then lane 15 / 31 broadcasts into the following rows: lane 63
-// ends up with the maximum) instead of six dependent ds_bpermute round trips through the LDS pipe (~100+ cycles each
-// under load, and each `s_waitcnt lgkmcnt(0)` also waits for every other LDS operation of the wave).  fmaxf drops NaNs,
-// as the shuffle form did.
-__device__ __forceinline__ float wave_max_nonneg(float v) {
-  auto step = [&](auto ctrl, auto row_mask) __attribute__((always_inline)) {
-    const int y = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), decltype(ctrl)::value,
-                                              decltype(row_mask)::value, 0xf, false);
-    v = fmaxf(v, __int_as_float(y));
-  };
-  using std::integral_constant;
-  step(integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});     // quad_perm [1,0,3,2]
-  step(integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});     // quad_perm [2,3,0,1]
-  step(integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});    // row_half_mirror
-  step(integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});    // row_mirror: every lane holds its row's maximum
-  step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});    // row_bcast:15 into rows 1 and 3
-  step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});    // row_bcast:31 into rows 2 and 3
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-
-__device__ __forceinline__ float act_fn(float v, int act, float slope) {
-  switch (act) {
-    case SG_ACT_LEAKY: return v > 0.f ? v : slope * v;
-    case SG_ACT_RELU: return v > 0.f ? v : 0.f;
-    case SG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-    case SG_ACT_TANH: return tanhf(v);
-    default: return v;
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // split: fp32 operand -> fragment-major f16 planes.  16-byte unit u(rb, ks, plane, lane) = ((rb*KS + ks)*2 + plane)*64 + lane
@@ -222,13 +162,6 @@ __global__ __launch_bounds__(256) void split_kernel(char* __restrict__ planes, i
 // ---------------------------------------------------------------------------------------------------------------------
 // the GEMM on planes
 // ---------------------------------------------------------------------------------------------------------------------
-struct PlaneArgs {
-  const char* pa;
-  const char* pb;
-  const int* exp_a;     // -log2(scale) of block (32-row block rb, 64-k block kb) at [rb * (KS / 4) + kb]
-  const int* exp_b;
-  int KS;               // 16-k steps per row block = Kp / 16 (a multiple of 4)
-};
 
 #ifndef SG_X3_ABLATE
 #define SG_X3_ABLATE 0      // development (timing only): 1 no MFMAs, 2 no fragment reads, 3 no DMA
@@ -259,21 +192,6 @@ __device__ unsigned long long g_x3_timing[6];
 #else
 #define X3_T(var)
 #endif
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
-typedef const __attribute__((address_space(4))) int cst_int;      // constant address space: scalar (s_load) access
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {      // counted wait on this wave's own LDS-DMA / global loads
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else static_assert(N == 0, "add the immediate");
-}
-
 // ---- epilogue shared by the kernels: one 64 x 64 wave tile (2 x 2 MFMA tiles).  TRANSPOSED: the product was formed with
 // the operands swapped (rows of this tile are COLUMNS of C); it is written as C^T into `out` (leading dimension ldo) and a
 // small pass transposes it afterwards -- used for weight gradients, whose C is a few MB.
@@ -1011,6 +929,8 @@ size_t f16x3_plane_bytes(long long M, long long N, long long K) {
          (M <= 256 ? align256(static_cast<size_t>(M) * N * 4) : 0);       // C^T of a swapped-operand product
 }
 
+void launch_x3w_planes(const GemmArgs& g, const f16x3::PlaneArgs& pl, int dev_variant, hipStream_t st);      // gemm_x3w.hip
+
 static std::atomic<int> g_x3_variant_override{-1};
 static int x3_variant() {      // tuning aid: SG_X3_VARIANT / sg_gemm_x3_variant = 0 auto, 1 <2,2,2>, 2 <2,1,5>, 3 <4,2,3>,
                                // 4 never hybrid, 5 hybrid at any size, 9 hybrid at any size with ONE K tile of A in flight (round-3 first form)
@@ -1150,8 +1070,14 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
   // workgroup and the 256-row geometries on every plane-path shape by 4-14 %: the third workgroup's matrix work fills the
   // barrier / DMA-wait gaps of the other two
   (void)slice;
-  int v = ((variant >= 1 && variant <= 3) || variant == 6 || variant == 7) ? variant : 6;
-  if (v == 3) {
+  int v = ((variant >= 1 && variant <= 3) || variant == 6 || variant == 7 || variant >= 10) ? variant : 6;
+  if (v >= 10) {              // 256 x 256 tiles, eight waves, one workgroup per CU (gemm_x3w.hip)
+    g.tiles_m = static_cast<int>((g.M + 255) / 256);
+    g.tiles_n = static_cast<int>((g.N + 255) / 256);
+    fit_splits(static_cast<long long>(g.tiles_m) * g.tiles_n, 256);
+    *splits_used = g.splits;
+    launch_x3w_planes(g, pl, v - 10, st);
+  } else if (v == 3) {
     g.tiles_m = static_cast<int>((g.M + 255) / 256);
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
     hipLaunchKernelGGL((gemm_f16x3_kernel<4, 2, 3>), dim3(static_cast<unsigned>(items)), dim3(512), 0, st, g, pl);
@@ -1173,7 +1099,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
 }  // namespace sg
 
 SG_API int sg_gemm_x3_variant(int variant) {
-  sg::g_x3_variant_override.store(variant < 0 || variant > 9 ? -1 : variant, std::memory_order_relaxed);
+  sg::g_x3_variant_override.store(variant < 0 || variant > 40 ? -1 : variant, std::memory_order_relaxed);
   return SG_OK;
 }
 
