@@ -930,6 +930,7 @@ size_t f16x3_plane_bytes(long long M, long long N, long long K) {
 }
 
 void launch_x3w_planes(const GemmArgs& g, const f16x3::PlaneArgs& pl, int dev_variant, hipStream_t st);      // gemm_x3w.hip
+void launch_x3w_hybrid(const GemmArgs& g, const f16x3::PlaneArgs& pl, bool arc, hipStream_t st);
 
 static std::atomic<int> g_x3_variant_override{-1};
 static int x3_variant() {      // tuning aid: SG_X3_VARIANT / sg_gemm_x3_variant = 0 auto, 1 <2,2,2>, 2 <2,1,5>, 3 <4,2,3>,
@@ -1019,7 +1020,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     g.tiles_per_split = per;
     g.splits = (ktiles + per - 1) / per;
   };
-  const long long big = (variant == 5 || variant == 9) ? 0 : 16ll << 20;  // elements: a 64 MB operand is worth keeping out of a split pass
+  const long long big = (variant == 5 || variant == 9 || variant == 40) ? 0 : 16ll << 20;  // elements: a 64 MB operand is worth keeping out of a split pass
   // A may stay fp32 when its layout allows the in-kernel loads (K-contiguous rows need 16-byte vectors)
   const bool a_fly_ok = transA || (g.vecA && g.K % 4 == 0 && g.K >= 4);
   const bool b_fly_ok = !transB || (g.vecB && g.K % 4 == 0 && g.K >= 4);
@@ -1028,17 +1029,27 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     // ---- hybrid: A fp32 in the kernel, B planes ----
     split(pb, eb, g.B, g.ldb, !transB, g.N, Np, g.vecB);
     PlaneArgs pl{nullptr, pb, nullptr, eb, KS};
+    const bool av4 = transA && g.vecA && g.M % 4 == 0;
+    if (variant == 40 && (!transA || av4)) {           // 256 x 256 tiles, eight waves (gemm_x3w.hip)
+      g.tiles_m = static_cast<int>((g.M + 255) / 256);
+      g.tiles_n = static_cast<int>((g.N + 255) / 256);
+      fit_splits(static_cast<long long>(g.tiles_m) * g.tiles_n, 256);
+      *splits_used = g.splits;
+      launch_x3w_hybrid(g, pl, transA, st);
+      return SG_OK;
+    }
     g.tiles_m = tm128;
     fit_splits(static_cast<long long>(g.tiles_m) * g.tiles_n, 512);
     *splits_used = g.splits;
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
-    launch_hybrid(g, pl, items, transA, transA && g.vecA && g.M % 4 == 0, variant == 9 ? 1 : 2, st);
+    launch_hybrid(g, pl, items, transA, av4, variant == 9 ? 1 : 2, st);
     return SG_OK;
   }
   if (variant != 4 && tm128 <= 2 && g.M <= 256 && static_cast<long long>(g.N) * g.K >= big && b_fly_ok && plain_epi) {
     // ---- swapped hybrid: C^T = op(B)^T op(A)^T with op(B)^T (the huge operand) fp32 in the kernel, op(A)^T as planes ----
     split(pa, ea, g.A, g.lda, transA, g.M, Mp, g.vecA);              // planes of op(A): rows m, K-contiguous units
-    fit_splits(static_cast<long long>(tn128) * tm128, 512);
+    if (variant == 40) fit_splits(static_cast<long long>((g.N + 255) / 256) * ((g.M + 255) / 256), 256);
+    else fit_splits(static_cast<long long>(tn128) * tm128, 512);
     GemmArgs h = g;
     h.M = g.N; h.N = g.M;
     h.A = g.B; h.lda = g.ldb; h.vecA = g.vecB;
@@ -1048,7 +1059,13 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     PlaneArgs pl{nullptr, pa, nullptr, ea, KS};
     const long long items = static_cast<long long>(h.tiles_m) * h.tiles_n * h.splits;
     // op(B)^T element (n, k): B stored (K x N) when !transB -> row-contiguous in n (ARC); (N x K) when transB -> K-contiguous
-    launch_hybrid(h, pl, items, !transB, !transB && h.vecA && h.M % 4 == 0, variant == 9 ? 1 : 2, st);
+    const bool hav4 = !transB && h.vecA && h.M % 4 == 0;
+    if (variant == 40 && (transB || hav4)) {
+      h.tiles_m = static_cast<int>((h.M + 255) / 256);
+      h.tiles_n = static_cast<int>((h.N + 255) / 256);
+      launch_x3w_hybrid(h, pl, !transB, st);
+    } else
+    launch_hybrid(h, pl, items, !transB, hav4, variant == 9 ? 1 : 2, st);
     const long long total = static_cast<long long>(g.M) * g.N;
     if (g.splits > 1) {
       hipLaunchKernelGGL(reduce_t_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, g.C, g.ldc, g.ws,

@@ -76,6 +76,8 @@ struct PlaneArgs {
   const int* exp_a;     // -log2(scale) of block (32-row block rb, 64-k block kb) at [rb * (KS / 4) + kb]
   const int* exp_b;
   int KS;               // 16-k steps per row block = Kp / 16 (a multiple of 4)
+  int* flag;            // gemm_x3w.hip, direct-accumulation kernels: raised when a scale block lies too far below the running
+                        // scale for the rescale form to be exact -- the launcher's fallback kernel then redoes the product
 };
 
 typedef __attribute__((address_space(3))) void lds_void;

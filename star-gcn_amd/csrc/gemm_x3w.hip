@@ -611,6 +611,301 @@ __global__ __launch_bounds__(512, 1) void gemm_x3d_kernel(const GemmArgs g, cons
   store_wave_tile(g, acc, smem, wave, lane, tm * 256 + wm * 128, tn * 256 + wn * 64, z);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Hybrid, 256 x 256: op(A) stays fp32 in memory and is split INSIDE the kernel (gemm_f16x3.hip, gemm_f16x3h_kernel, for the
+// reasons), op(B) comes as planes by LDS-DMA; direct accumulation as in gemm_x3d_kernel.  Each of the eight waves converts
+// ONE 32-row x 32-k block of the next K tile per tile (the 128 x 128 form converts one per 24 matrix instructions, this one
+// per 48, and with N <= 256 an A block is converted once, not once per column tile).  Per K tile kt:
+//   phases 0-2   matrix work on tile kt; B's planes of tile kt+2 arrive by DMA (issued behind barrier kt-1 .. phase 0)
+//   end of ph 2  vmcnt(0): A's fp32 block of tile kt+1 (requested one tile ago) is here -> block maximum (DPP) -> exponent
+//                (kept from the last tile while the maximum still fits: fewer rescales) -> two f16 planes -> LDS, stage (kt+1)&1
+//   phase 3      barrier kt: tile kt+1 is complete and tile kt's B stage is free; request A's block of tile kt+2, read
+//                tile kt+1's first fragments and exponents while the last matrix instructions of tile kt run
+// A's scale block is 32 x 32 (one K tile), B's 32 x 64.  LDS: 2 x 32 KiB of A planes + 2 x 32 KiB of B planes + exponents.
+// ARC = false: A element (m, k) at A[m * lda + k] (K % 4 == 0, 16-byte aligned rows); ARC = true: at A[k * lda + m] with
+// M % 4 == 0 and 16-byte aligned k rows (float4 loads along m, register transpose).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int H_SMEM = 4 * WSTG + 64;
+
+template <bool ARC>
+__global__ __launch_bounds__(512, 1) void gemm_x3dh_kernel(const GemmArgs g, const PlaneArgs pl) {
+  __shared__ __attribute__((aligned(1024))) char smem[H_SMEM];
+  int* exp_lds = reinterpret_cast<int*>(smem + 4 * WSTG);               // [stage][row block]
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nt = g.tiles_m * g.tiles_n;
+  const int item = blockIdx.x;
+  const int z = item / nt, lin = item - z * nt;
+  const int q8 = nt >> 3, r8 = nt & 7, x8 = lin & 7;
+  const int tile = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (lin >> 3);
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int ktiles = (g.K + 31) / 32;
+  const int kt0 = z * g.tiles_per_split, kt1e = min(ktiles, kt0 + g.tiles_per_split);
+  const int T = kt1e - kt0;                            // 32-k tiles of this slice (>= 1)
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // ---- B planes by DMA: wave w moves row block w of B's tile (4 KiB per K tile) ----
+  const long long rb_stride = static_cast<long long>(pl.KS) * 2 * UNIT;
+  const char* b_src = pl.pb + (static_cast<long long>(tn) * 8 + wave) * rb_stride + static_cast<long long>(kt0) * (4 * UNIT) + lane * 16;
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_void*)smem));
+  const unsigned b_dst = lds0 + 2 * WSTG + wave * 4 * UNIT;
+  auto issue_b = [&](int kt, int part) __attribute__((always_inline)) {
+    const int ktc = min(kt, T - 1);                    // past the end: a harmless re-load of the last tile
+    dma_unit(b_src + static_cast<long long>(ktc) * (4 * UNIT) + part * UNIT, b_dst + (kt & 1) * WSTG + part * UNIT);
+  };
+
+  // ---- A: this wave's 32-row block of a K tile, 16 fp32 per lane, loaded unconditionally from clamped coordinates ----
+  const int m_blk = tm * 256 + wave * 32;
+  f32x4 va[4];
+  auto load_a = [&](int kt_in) __attribute__((always_inline)) {
+    const int k0 = (kt0 + min(kt_in, T - 1)) * 32;
+    if (!ARC) {           // lane = (row lane / 8 + 8 i, k = 4 (lane % 8) .. + 3)
+      const int k = min(k0 + (lane & 7) * 4, g.K - 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = min(m_blk + (lane >> 3) + 8 * i, g.M - 1);
+        va[i] = *reinterpret_cast<const f32x4*>(g.A + static_cast<long long>(row) * g.lda + k);
+      }
+    } else {              // lane = (4 op rows m = 4 (lane % 8) .., k = 4 (lane / 8) + i): 128-byte k-row segments
+      const int m = min(m_blk + (lane & 7) * 4, g.M - 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = min(k0 + (lane >> 3) * 4 + i, g.K - 1);
+        va[i] = *reinterpret_cast<const f32x4*>(g.A + static_cast<long long>(k) * g.lda + m);
+      }
+    }
+  };
+  int e_keep = 1 << 20;                                  // exponent of this wave's previous block (none yet)
+  auto store_a = [&](int kt) __attribute__((always_inline)) {      // convert va (tile kt), planes + exponent into stage kt & 1
+    const int k0 = (kt0 + kt) * 32;
+    float x[16];
+    float mx = 0.f;
+    if (!ARC) {
+      const bool kdead = k0 + (lane & 7) * 4 >= g.K;       // K % 4 == 0: a float4 is in or out as a whole
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool dead = kdead || (m_blk + (lane >> 3) + 8 * i >= g.M);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[4 * i + j] = dead ? 0.f : va[i][j]; mx = fmaxf(mx, fabsf(x[4 * i + j])); }
+      }
+    } else {              // transpose in registers: x[4 j + i] = (m j, k i) -> four consecutive k per op row
+      const bool mdead = m_blk + (lane & 7) * 4 >= g.M;       // M % 4 == 0: four rows are in or out together
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool dead = mdead || (k0 + (lane >> 3) * 4 + i >= g.K);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[4 * j + i] = dead ? 0.f : va[i][j]; mx = fmaxf(mx, fabsf(x[4 * j + i])); }
+      }
+    }
+    mx = wave_max_nonneg(mx);
+    bool nonfinite = false;
+    if (__builtin_expect(!(mx <= 3.402823466e38f), 0)) {      // wave-uniform, rare: an inf in the block -- see split_kernel
+      nonfinite = true;
+      float mf = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float a = fabsf(x[i]); mf = fmaxf(mf, a <= 3.402823466e38f ? a : 0.f); }
+      mx = wave_max_nonneg(mf);
+    }
+    int e = 0;
+    {
+      const unsigned bits = __float_as_uint(mx);
+      const int ex = static_cast<int>((bits >> 23) & 0xffu);
+      if (bits != 0u && ex != 0xff) e = 14 - (max(ex, 1) - 127);
+      e = min(max(e, -126), 126);
+      // the last block's scale is kept while this block's maximum still lands in [2^12, 2^15) under it (and always for an
+      // all-zero block): two bits of the residual plane's range against a rescale of the running results in all eight waves
+      if (bits == 0u || (e - e_keep >= 0 && e - e_keep <= 2)) e = e_keep == (1 << 20) ? e : e_keep;
+      e_keep = e;
+    }
+    const float sc = __uint_as_float(static_cast<unsigned>(127 + e) << 23);
+    unsigned h1[8], h2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x2 v = {x[2 * j] * sc, x[2 * j + 1] * sc};
+      const f16x2 a = __builtin_convertvector(v, f16x2);
+      f32x2 res = {__builtin_fmaf(x[2 * j], sc, -static_cast<float>(a[0])), __builtin_fmaf(x[2 * j + 1], sc, -static_cast<float>(a[1]))};
+      if (nonfinite) {    // wave-uniform: an inf keeps a zero residual (inf - inf = NaN would poison the product's inf)
+        if (fabsf(v[0]) == __builtin_inff()) res[0] = 0.f;
+        if (fabsf(v[1]) == __builtin_inff()) res[1] = 0.f;
+      }
+      const f16x2 b = __builtin_convertvector(res, f16x2);
+      h1[j] = __builtin_bit_cast(unsigned, a);
+      h2[j] = __builtin_bit_cast(unsigned, b);
+    }
+    // 4 consecutive k of row r: half a 16-byte slot of unit (ks, plane), lane slot kg * 32 + r
+    char* st = smem + (kt & 1) * WSTG + wave * (4 * UNIT);
+    const int kq = ARC ? (lane >> 3) : (lane & 7);
+    const int off = ((kq >> 2) * 2) * UNIT + (((kq >> 1) & 1) * 32) * 16 + (kq & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = ARC ? (lane & 7) * 4 + i : (lane >> 3) + 8 * i;
+      *reinterpret_cast<uint2*>(st + off + r * 16) = make_uint2(h1[2 * i], h1[2 * i + 1]);
+      *reinterpret_cast<uint2*>(st + off + UNIT + r * 16) = make_uint2(h2[2 * i], h2[2 * i + 1]);
+    }
+    if (lane == 0) exp_lds[(kt & 1) * 8 + wave] = -e;
+  };
+
+  // ---- fragments ----
+  const char* a_frag0 = smem + wm * 16 * UNIT + lane * 16;                      // + stage * WSTG + (i * 4 + ks * 2 + plane) * UNIT
+  const char* b_frag0 = smem + 2 * WSTG + wn * 8 * UNIT + lane * 16;            // + stage * WSTG + (j * 4 + ks * 2 + plane) * UNIT
+  f16x8 aF[2][2][2];       // [buffer][k step][plane]
+  f16x8 bF[2][2][2][2];    // [tile parity][k step][j][plane]
+  auto read_a = [&](int buf, int st, int i) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        aF[buf][ks][p] = *reinterpret_cast<const f16x8*>(a_frag0 + st * WSTG + (i * 4 + ks * 2 + p) * UNIT);
+  };
+  auto read_b = [&](int set, int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          bF[set][ks][j][p] = *reinterpret_cast<const f16x8*>(b_frag0 + st * WSTG + (j * 4 + ks * 2 + p) * UNIT);
+  };
+
+  // B's block exponents: lane l of ebV holds 64-k block c0 + l of the current chunk (see gemm_x3w_kernel)
+  const int kbs = pl.KS >> 2;
+  const int kb0 = kt0 >> 1;                            // first 64-k block this slice touches (a slice may start mid-block)
+  const int nkb = ((kt0 + T + 1) >> 1) - kb0;
+  int ebV[2];
+  auto load_eb = [&](int c0) __attribute__((always_inline)) {
+    const int kbl = min(c0 + lane, nkb - 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ebV[j] = pl.exp_b[static_cast<long long>(tn * 8 + wn * 2 + j) * kbs + kb0 + kbl];
+    asm volatile("" : : "v"(ebV[0]), "v"(ebV[1]) : "memory");
+  };
+
+  // ---- prologue ----
+#pragma unroll
+  for (int p = 0; p < 4; ++p) issue_b(0, p);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) issue_b(1, p);
+  load_a(0);
+  load_eb(0);                                           // the compiler's vmcnt(0) for these loads also covers A's tile 0 and the DMA
+  store_a(0);
+  load_a(1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wait_vm<4>();                                         // B's tile 0 has landed (tile 1 and A's tile 1 may be in flight)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_b(0, 0);
+  read_a(0, 0, 0);
+  int ea_v[4];                                          // exponents of the current tile's four A row blocks (uniform values in VGPRs)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ea_v[i] = exp_lds[wm * 4 + i];
+
+  int E[4][2], Mx[4][2];   // scale exponent the running result of tile (i, j) is held in; largest so far
+  int viol = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { E[i][j] = 0; Mx[i][j] = -(1 << 20); }
+
+  auto body = [&](int kt, auto par) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par)::value;           // kt & 1: LDS stage and B fragment set of this tile
+    // ---- this tile's scales: rescale the running results whose scale changes (rare with the kept exponents) ----
+    const int kl = (((kt0 + kt) >> 1) - kb0) & 63;
+    int e[4][2];
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ea = __builtin_amdgcn_readfirstlane(ea_v[i]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        e[i][j] = ea + __builtin_amdgcn_readlane(ebV[j], kl);
+        any = any || (e[i][j] != E[i][j]);
+      }
+    }
+    if (any) {                                          // wave-uniform
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          Mx[i][j] = max(Mx[i][j], e[i][j]);
+          viol |= (Mx[i][j] - e[i][j] > 60) ? 1 : 0;    // a block 2^60 below the running scale: the fallback kernel redoes the product
+          const int d = kt == 0 ? 0 : min(E[i][j] - e[i][j], 60);
+          const float f = d >= -126 ? __uint_as_float(static_cast<unsigned>(127 + d) << 23) : 0.f;
+          E[i][j] = e[i][j];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[i][j][q] *= f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < 3) {
+        read_a((i + 1) & 1, PAR, i + 1);
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my plane stores and every fragment read of tile kt
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_a(kt + 2);
+        read_a(0, PAR ^ 1, 0);
+        read_b(PAR ^ 1, PAR ^ 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ea_v[q] = exp_lds[(PAR ^ 1) * 8 + wm * 4 + q];
+      }
+      const f16x8 (&a)[2][2] = aF[i & 1];
+      const f16x8 (&b)[2][2][2] = bF[PAR];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][1], b[ks][j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][0], b[ks][j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks][0], b[ks][j][0], acc[i][j], 0, 0, 0);
+        if (ks == 0) {
+          asm volatile("" ::: "memory");
+          // B's tile kt+2 into the stage tile kt uses: free behind this tile's barrier (phase 3), two DMA there, two in phase 0
+          if (i == 3) { issue_b(kt + 2, 0); issue_b(kt + 2, 1); }
+          else if (i == 0) { issue_b(kt + 1, 2); issue_b(kt + 1, 3); }
+          asm volatile("" ::: "memory");
+        }
+      }
+      if (i == 2) {
+        // A's block of tile kt+1 (requested a tile ago) and B's tile kt+1 have had ~a tile to land
+        asm volatile("" ::: "memory");
+        store_a(kt + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+  };
+  // prologue issued all four parts of B's tiles 0 and 1: the phase-0 slot of tile 0 re-loads two parts of tile 1 (harmless)
+  for (int c0 = 0; c0 < nkb; c0 += 64) {
+    if (c0 > 0) load_eb(c0);
+    const int kt_lo = max(0, (kb0 + c0) * 2 - kt0), kt_hi = min(T, (kb0 + c0 + 64) * 2 - kt0);
+    int kt = kt_lo;
+    if (kt < kt_hi && (kt & 1)) { body(kt, std::integral_constant<int, 1>{}); ++kt; }
+    for (; kt + 1 < kt_hi; kt += 2) {
+      body(kt, std::integral_constant<int, 0>{});
+      body(kt + 1, std::integral_constant<int, 1>{});
+    }
+    if (kt < kt_hi) body(kt, std::integral_constant<int, 0>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (viol && pl.flag && lane == 0) atomicOr(pl.flag, 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = ldexpf(acc[i][j][e], E[i][j]);
+  __syncthreads();
+  store_wave_tile(g, acc, smem, wave, lane, tm * 256 + wm * 128, tn * 256 + wn * 64, z);
+}
+
 }  // namespace f16x3
 
 // g.tiles_m / g.tiles_n count 256-wide tiles; the planes and exponents are those of gemm_f16x3.hip's split_kernel
@@ -643,6 +938,13 @@ void launch_x3w_planes(const GemmArgs& g, const f16x3::PlaneArgs& pl, int dev_va
     case 29: hipLaunchKernelGGL((gemm_x3d_kernel<64>), grid, block, 0, st, g, pl); break;
     default: hipLaunchKernelGGL((gemm_x3w_kernel<0, 0>), grid, block, 0, st, g, pl); break;
   }
+}
+
+void launch_x3w_hybrid(const GemmArgs& g, const f16x3::PlaneArgs& pl, bool arc, hipStream_t st) {
+  const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
+  const dim3 grid(static_cast<unsigned>(items)), block(512);
+  if (arc) hipLaunchKernelGGL((f16x3::gemm_x3dh_kernel<true>), grid, block, 0, st, g, pl);
+  else hipLaunchKernelGGL((f16x3::gemm_x3dh_kernel<false>), grid, block, 0, st, g, pl);
 }
 
 }  // namespace sg
