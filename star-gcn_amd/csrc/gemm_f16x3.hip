@@ -930,7 +930,31 @@ size_t f16x3_plane_bytes(long long M, long long N, long long K) {
 }
 
 void launch_x3w_planes(const GemmArgs& g, const f16x3::PlaneArgs& pl, int dev_variant, hipStream_t st);      // gemm_x3w.hip
-void launch_x3w_hybrid(const GemmArgs& g, const f16x3::PlaneArgs& pl, bool arc, hipStream_t st);
+void launch_x3w_hybrid(const GemmArgs& g, const f16x3::PlaneArgs& pl, bool arc, int persistent_ctas, int skew, hipStream_t st);
+
+// the persistent kernel's stream looks two K tiles ahead: every K slice must hold at least two 32-k tiles
+static bool wide_slices_ok(const GemmArgs& g) {
+  const int ktiles = (g.K + 31) / 32;
+  if (g.splits <= 1) return ktiles >= 2;
+  return g.tiles_per_split >= 2 && ktiles - (g.splits - 1) * g.tiles_per_split >= 2;
+}
+
+// start skew of the persistent kernel in cycles (one item's duration, so that the eight classes spread over it): only when
+// a workgroup has enough items for the late start to be noise and the item is short enough for its store burst to matter
+static int wide_skew(const GemmArgs& g, int variant) {
+  if (variant == 44) return -1;      // development (timing only): no global stores in the epilogue
+  if (variant == 45) return -2;      // development (timing only): no epilogue
+  if (variant == 48) return -5;      // development (timing only): stores into an L2-resident region
+  if (variant == 46) return -3;      // development: plain instead of non-temporal stores
+  if (variant == 47) return -4;      // development: plain stores + start skew
+  if (variant != 42 && variant != 43) return 0;
+  const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
+  const int ktiles = (g.K + 31) / 32;
+  const int T = g.splits > 1 ? g.tiles_per_split : ktiles;
+  if (items < 256 * 4) return 0;
+  const long long cyc = static_cast<long long>(T) * 6000 + 24000;
+  return static_cast<int>(cyc > (1 << 22) ? (1 << 22) : cyc) * (variant == 43 ? 2 : 1);
+}
 
 static std::atomic<int> g_x3_variant_override{-1};
 static int x3_variant() {      // tuning aid: SG_X3_VARIANT / sg_gemm_x3_variant = 0 auto, 1 <2,2,2>, 2 <2,1,5>, 3 <4,2,3>,
@@ -1020,22 +1044,24 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     g.tiles_per_split = per;
     g.splits = (ktiles + per - 1) / per;
   };
-  const long long big = (variant == 5 || variant == 9 || variant == 40) ? 0 : 16ll << 20;  // elements: a 64 MB operand is worth keeping out of a split pass
+  const long long big = (variant == 5 || variant == 9 || (variant >= 40 && variant <= 48)) ? 0 : 16ll << 20;  // elements: a 64 MB operand is worth keeping out of a split pass
   // A may stay fp32 when its layout allows the in-kernel loads (K-contiguous rows need 16-byte vectors)
   const bool a_fly_ok = transA || (g.vecA && g.K % 4 == 0 && g.K >= 4);
   const bool b_fly_ok = !transB || (g.vecB && g.K % 4 == 0 && g.K >= 4);
   const bool plain_epi = !g.bias && g.act == SG_ACT_NONE && !g.accumulate;
-  if (variant != 4 && tn128 <= 2 && static_cast<long long>(g.M) * g.K >= big && a_fly_ok) {
+  const bool swap_ok = tm128 <= 2 && g.M <= 256 && static_cast<long long>(g.N) * g.K >= big && b_fly_ok && plain_epi;
+  if (variant != 4 && (tn128 <= 2 || (variant >= 41 && variant <= 48 && !(swap_ok && g.N > g.M))) &&
+      static_cast<long long>(g.M) * g.K >= big && a_fly_ok) {
     // ---- hybrid: A fp32 in the kernel, B planes ----
     split(pb, eb, g.B, g.ldb, !transB, g.N, Np, g.vecB);
     PlaneArgs pl{nullptr, pb, nullptr, eb, KS};
     const bool av4 = transA && g.vecA && g.M % 4 == 0;
-    if (variant == 40 && (!transA || av4)) {           // 256 x 256 tiles, eight waves (gemm_x3w.hip)
+    if ((variant >= 40 && variant <= 48) && (!transA || av4)) {           // 256 x 256 tiles, eight waves (gemm_x3w.hip)
       g.tiles_m = static_cast<int>((g.M + 255) / 256);
       g.tiles_n = static_cast<int>((g.N + 255) / 256);
       fit_splits(static_cast<long long>(g.tiles_m) * g.tiles_n, 256);
       *splits_used = g.splits;
-      launch_x3w_hybrid(g, pl, transA, st);
+      launch_x3w_hybrid(g, pl, transA, (variant >= 41 && wide_slices_ok(g)) ? 256 : 0, wide_skew(g, variant), st);
       return SG_OK;
     }
     g.tiles_m = tm128;
@@ -1048,7 +1074,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
   if (variant != 4 && tm128 <= 2 && g.M <= 256 && static_cast<long long>(g.N) * g.K >= big && b_fly_ok && plain_epi) {
     // ---- swapped hybrid: C^T = op(B)^T op(A)^T with op(B)^T (the huge operand) fp32 in the kernel, op(A)^T as planes ----
     split(pa, ea, g.A, g.lda, transA, g.M, Mp, g.vecA);              // planes of op(A): rows m, K-contiguous units
-    if (variant == 40) fit_splits(static_cast<long long>((g.N + 255) / 256) * ((g.M + 255) / 256), 256);
+    if (variant >= 40 && variant <= 48) fit_splits(static_cast<long long>((g.N + 255) / 256) * ((g.M + 255) / 256), 256);
     else fit_splits(static_cast<long long>(tn128) * tm128, 512);
     GemmArgs h = g;
     h.M = g.N; h.N = g.M;
@@ -1060,10 +1086,10 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     const long long items = static_cast<long long>(h.tiles_m) * h.tiles_n * h.splits;
     // op(B)^T element (n, k): B stored (K x N) when !transB -> row-contiguous in n (ARC); (N x K) when transB -> K-contiguous
     const bool hav4 = !transB && h.vecA && h.M % 4 == 0;
-    if (variant == 40 && (transB || hav4)) {
+    if ((variant >= 40 && variant <= 48) && (transB || hav4)) {
       h.tiles_m = static_cast<int>((h.M + 255) / 256);
       h.tiles_n = static_cast<int>((h.N + 255) / 256);
-      launch_x3w_hybrid(h, pl, !transB, st);
+      launch_x3w_hybrid(h, pl, !transB, (variant >= 41 && wide_slices_ok(h)) ? 256 : 0, wide_skew(h, variant), st);
     } else
     launch_hybrid(h, pl, items, !transB, hav4, variant == 9 ? 1 : 2, st);
     const long long total = static_cast<long long>(g.M) * g.N;
@@ -1116,7 +1142,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
 }  // namespace sg
 
 SG_API int sg_gemm_x3_variant(int variant) {
-  sg::g_x3_variant_override.store(variant < 0 || variant > 40 ? -1 : variant, std::memory_order_relaxed);
+  sg::g_x3_variant_override.store(variant < 0 || variant > 60 ? -1 : variant, std::memory_order_relaxed);
   return SG_OK;
 }
 

@@ -163,7 +163,9 @@ int main(int argc, char** argv) {
         {512, 768, 8256, 0, 1, "129 blocks (two exponent chunks)"}, {1000, 76, 252, 0, 1, "narrow"}, {5, 300, 1028, 0, 1, "short M"},
         {200, 130, 40000, 1, 0, "split-K"}, {2304, 2560, 256, 0, 1, "many tiles"},
         {3000, 256, 128, 0, 1, "hybrid NT"}, {3000, 200, 2052, 0, 0, "hybrid NN"}, {1028, 256, 3000, 1, 0, "hybrid TN (row-contiguous A)"},
-        {96, 2000, 40004, 1, 0, "swapped hybrid"}, {256, 4160, 20000, 1, 0, "swapped hybrid, dWext-like"}, {700, 130, 100, 0, 1, "hybrid, odd tile count"}};
+        {96, 2000, 40004, 1, 0, "swapped hybrid"}, {256, 4160, 20000, 1, 0, "swapped hybrid, dWext-like"}, {700, 130, 100, 0, 1, "hybrid, odd tile count"},
+        {153600, 256, 256, 0, 1, "600 items"}, {70000, 300, 160, 0, 0, "548 items, 5 tiles each"}, {76800, 256, 8260, 0, 1, "300 items, two chunks"},
+        {2052, 70000, 96, 1, 0, "2200 items, TN"}, {256, 4160, 100000, 1, 0, "swapped, split-K"}};
     for (const Case& c : cases)
       for (int v : variants) {
         const bool full = static_cast<double>(c.M) * c.N * c.K < 2e8;
