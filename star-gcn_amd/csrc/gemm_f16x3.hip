@@ -39,6 +39,7 @@
 #include "gemm_x3_shared.hpp"
 
 #include <atomic>
+#include <cmath>
 #include <cstdlib>
 
 namespace sg {
@@ -52,10 +53,12 @@ namespace f16x3 {
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool RC>
 __global__ __launch_bounds__(256) void split_kernel(char* __restrict__ planes, int* __restrict__ expo,
-                                                    const float* __restrict__ p, long long ld, int R, int K, int KS, int vec) {
+                                                    const float* __restrict__ p, long long ld, int R, int K, int KS, int vec,
+                                                    int* __restrict__ clear_flag) {
   __shared__ float tile[32][65];
   __shared__ float wmax[4];
   const int t = threadIdx.x;
+  if (clear_flag && t == 0 && blockIdx.x == 0 && blockIdx.y == 0) *clear_flag = 0;      // the exactness flag of gemm_x3w.hip
   const int rb = blockIdx.x, k0 = blockIdx.y * 64;
   const int r0 = rb * 32;
   float m = 0.f;
@@ -591,6 +594,8 @@ __global__ __launch_bounds__(128 * WM, MINW) void gemm_f16x3_kernel(const GemmAr
 template <bool ARC, bool AV4 = false, int APF = 1>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3h_kernel(const GemmArgs g, const PlaneArgs pl) {
   static_assert(APF == 1 || APF == 2, "one or two K tiles of A in flight");
+  // launched as the FALLBACK of the 256-wide kernel (gemm_x3w.hip): nothing to do unless that kernel raised the flag
+  if (pl.flag != nullptr && *reinterpret_cast<const volatile int*>(pl.flag) == 0) return;
   constexpr int UPB = 4, RBA = 4, STAGE_B = 32 * UNIT;      // per stage: A units 0..15, B units 16..31
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B + 64];
   int* exp_lds = reinterpret_cast<int*>(smem + 2 * STAGE_B);               // [stage][row block]
@@ -926,11 +931,28 @@ size_t f16x3_plane_bytes(long long M, long long N, long long K) {
   const long long Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + 63) / 64 * 64;
   return align256(static_cast<size_t>(Mp) * Kp * 4) + align256(static_cast<size_t>(Np) * Kp * 4) +
          align256(static_cast<size_t>(Mp / 32) * (Kp / 64) * 4) + align256(static_cast<size_t>(Np / 32) * (Kp / 64) * 4) +
-         (M <= 256 ? align256(static_cast<size_t>(M) * N * 4) : 0);       // C^T of a swapped-operand product
+         (M <= 256 ? align256(static_cast<size_t>(M) * N * 4) : 0) +     // C^T of a swapped-operand product
+         256;                                                             // the exactness flag of the 256-wide kernel
 }
 
-void launch_x3w_planes(const GemmArgs& g, const f16x3::PlaneArgs& pl, int dev_variant, hipStream_t st);      // gemm_x3w.hip
-void launch_x3w_hybrid(const GemmArgs& g, const f16x3::PlaneArgs& pl, bool arc, int persistent_ctas, int skew, hipStream_t st);
+void launch_x3w_hybrid(const GemmArgs& g, const f16x3::PlaneArgs& pl, bool arc, int ctas, hipStream_t st);      // gemm_x3w.hip
+
+constexpr int kWideCtas = 256;      // workgroups of the persistent 256-wide kernel: one per CU of an MI355X
+
+// Does the 256-wide persistent kernel pay?  The chip is power-bound on these kernels: a launch that fills only half the CUs
+// runs them at a higher clock and finishes the same work in about the same time (4096 x 256 x 1 M as 128 items on 256 CUs:
+// 7.7 ms = 1.97 us per 32-k tile and workgroup, against 3.6 us with every CU busy).  So the time of a launch is the larger
+// of work / chip rate and rounds x unloaded tile time.  Calibrated on the config-5 products (tools/x3w_harness.cpp): a
+// 256 x 256 x 32 tile 3.6 us with all CUs busy, 1.9 us unloaded, plus ~10 us per item in which the persistent workgroup's
+// eight waves store the result and no matrix instruction issues; a 128 x 128 x 32 tile 2.3 us in each of a CU's two slots,
+// 1.3 us unloaded (its epilogue hides behind the other workgroups of the CU).
+static bool wide_pays(long long items_w, int tiles_per_item_w, long long items_o, int tiles_per_item_o) {
+  const double rw = static_cast<double>((items_w + kWideCtas - 1) / kWideCtas);
+  const double ro = static_cast<double>((items_o + 2 * kWideCtas - 1) / (2 * kWideCtas));
+  const double tw = fmax(static_cast<double>(items_w) * tiles_per_item_w * 3.6 / kWideCtas, rw * tiles_per_item_w * 1.9) + rw * 10.0;
+  const double to = fmax(static_cast<double>(items_o) * tiles_per_item_o * 2.3 / (2 * kWideCtas), ro * tiles_per_item_o * 1.3);
+  return tw < to;
+}
 
 // the persistent kernel's stream looks two K tiles ahead: every K slice must hold at least two 32-k tiles
 static bool wide_slices_ok(const GemmArgs& g) {
@@ -939,25 +961,8 @@ static bool wide_slices_ok(const GemmArgs& g) {
   return g.tiles_per_split >= 2 && ktiles - (g.splits - 1) * g.tiles_per_split >= 2;
 }
 
-// start skew of the persistent kernel in cycles (one item's duration, so that the eight classes spread over it): only when
-// a workgroup has enough items for the late start to be noise and the item is short enough for its store burst to matter
-static int wide_skew(const GemmArgs& g, int variant) {
-  if (variant == 44) return -1;      // development (timing only): no global stores in the epilogue
-  if (variant == 45) return -2;      // development (timing only): no epilogue
-  if (variant == 48) return -5;      // development (timing only): stores into an L2-resident region
-  if (variant == 46) return -3;      // development: plain instead of non-temporal stores
-  if (variant == 47) return -4;      // development: plain stores + start skew
-  if (variant != 42 && variant != 43) return 0;
-  const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
-  const int ktiles = (g.K + 31) / 32;
-  const int T = g.splits > 1 ? g.tiles_per_split : ktiles;
-  if (items < 256 * 4) return 0;
-  const long long cyc = static_cast<long long>(T) * 6000 + 24000;
-  return static_cast<int>(cyc > (1 << 22) ? (1 << 22) : cyc) * (variant == 43 ? 2 : 1);
-}
-
 static std::atomic<int> g_x3_variant_override{-1};
-static int x3_variant() {      // tuning aid: SG_X3_VARIANT / sg_gemm_x3_variant = 0 auto, 1 <2,2,2>, 2 <2,1,5>, 3 <4,2,3>,
+static int x3_variant() {      // tuning aid: SG_X3_VARIANT / sg_gemm_x3_variant = 0 auto, 1 <2,2,2>, 2 <2,1,5>, 3 <4,2,3>, 8 the 256-wide hybrid at any size,
                                // 4 never hybrid, 5 hybrid at any size, 9 hybrid at any size with ONE K tile of A in flight (round-3 first form)
   const int o = g_x3_variant_override.load(std::memory_order_relaxed);
   if (o >= 0) return o;
@@ -1009,16 +1014,17 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
   const long long Kp = (static_cast<long long>(g.K) + 63) / 64 * 64;
   const int KS = static_cast<int>(Kp / 16);
   if (g.splits > 1 && (g.tiles_per_split & 1)) return fail(SG_ERR_INVALID, "f16x3: odd K-tile count per split-K slice");
-  char* pa = scratch;
+  int* flag = reinterpret_cast<int*>(scratch);        // exactness flag of the 256-wide kernel (cleared by the split pass)
+  char* pa = scratch + 256;
   char* pb = pa + align256(static_cast<size_t>(Mp) * Kp * 4);
   int* ea = reinterpret_cast<int*>(pb + align256(static_cast<size_t>(Np) * Kp * 4));
   int* eb = reinterpret_cast<int*>(reinterpret_cast<char*>(ea) + align256(static_cast<size_t>(Mp / 32) * (Kp / 64) * 4));
   float* ct = reinterpret_cast<float*>(reinterpret_cast<char*>(eb) + align256(static_cast<size_t>(Np / 32) * (Kp / 64) * 4));
   if (Kp / 64 > 65535) return fail(SG_ERR_INVALID, "f16x3: K too large for the split grid");
-  auto split = [&](char* planes, int* expo, const float* p, long long ld, bool rc, int R, long long Rp, int vec) {
+  auto split = [&](char* planes, int* expo, const float* p, long long ld, bool rc, int R, long long Rp, int vec, int* clear) {
     const dim3 grid(static_cast<unsigned>(Rp / 32), static_cast<unsigned>(Kp / 64));
-    if (rc) hipLaunchKernelGGL((split_kernel<true>), grid, dim3(256), 0, st, planes, expo, p, ld, R, g.K, KS, vec);
-    else hipLaunchKernelGGL((split_kernel<false>), grid, dim3(256), 0, st, planes, expo, p, ld, R, g.K, KS, vec);
+    if (rc) hipLaunchKernelGGL((split_kernel<true>), grid, dim3(256), 0, st, planes, expo, p, ld, R, g.K, KS, vec, clear);
+    else hipLaunchKernelGGL((split_kernel<false>), grid, dim3(256), 0, st, planes, expo, p, ld, R, g.K, KS, vec, clear);
   };
   const int variant = x3_variant();
   const int tm128 = (g.M + 127) / 128, tn128 = (g.N + 127) / 128;
@@ -1026,12 +1032,12 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
   // CU for the 256-thread fp32 kernel; here 64 tiles x 12 slices = 768 workgroups on 512 slots run as 1.5 rounds (75 %
   // efficient).  Fewer slices are always allowed (the workspace was sized for the plan's count): take the count in
   // [splits / 2, splits] with the fullest rounds.
-  auto fit_splits = [&](long long tiles, int slots) {
-    if (g.splits <= 1) return;
-    const int ktiles = (g.K + 31) / 32;
-    int best = g.splits;
+  auto fit_splits = [&](GemmArgs& a, long long tiles, int slots) {
+    if (a.splits <= 1) return;
+    const int ktiles = (a.K + 31) / 32;
+    int best = a.splits;
     double best_eff = 0.0;
-    for (int sp = g.splits; sp >= (g.splits + 1) / 2; --sp) {
+    for (int sp = a.splits; sp >= (a.splits + 1) / 2; --sp) {
       int per = (ktiles + sp - 1) / sp;
       per += per & 1;
       const int real = (ktiles + per - 1) / per;
@@ -1041,57 +1047,64 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     }
     int per = (ktiles + best - 1) / best;
     per += per & 1;
-    g.tiles_per_split = per;
-    g.splits = (ktiles + per - 1) / per;
+    a.tiles_per_split = per;
+    a.splits = (ktiles + per - 1) / per;
   };
-  const long long big = (variant == 5 || variant == 9 || (variant >= 40 && variant <= 48)) ? 0 : 16ll << 20;  // elements: a 64 MB operand is worth keeping out of a split pass
+  // The in-kernel-split ("hybrid") forms, 128 wide (this file) or 256 wide and persistent (gemm_x3w.hip).  `h` is the
+  // product as the kernel sees it (the swapped form exchanges the operands).  The wide kernel takes products that fill the
+  // chip with 256 x 256 items; it is exact unless a scale block drops 2^60 below the slice's running scale -- then it raises
+  // the flag and the 128-wide kernel, launched behind it with the same slices, redoes the product (it returns at once
+  // otherwise).  variant 5 / 9: always 128 wide; 8: 256 wide at any size (tests).
+  auto run_hybrid = [&](GemmArgs h, const PlaneArgs& pl_in, bool arc, bool av4, int t128m, int t128n) {
+    PlaneArgs pl = pl_in;
+    const int t256m = (h.M + 255) / 256, t256n = (h.N + 255) / 256;
+    bool wide = variant != 5 && variant != 9 && (!arc || av4);
+    if (wide) {
+      GemmArgs w = h;
+      w.tiles_m = t256m; w.tiles_n = t256n;
+      fit_splits(w, static_cast<long long>(t256m) * t256n, kWideCtas);
+      GemmArgs o = h;
+      fit_splits(o, static_cast<long long>(t128m) * t128n, 512);
+      const int ktiles = (h.K + 31) / 32;
+      wide = wide_slices_ok(w) &&
+             (variant == 8 || wide_pays(static_cast<long long>(t256m) * t256n * w.splits, w.splits > 1 ? w.tiles_per_split : ktiles,
+                                        static_cast<long long>(t128m) * t128n * o.splits, o.splits > 1 ? o.tiles_per_split : ktiles));
+      if (wide) {
+        h.splits = w.splits; h.tiles_per_split = w.tiles_per_split;      // the fallback uses the same slices
+        pl.flag = flag;
+        launch_x3w_hybrid(w, pl, arc, kWideCtas, st);
+      }
+    }
+    h.tiles_m = t128m; h.tiles_n = t128n;
+    if (!wide) fit_splits(h, static_cast<long long>(t128m) * t128n, 512);
+    const long long items = static_cast<long long>(h.tiles_m) * h.tiles_n * h.splits;
+    static const bool no_fallback = [] { const char* e = getenv("SG_X3_NOFALLBACK"); return e && atoi(e) != 0; }();      // development
+    if (!(wide && no_fallback)) launch_hybrid(h, pl, items, arc, av4, variant == 9 ? 1 : 2, st);
+    return h.splits;
+  };
+  const long long big = (variant == 5 || variant == 8 || variant == 9) ? 0 : 16ll << 20;  // elements: a 64 MB operand is worth keeping out of a split pass
   // A may stay fp32 when its layout allows the in-kernel loads (K-contiguous rows need 16-byte vectors)
   const bool a_fly_ok = transA || (g.vecA && g.K % 4 == 0 && g.K >= 4);
   const bool b_fly_ok = !transB || (g.vecB && g.K % 4 == 0 && g.K >= 4);
   const bool plain_epi = !g.bias && g.act == SG_ACT_NONE && !g.accumulate;
-  const bool swap_ok = tm128 <= 2 && g.M <= 256 && static_cast<long long>(g.N) * g.K >= big && b_fly_ok && plain_epi;
-  if (variant != 4 && (tn128 <= 2 || (variant >= 41 && variant <= 48 && !(swap_ok && g.N > g.M))) &&
-      static_cast<long long>(g.M) * g.K >= big && a_fly_ok) {
+  if (variant != 4 && tn128 <= 2 && static_cast<long long>(g.M) * g.K >= big && a_fly_ok) {
     // ---- hybrid: A fp32 in the kernel, B planes ----
-    split(pb, eb, g.B, g.ldb, !transB, g.N, Np, g.vecB);
-    PlaneArgs pl{nullptr, pb, nullptr, eb, KS};
-    const bool av4 = transA && g.vecA && g.M % 4 == 0;
-    if ((variant >= 40 && variant <= 48) && (!transA || av4)) {           // 256 x 256 tiles, eight waves (gemm_x3w.hip)
-      g.tiles_m = static_cast<int>((g.M + 255) / 256);
-      g.tiles_n = static_cast<int>((g.N + 255) / 256);
-      fit_splits(static_cast<long long>(g.tiles_m) * g.tiles_n, 256);
-      *splits_used = g.splits;
-      launch_x3w_hybrid(g, pl, transA, (variant >= 41 && wide_slices_ok(g)) ? 256 : 0, wide_skew(g, variant), st);
-      return SG_OK;
-    }
-    g.tiles_m = tm128;
-    fit_splits(static_cast<long long>(g.tiles_m) * g.tiles_n, 512);
-    *splits_used = g.splits;
-    const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
-    launch_hybrid(g, pl, items, transA, av4, variant == 9 ? 1 : 2, st);
+    split(pb, eb, g.B, g.ldb, !transB, g.N, Np, g.vecB, flag);
+    PlaneArgs pl{nullptr, pb, nullptr, eb, KS, nullptr};
+    *splits_used = run_hybrid(g, pl, transA, transA && g.vecA && g.M % 4 == 0, tm128, tn128);
     return SG_OK;
   }
   if (variant != 4 && tm128 <= 2 && g.M <= 256 && static_cast<long long>(g.N) * g.K >= big && b_fly_ok && plain_epi) {
     // ---- swapped hybrid: C^T = op(B)^T op(A)^T with op(B)^T (the huge operand) fp32 in the kernel, op(A)^T as planes ----
-    split(pa, ea, g.A, g.lda, transA, g.M, Mp, g.vecA);              // planes of op(A): rows m, K-contiguous units
-    if (variant >= 40 && variant <= 48) fit_splits(static_cast<long long>((g.N + 255) / 256) * ((g.M + 255) / 256), 256);
-    else fit_splits(static_cast<long long>(tn128) * tm128, 512);
+    split(pa, ea, g.A, g.lda, transA, g.M, Mp, g.vecA, flag);              // planes of op(A): rows m, K-contiguous units
     GemmArgs h = g;
     h.M = g.N; h.N = g.M;
     h.A = g.B; h.lda = g.ldb; h.vecA = g.vecB;
     h.C = ct; h.ldc = g.M;
     h.bias = nullptr;
-    h.tiles_m = tn128; h.tiles_n = tm128;
-    PlaneArgs pl{nullptr, pa, nullptr, ea, KS};
-    const long long items = static_cast<long long>(h.tiles_m) * h.tiles_n * h.splits;
+    PlaneArgs pl{nullptr, pa, nullptr, ea, KS, nullptr};
     // op(B)^T element (n, k): B stored (K x N) when !transB -> row-contiguous in n (ARC); (N x K) when transB -> K-contiguous
-    const bool hav4 = !transB && h.vecA && h.M % 4 == 0;
-    if ((variant >= 40 && variant <= 48) && (transB || hav4)) {
-      h.tiles_m = static_cast<int>((h.M + 255) / 256);
-      h.tiles_n = static_cast<int>((h.N + 255) / 256);
-      launch_x3w_hybrid(h, pl, !transB, (variant >= 41 && wide_slices_ok(h)) ? 256 : 0, wide_skew(h, variant), st);
-    } else
-    launch_hybrid(h, pl, items, !transB, hav4, variant == 9 ? 1 : 2, st);
+    g.splits = run_hybrid(h, pl, !transB, !transB && h.vecA && h.M % 4 == 0, tn128, tm128);
     const long long total = static_cast<long long>(g.M) * g.N;
     if (g.splits > 1) {
       hipLaunchKernelGGL(reduce_t_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, g.C, g.ldc, g.ws,
@@ -1100,12 +1113,13 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
       hipLaunchKernelGGL(transpose_out_kernel, dim3(static_cast<unsigned>((g.N + 31) / 32), static_cast<unsigned>((g.M + 31) / 32)),
                          dim3(256), 0, st, g.C, g.ldc, ct, g.M, g.N);
     }
+    *splits_used = g.splits;
     *reduced = true;
     return SG_OK;
   }
-  split(pa, ea, g.A, g.lda, transA, g.M, Mp, g.vecA);
-  split(pb, eb, g.B, g.ldb, !transB, g.N, Np, g.vecB);
-  PlaneArgs pl{pa, pb, ea, eb, KS};
+  split(pa, ea, g.A, g.lda, transA, g.M, Mp, g.vecA, nullptr);
+  split(pb, eb, g.B, g.ldb, !transB, g.N, Np, g.vecB, nullptr);
+  PlaneArgs pl{pa, pb, ea, eb, KS, nullptr};
   // variant: short K slices are dominated by the epilogue (two workgroups per CU overlap it); long ones by DMA latency
   const int ktiles32 = (g.K + 31) / 32;
   const int slice = g.splits > 1 ? g.tiles_per_split : ktiles32;
@@ -1113,14 +1127,8 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
   // workgroup and the 256-row geometries on every plane-path shape by 4-14 %: the third workgroup's matrix work fills the
   // barrier / DMA-wait gaps of the other two
   (void)slice;
-  int v = ((variant >= 1 && variant <= 3) || variant == 6 || variant == 7 || variant >= 10) ? variant : 6;
-  if (v >= 10) {              // 256 x 256 tiles, eight waves, one workgroup per CU (gemm_x3w.hip)
-    g.tiles_m = static_cast<int>((g.M + 255) / 256);
-    g.tiles_n = static_cast<int>((g.N + 255) / 256);
-    fit_splits(static_cast<long long>(g.tiles_m) * g.tiles_n, 256);
-    *splits_used = g.splits;
-    launch_x3w_planes(g, pl, v - 10, st);
-  } else if (v == 3) {
+  int v = ((variant >= 1 && variant <= 3) || variant == 6 || variant == 7) ? variant : 6;
+  if (v == 3) {
     g.tiles_m = static_cast<int>((g.M + 255) / 256);
     const long long items = static_cast<long long>(g.tiles_m) * g.tiles_n * g.splits;
     hipLaunchKernelGGL((gemm_f16x3_kernel<4, 2, 3>), dim3(static_cast<unsigned>(items)), dim3(512), 0, st, g, pl);
@@ -1142,7 +1150,7 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
 }  // namespace sg
 
 SG_API int sg_gemm_x3_variant(int variant) {
-  sg::g_x3_variant_override.store(variant < 0 || variant > 60 ? -1 : variant, std::memory_order_relaxed);
+  sg::g_x3_variant_override.store(variant < 0 || variant > 9 ? -1 : variant, std::memory_order_relaxed);
   return SG_OK;
 }
 
