@@ -490,10 +490,16 @@ def hbm_leg(args, dev):
         out["roofline"] = roof
         out["step_roofline_frac"] = out["edges_per_s"] * 8 * (8 + 4 * D) / HBM_PEAK
     loss = None
-    out["dense_roofline"] = dense_roofline(step, 2)
-    out["ms_per_step_exact_fp32_gemm"] = exact_fp32_step_ms(step, 2)     # every dense product on the exact fp32 MFMA kernel
+
+    def sub(fn, *a):      # a secondary measurement must not cost the primary timings of this leg
+        try:
+            return fn(*a)
+        except Exception as e:
+            return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    out["dense_roofline"] = sub(dense_roofline, step, 2)
+    out["ms_per_step_exact_fp32_gemm"] = sub(exact_fp32_step_ms, step, 2)     # every dense product on the exact fp32 MFMA kernel
     if not args.no_verify:
-        out["verify"] = verify_leg(net, step, (dg.ind_ptr, dg.end_points, dg.level, ni, R, None), y, 1.0 / E)
+        out["verify"] = sub(verify_leg, net, step, (dg.ind_ptr, dg.end_points, dg.level, ni, R, None), y, 1.0 / E)
     out["init"] = "embeddings U(-0.1, 0.1), Xavier-in weights, zero biases, then layer-sequential scale calibration " \
                   "(model.calibrate_output_scale); pre-calibration rms per stage: %s" % json.dumps(
                       [{k: float("%.3g" % v) for k, v in st.items()} for st in calib])
@@ -786,35 +792,60 @@ def run_rank(args):
             # `frac_vs_l2_peak` (every byte at BW_L2) is the unconditional figure.  The HBM fraction the metric asks for is
             # `hbm_bound.roofline.frac` (config-5 shard), where HBM does bind.
             hits = (rec or {}).get("l2_hit_rate_by_source_mb") if (live and same) else None
+
+            def hit_for(mb):      # the PMC class with the nearest source footprint (a few % apart: same column slicing)
+                if not hits:
+                    return None
+                key = min(hits, key=lambda k: abs(float(k) - mb))
+                return hits[key] if abs(float(key) - mb) <= 0.25 * max(mb, 1) else None
+            classes = sorted(roof["_classes"].items())
+            # the Infinity-Cache rate of THIS run and box: clean strided read over each class's footprint (falls back to the
+            # committed sweep's 7.4 TB/s when the ceiling measurement is switched off)
+            mall_run = {}
+            if not args.no_ceiling:
+                for (sb, phased), (n, t_avg, e_avg) in classes:
+                    mall_run[(sb, phased)] = measure_stream_ceiling(dev, max(1 << 20, (sb >> 20) << 20),
+                                                                    (int(e_avg) + 255) // 256, strided=True)
+            mall_mean = (sum(mall_run.values()) / len(mall_run)) if mall_run else None
+            bw_mall = mall_mean * 1e9 if mall_mean else BW_MALL
             t_bound = t_l2 = t_actual = 0.0
             per_class, have_all = [], True
-            for (sb, phased), (n, t_avg, e_avg) in sorted(roof["_classes"].items()):
+            for (sb, phased), (n, t_avg, e_avg) in classes:
                 b_launch = (8 + 4 * D) * e_avg
-                hit = None if not hits else hits.get(str(sb >> 20))
-                t_b = b_launch * (hit / BW_L2 + (1.0 - hit) / BW_MALL) if hit is not None else None
+                hit = hit_for(sb >> 20)
+                t_b = b_launch * (hit / BW_L2 + (1.0 - hit) / bw_mall) if hit is not None else None
                 have_all = have_all and t_b is not None
                 t_bound += n * (t_b or 0.0)
                 t_l2 += n * b_launch / BW_L2
                 t_actual += n * t_avg
                 cls = {"gathered_matrix_mb": sb >> 20, "source_range_phase": bool(phased), "launches_per_step": n / args.steps,
                        "edges_per_launch": e_avg, "avg_launch_ms": t_avg * 1e3, "achieved_gbs": b_launch / t_avg / 1e9,
-                       "l2_hit_rate": hit, "bound_ms": None if t_b is None else t_b * 1e3,
-                       "frac": None if t_b is None else t_b / t_avg, "frac_vs_l2_peak": b_launch / BW_L2 / t_avg}
-                if not args.no_ceiling:     # cross-check of BW_MALL on THIS box: clean strided read over this class's footprint
-                    cls["mall_rate_in_run_gbs"] = measure_stream_ceiling(dev, max(1 << 20, (sb >> 20) << 20),
-                                                                         (int(e_avg) + 255) // 256, strided=True)
+                       "frac": b_launch / BW_L2 / t_avg, "l2_hit_rate": hit,
+                       "cache_model_bound_ms": None if t_b is None else t_b * 1e3,
+                       "frac_vs_cache_model": None if t_b is None else t_b / t_avg}
+                if (sb, phased) in mall_run:
+                    cls["mall_rate_in_run_gbs"] = mall_run[(sb, phased)]
                 per_class.append(cls)
-            frac = (t_bound / t_actual) if have_all else None
-            roof.update(bound="l2+infinity_cache", frac=frac, peak=(roof["achieved"] / frac) if frac else None,
-                        frac_vs_l2_peak=t_l2 / t_actual, per_class=per_class,
-                        bound_model={"formula": "t_bound = bytes * (hit / BW_L2 + (1 - hit) / BW_MALL), summed over the step's "
-                                                "aggregation launches; frac = t_bound / measured",
+            # Vocabulary (fixed from round 5 on): for this cache-resident leg `frac` IS the unconditional
+            # fraction of the L2 peak (every algorithmic byte at 34.5 TB/s) -- it moves only when the kernel moves.  The
+            # model-conditional number (bound built from the kernel's own L2 hit rate and the Infinity-Cache rate) is
+            # `frac_vs_cache_model`: a diagnostic of how close the launches run to what their hit rate allows, not a target.
+            # The "% HBM" the metric asks for is `hbm_bound.roofline.frac`, where HBM binds.
+            roof.update(bound="l2", peak=BW_L2 / 1e9, frac=t_l2 / t_actual, frac_vs_l2_peak=t_l2 / t_actual,
+                        frac_vs_cache_model=(t_bound / t_actual) if have_all else None,
+                        mall_rate_in_run_gbs=mall_mean, per_class=per_class,
+                        cache_model={"formula": "t_bound = bytes * (hit / BW_L2 + (1 - hit) / BW_MALL), summed over the step's "
+                                                "aggregation launches; frac_vs_cache_model = t_bound / measured",
                                      "BW_L2_gbs": BW_L2 / 1e9, "BW_L2_source": "MI355X_MICROARCH.md: L2 ~34.5 TB/s aggregate",
-                                     "BW_MALL_gbs": BW_MALL / 1e9,
-                                     "BW_MALL_source": "profiles/r4_mall_sweep.txt (tools/mall_sweep.py): clean streaming-read "
+                                     "BW_MALL_gbs": bw_mall / 1e9,
+                                     "BW_MALL_source": ("mean of the clean strided reads over each class's footprint measured in this "
+                                                        "run (per_class.mall_rate_in_run_gbs)") if mall_mean else
+                                                       "profiles/r4_mall_sweep.txt (tools/mall_sweep.py): clean streaming-read "
                                                        "plateau 48 MB .. 512 MB through the vector L1",
                                      "hit_source": (rec or {}).get("source") if hits else "no PMC record for this kernel source: "
-                                                                                          "frac withheld"},
+                                                                                          "frac_vs_cache_model withheld",
+                                     "hit_note": "the hit rate is the kernel's OWN: a kernel with a worse hit rate gets a looser "
+                                                 "bound -- which is why this is not `frac`"},
                         note="gathered matrices (%s MB) sit in the 256 MB Infinity Cache / partly in the 8 x 4 MB L2s at "
                              "this shape, so HBM does not bind (hbm_equiv_frac > 1 is the cache hierarchy at work); the "
                              "HBM-bound measurement is the `hbm_bound` leg" % "/".join(str(m) for m in src_mb))

@@ -201,35 +201,49 @@ def stream_ptr():
 
 
 _ws_cache = collections.OrderedDict()
-_WS_CACHE_MAX = 4       # (device, stream) pairs that keep a scratch buffer; older ones are released
+_WS_STREAMS_PER_DEVICE = 4       # (stream) scratch buffers kept per DEVICE; older ones of that device are released
 
 
 def workspace(nbytes, device):
     """Per-(device, stream) scratch buffer; kernels are stream-ordered so reuse across calls is safe.  At most
-    _WS_CACHE_MAX buffers are kept (least recently used first out): a process that creates many streams -- or one that ran
-    a config-5-sized step on a side stream once -- must not pin a multi-GB buffer per stream for ever.  Dropping an entry
-    only drops this module's reference: the block goes back to torch's allocator pool of the stream it was allocated on,
-    which re-issues it in that stream's order."""
+    _WS_STREAMS_PER_DEVICE buffers are kept per device (least recently used first out): a process that creates many
+    streams -- or one that ran a config-5-sized step on a side stream once -- must not pin a multi-GB buffer per stream
+    for ever, and a process that drives eight GPUs must not evict seven of them on every call (the cap used
+    to be global).  Dropping an entry only drops this module's reference: the block goes back to torch's allocator pool
+    of the stream it was allocated on, which re-issues it in that stream's order.
+    While a hipGraph is being captured on the current stream nothing is evicted or replaced-and-dropped: a captured kernel
+    may hold the address of a buffer handed out earlier in the capture, and a block returned to the pool could be handed
+    out again before the graph is replayed.  Buffers that grow during a capture are kept alive in `_ws_pinned`."""
     if nbytes <= 0:
         return None, 0
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream().cuda_stream)
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev_index, torch.cuda.current_stream().cuda_stream)
+    capturing = torch.cuda.is_current_stream_capturing()
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and capturing:
+            _ws_pinned.append(buf)          # still referenced by already-captured kernels
         buf = None
         _ws_cache.pop(key, None)            # release the smaller buffer BEFORE allocating the larger one
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
-        while len(_ws_cache) > _WS_CACHE_MAX:
-            _ws_cache.popitem(last=False)
+        if not capturing:
+            mine = [k for k in _ws_cache if k[0] == dev_index]
+            for k in mine[:max(0, len(mine) - _WS_STREAMS_PER_DEVICE)]:
+                del _ws_cache[k]
     else:
         _ws_cache.move_to_end(key)
     return buf, buf.numel()
 
 
+_ws_pinned = []
+
+
 def release_workspaces():
-    """Drop every cached scratch buffer (after a one-off large problem: the next call allocates what IT needs)."""
+    """Drop every cached scratch buffer (after a one-off large problem: the next call allocates what IT needs).  Not while a
+    captured hipGraph that used them is still going to be replayed."""
     _ws_cache.clear()
+    del _ws_pinned[:]
 
 
 def f32c(t):

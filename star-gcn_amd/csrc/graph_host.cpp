@@ -15,6 +15,7 @@
 // so small inputs stay serial and large ones use a bounded team.
 #define SG_HOST_THREADS 16
 #define SG_OMP_MIN_WORK (1 << 20)
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -39,11 +40,22 @@ static void parallel_blocks(int64_t n, bool parallel, F body) {      // body(beg
   std::vector<std::thread> team;
   team.reserve(t - 1);
   const int64_t per = (n + t - 1) / t;
+  int64_t serial_from = n;      // ranges [serial_from, n) could not get a thread and are run by the caller
   for (int k = 1; k < t; ++k) {
     const int64_t b = per * k, e = (b + per < n) ? b + per : n;
-    if (b < e) team.emplace_back([=] { body(b, e); });
+    if (b >= e) continue;
+    // std::thread's constructor throws std::system_error on EAGAIN (pids cgroup, RLIMIT_NPROC): an exception leaving an
+    // extern "C" entry point past joinable threads would be std::terminate -- the host process gone.  Fall back to
+    // running the remaining ranges serially instead.
+    try {
+      team.emplace_back([=] { body(b, e); });
+    } catch (const std::system_error&) {
+      serial_from = b;
+      break;
+    }
   }
   body(static_cast<int64_t>(0), per < n ? per : n);
+  if (serial_from < n) body(serial_from, n);
   for (auto& th : team) th.join();
 }
 
