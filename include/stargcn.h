@@ -527,6 +527,10 @@ int sg_sample_distinct_dev_hip(int32_t* out, int64_t n, int64_t k, uint64_t seed
                                const uint64_t* dev_counter, void* stream);
 int sg_recon_mask_dev_hip(int32_t* noise, int32_t* recon, int64_t n, int64_t k, float p_zero, uint64_t seed,
                           uint64_t counter, const uint64_t* dev_counter, void* stream);
+/* inductive form (iterators.py:332-346, "nodes unseen in the training graph are masked as -1"): `cand` = the m distinct node
+ * ids that occur in the training graph; noise = -1 for every other node, recon = k distinct CANDIDATES */
+int sg_recon_mask_cand_dev_hip(int32_t* noise, int32_t* recon, int64_t n, const int32_t* cand, int64_t m, int64_t k,
+                               float p_zero, uint64_t seed, uint64_t counter, const uint64_t* dev_counter, void* stream);
 int sg_counter_add_hip(uint64_t* counter, uint64_t v, void* stream);
 size_t sg_sort_i32_workspace_bytes(int64_t n);
 int sg_sort_i32_hip(int32_t* keys_out, int32_t* vals_out, const int32_t* keys, const int32_t* vals, int64_t n,

@@ -114,6 +114,7 @@ _SIGS = {
     "sg_recon_mask_hip": (_INT, [_P, _P, _I64, _I64, _F32, _c.c_uint64, _c.c_uint64, _P]),
     "sg_sample_distinct_dev_hip": (_INT, [_P, _I64, _I64, _c.c_uint64, _c.c_uint64, _P, _P]),
     "sg_recon_mask_dev_hip": (_INT, [_P, _P, _I64, _I64, _F32, _c.c_uint64, _c.c_uint64, _P, _P]),
+    "sg_recon_mask_cand_dev_hip": (_INT, [_P, _P, _I64, _P, _I64, _I64, _F32, _c.c_uint64, _c.c_uint64, _P, _P]),
     "sg_counter_add_hip": (_INT, [_P, _c.c_uint64, _P]),
     "sg_sort_i32_workspace_bytes": (_SZ, [_I64]),
     "sg_sort_i32_hip": (_INT, [_P] * 4 + [_I64, _I64, _P, _SZ, _P]),

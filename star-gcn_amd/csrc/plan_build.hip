@@ -788,6 +788,20 @@ __global__ void recon_noise_kernel(int32_t* __restrict__ noise, const int32_t* _
   const float u = (mix32(static_cast<uint32_t>(j) ^ mix32(k0 ^ 0x5bd1e995U) ^ (k1 * 0x27d4eb2fU)) >> 8) * (1.0f / 16777216.0f);
   noise[node] = (u < p_zero) ? -1 : static_cast<int32_t>(node);
 }
+// noise[cand[i]] = cand[i]: the nodes of the training graph keep their own embedding (iterators.py:341-342)
+__global__ void scatter_identity_kernel(int32_t* __restrict__ noise, const int32_t* __restrict__ cand, long long m, long long n) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const long long v = cand[i];
+  if (v >= 0 && v < n) noise[v] = static_cast<int32_t>(v);
+}
+// recon[j] = cand[recon[j]] (in place: positions in the candidate list -> node ids)
+__global__ void map_through_kernel(int32_t* __restrict__ recon, const int32_t* __restrict__ cand, long long k, long long m) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  const long long p = recon[j];
+  recon[j] = (p >= 0 && p < m) ? cand[p] : -1;
+}
 __global__ void add_u64_kernel(uint64_t* __restrict__ c, uint64_t v) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *c += v;
 }
@@ -893,6 +907,31 @@ SG_API int sg_recon_mask_dev_hip(int32_t* noise, int32_t* recon, int64_t n, int6
     hipLaunchKernelGGL(recon_noise_kernel, dim3(blocks(k)), dim3(256), 0, st, noise, recon, static_cast<long long>(k),
                        static_cast<long long>(n), p_zero, seed ^ 0xa5a5a5a5ULL, counter, dev_counter);
   return check_launch("sg_recon_mask_hip");
+}
+
+// The INDUCTIVE form of the same sampler (reference iterators.py:332-346 with _recon_train_candidates a strict subset of the
+// graph's nodes): `cand` lists the m nodes that occur in the training graph (distinct ids in [0, n)).  noise starts as -1
+// for EVERY node ("nodes unseen in the training graph are masked as -1"), the candidates get their own id, k distinct
+// candidates are drawn for reconstruction (recon = their node ids) and take -1 with probability p_zero.
+SG_API int sg_recon_mask_cand_dev_hip(int32_t* noise, int32_t* recon, int64_t n, const int32_t* cand, int64_t m, int64_t k,
+                                      float p_zero, uint64_t seed, uint64_t counter, const uint64_t* dev_counter, void* stream) {
+  if (n < 0 || m < 0 || k < 0 || k > m || m > n || n >= (1ll << 31)) return fail(SG_ERR_INVALID, "need 0 <= k <= m <= n < 2^31");
+  if (n == 0) return SG_OK;
+  if (!noise || (m > 0 && !cand) || (k > 0 && !recon)) return fail(SG_ERR_INVALID, "null pointer argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks(n)), dim3(256), 0, st, noise, static_cast<long long>(n), -1);
+  if (m > 0)
+    hipLaunchKernelGGL(scatter_identity_kernel, dim3(blocks(m)), dim3(256), 0, st, noise, cand, static_cast<long long>(m),
+                       static_cast<long long>(n));
+  if (k > 0) {
+    int rc = sg_sample_distinct_dev_hip(recon, m, k, seed, counter, dev_counter, stream);
+    if (rc != SG_OK) return rc;
+    hipLaunchKernelGGL(map_through_kernel, dim3(blocks(k)), dim3(256), 0, st, recon, cand, static_cast<long long>(k),
+                       static_cast<long long>(m));
+    hipLaunchKernelGGL(recon_noise_kernel, dim3(blocks(k)), dim3(256), 0, st, noise, recon, static_cast<long long>(k),
+                       static_cast<long long>(n), p_zero, seed ^ 0xa5a5a5a5ULL, counter, dev_counter);
+  }
+  return check_launch("sg_recon_mask_cand_dev_hip");
 }
 
 // ------------------------------------------------------------------------------------------------------------------

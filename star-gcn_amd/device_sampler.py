@@ -21,8 +21,15 @@ from . import _lib as L
 
 
 class DeviceBatchSampler(object):
-    def __init__(self, resident, batch_size, embed_P_mask=0.1, embed_p_zero=0.0, seed=0):
+    def __init__(self, resident, batch_size, embed_P_mask=0.1, embed_p_zero=0.0, seed=0, recon_candidates=None):
+        """recon_candidates: optional {node key: int array of the node ids that occur in the TRAINING graph} -- the
+        reference's `_recon_train_candidates` (iterators.py:332-346).  For a listed key the sampler is inductive: nodes
+        outside the list get noise -1 ("nodes unseen in the training graph are masked as -1"), the reconstruction nodes are
+        ceil(P_mask |list|) of the list.  A key without a list is transductive (every node is a candidate)."""
         self.res, self.batch_size, self.seed = resident, int(min(batch_size, resident.nnz)), int(seed)
+        self._cand = {}
+        for key, ids in (recon_candidates or {}).items():
+            self._cand[key] = torch.as_tensor(ids, dtype=torch.int32).to(resident.device).contiguous()
         self.P_mask, self.p_zero = float(embed_P_mask), float(embed_p_zero)
         self.iteration = 0
         dev = resident.device
@@ -56,10 +63,17 @@ class DeviceBatchSampler(object):
         ratings = self._values[ids[:B].long()]
         noise, recon = dict(), dict()
         for j, (key, n) in enumerate(self._n.items()):
-            k = int(math.ceil(self.P_mask * n))
-            nz, rc = self._i32(n), self._i32(k)
-            L.check(lib.sg_recon_mask_dev_hip(L.ptr(nz), L.ptr(rc), n, k, self.p_zero, self.seed, 3 * it + 1 + j, dc, st),
-                    "sg_recon_mask_hip")
+            cand = self._cand.get(key)
+            if cand is not None:
+                k = int(math.ceil(self.P_mask * cand.numel()))
+                nz, rc = self._i32(n), self._i32(k)
+                L.check(lib.sg_recon_mask_cand_dev_hip(L.ptr(nz), L.ptr(rc), n, L.ptr(cand), cand.numel(), k, self.p_zero,
+                                                       self.seed, 3 * it + 1 + j, dc, st), "sg_recon_mask_cand_dev_hip")
+            else:
+                k = int(math.ceil(self.P_mask * n))
+                nz, rc = self._i32(n), self._i32(k)
+                L.check(lib.sg_recon_mask_dev_hip(L.ptr(nz), L.ptr(rc), n, k, self.p_zero, self.seed, 3 * it + 1 + j, dc, st),
+                        "sg_recon_mask_hip")
             noise[key], recon[key] = nz[:n], rc[:k]
         if advance_on_device:
             L.check(lib.sg_counter_add_hip(L.ptr(self.dev_counter), 3, st), "sg_counter_add_hip")

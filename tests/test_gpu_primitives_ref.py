@@ -187,8 +187,10 @@ def test_device_twins_live_against_the_compiled_reference_on_a_random_graph():
     twins against the reference's compiled C++ CALLED HERE, on a fresh 200 k-edge graph -- support in both directions and
     both normalisations, level lists, edge removal with repeats and non-edges."""
     from oracle import gs_ref
-    if not gs_ref.available():
-        pytest.skip("oracle/_ref not in this snapshot")
+    # no silent skip (VERDICT r4): the compiled reference is a build product of __graft_entry__.build() that travels with the
+    # snapshot like the library itself; a GPU run without it has lost the live differential and must say so
+    assert gs_ref.available(), ("oracle/_ref/libgs_ref.so is not in this snapshot and /root/reference is not here to build it: "
+                                "run __graft_entry__.build() in the build container before shipping the tree")
     from star_gcn_amd import _lib as L
     from star_gcn_amd.plan import MultiLinkPlan
     ref = gs_ref.GraphSamplerRef()

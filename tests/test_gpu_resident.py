@@ -164,6 +164,56 @@ def test_device_sampler_draws_are_distinct_uniform_and_reproducible():
     assert 0.22 < frac < 0.38
 
 
+def test_device_recon_mask_inductive_rule_unseen_nodes_are_minus_one():
+    """Reference iterators.py:332-346: the noise array starts as -1 for EVERY node of the graph ("nodes unseen in the training
+    graph are masked as -1.0"), the nodes of the training graph (`_recon_train_candidates`) get their own id, and
+    ceil(P_mask |candidates|) of THEM are drawn for reconstruction, -1 with probability p_zero.  The device form
+    (sg_recon_mask_cand_dev_hip) is held to exactly those set-level facts -- the reference's Mersenne-Twister stream is
+    deliberately not reproduced (include/stargcn.h section 12) -- and to the degenerate probabilities, where the noise
+    array is a deterministic function of the drawn set and must equal the reference expression evaluated on it."""
+    from star_gcn_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(5)
+    n = 50_000
+    cand = np.sort(rng.choice(n, 31_007, replace=False)).astype(np.int32)       # nodes seen in the training graph
+    unseen = np.setdiff1d(np.arange(n), cand)
+    k = int(np.ceil(0.1 * cand.size))
+    cd = torch.from_numpy(cand).cuda()
+    for p_zero in (0.0, 1.0, 0.35):
+        nz = torch.full((n,), 12345, dtype=torch.int32, device="cuda")
+        rc = torch.empty(k, dtype=torch.int32, device="cuda")
+        L.check(lib.sg_recon_mask_cand_dev_hip(L.ptr(nz), L.ptr(rc), n, L.ptr(cd), cand.size, k, p_zero, 11, 4, None, None), "recon")
+        nzh, rch = nz.cpu().numpy(), rc.cpu().numpy()
+        assert np.unique(rch).size == k and np.isin(rch, cand).all()            # k distinct CANDIDATES
+        assert (nzh[unseen] == -1).all()                                        # the inductive rule
+        remain = np.setdiff1d(cand, rch)
+        assert np.array_equal(nzh[remain], remain)                              # embed_noise[remain] = remain
+        if p_zero in (0.0, 1.0):
+            # the reference expression on the drawn set: mask_type = multinomial(1, [p_zero, p_self]) is one-hot and certain
+            mask_type = np.tile(np.array([[1, 0]] if p_zero == 1.0 else [[0, 1]]), (k, 1))
+            expect = -np.ones(n, dtype=np.int32)
+            expect[remain] = remain
+            expect[rch] = (mask_type * np.stack([-np.ones(rch.shape), rch], axis=1)).sum(axis=1).astype(np.int32)
+            assert np.array_equal(nzh, expect)
+        else:
+            on = nzh[rch]
+            assert set(np.unique(on - rch * (on >= 0))) <= {0, -1}
+            assert 0.30 < float((on == -1).mean()) < 0.40
+    # the sampler class: `recon_candidates` switches the inductive form on
+    import types
+    from star_gcn_amd.device_sampler import DeviceBatchSampler
+    csr = types.SimpleNamespace(values=np.ones(10, dtype=np.float32))
+    res = types.SimpleNamespace(nnz=10, device=torch.device("cuda"), csr=csr, U="user", I="movie", n_user=n, n_item=1000,
+                                _edge_row=torch.zeros(10, dtype=torch.int32, device="cuda"),
+                                _edge_col=torch.zeros(10, dtype=torch.int32, device="cuda"))
+    smp = DeviceBatchSampler(res, 4, embed_P_mask=0.1, embed_p_zero=0.0, seed=2, recon_candidates={"user": cand})
+    b = smp.next_batch()
+    nu = b["noise"]["user"].cpu().numpy()
+    assert (nu[unseen] == -1).all() and np.isin(b["recon"]["user"].cpu().numpy(), cand).all()
+    assert b["recon"]["user"].numel() == k
+    assert np.array_equal(b["noise"]["movie"].cpu().numpy(), np.arange(1000))   # no candidate list: transductive, as before
+
+
 def test_device_batch_equals_host_batch():
     """DeviceBatchSampler + ResidentPlan.set_batch_device (samplers, pair plan, take plans, edge masking all on the
     device) give bit-identical network outputs to the host-planned batch (set_batch) of the SAME edges / noise / nodes."""
