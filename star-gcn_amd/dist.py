@@ -116,6 +116,40 @@ class _Pending(object):
             self.events = []
 
 
+class _SumCheck(object):
+    """Self-check of the all-reduces (bench.py `partition_check`, outside any timed region): while enabled, every _launch_sum
+    also forms the float64 sum and sum of magnitudes of the local buffer BEFORE the collective, all-reduces those two scalars
+    on their own, and compares the sum of the reduced buffer with the reduced scalar: |sum(result) - sum_r sum(local_r)| /
+    sum_r sum |local_r|.  A checksum of checksums: it proves the collective added every rank's buffer, whatever the buffers
+    hold, to fp32 summation accuracy.  Records (elements, relative error) per collective; forces completion of each
+    collective on the spot (so it serialises the step it watches)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def reset(self):
+        self.records = []
+
+
+CHECK = _SumCheck()
+
+
+def _check_before(y):
+    if not CHECK.enabled or (y.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return None
+    yd = y.detach().double()
+    return torch.stack([yd.sum(), yd.abs().sum()])
+
+
+def _check_after(y, before):
+    after = y.detach().double().sum()
+    c = before.cpu() if dist.get_backend() != "nccl" else before
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    c = c.cpu()
+    CHECK.records.append((int(y.numel()), abs(float(after) - float(c[0])) / max(float(c[1]), 1e-300)))
+
+
 def _launch_sum(y, pending=None):
     """Sum `y` over ranks IN PLACE.  RCCL ('nccl'): enqueued on the communication stream behind the work already
     queued on the current stream; the caller's stream only waits when `pending.wait()` is called (immediately when
@@ -124,6 +158,7 @@ def _launch_sum(y, pending=None):
     if STATS.enabled:
         STATS.bytes += y.numel() * y.element_size()
         STATS.calls += 1
+    chk = _check_before(y)
     if dist.get_backend() != "nccl" or not y.is_cuda:
         import time
         t0 = time.perf_counter() if STATS.enabled else 0.0
@@ -135,6 +170,8 @@ def _launch_sum(y, pending=None):
             dist.all_reduce(y, op=dist.ReduceOp.SUM)
         if STATS.enabled:
             STATS.host_s += time.perf_counter() - t0
+        if chk is not None:
+            _check_after(y, chk)
         return
     cur = torch.cuda.current_stream(y.device)
     cs = comm_stream(y.device)
@@ -151,10 +188,12 @@ def _launch_sum(y, pending=None):
         done = torch.cuda.Event()
         done.record(cs)
     y.record_stream(cs)
-    if pending is None:
+    if pending is None or chk is not None:
         _wait_on(cur, done)
-    else:
+    if pending is not None:
         pending.events.append(done)
+    if chk is not None:
+        _check_after(y, chk)
 
 
 def all_reduce_sum(t):
