@@ -941,16 +941,21 @@ constexpr int kWideCtas = 256;      // workgroups of the persistent 256-wide ker
 
 // Does the 256-wide persistent kernel pay?  The chip is power-bound on these kernels: a launch that fills only half the CUs
 // runs them at a higher clock and finishes the same work in about the same time (4096 x 256 x 1 M as 128 items on 256 CUs:
-// 7.7 ms = 1.97 us per 32-k tile and workgroup, against 3.6 us with every CU busy).  So the time of a launch is the larger
-// of work / chip rate and rounds x unloaded tile time.  Calibrated on the config-5 products (tools/x3w_harness.cpp): a
-// 256 x 256 x 32 tile 3.6 us with all CUs busy, 1.9 us unloaded, plus ~10 us per item in which the persistent workgroup's
-// eight waves store the result and no matrix instruction issues; a 128 x 128 x 32 tile 2.3 us in each of a CU's two slots,
-// 1.3 us unloaded (its epilogue hides behind the other workgroups of the CU).
+// 7.7 ms = 1.97 us per 32-k tile and workgroup, against 3.6 us with every CU busy).  Calibrated on the config-5 and the
+// ML-10M products (tools/x3w_harness.cpp, profiles/r5_gemm_wide.md): a 256 x 256 x 32 tile takes 3.6 us with all CUs busy,
+// 1.9 us unloaded; a 128 x 128 x 32 tile 2.3 us in each of a CU's two slots, 1.3 us unloaded.
 static bool wide_pays(long long items_w, int tiles_per_item_w, long long items_o, int tiles_per_item_o) {
-  const double rw = static_cast<double>((items_w + kWideCtas - 1) / kWideCtas);
-  const double ro = static_cast<double>((items_o + 2 * kWideCtas - 1) / (2 * kWideCtas));
-  const double tw = fmax(static_cast<double>(items_w) * tiles_per_item_w * 3.6 / kWideCtas, rw * tiles_per_item_w * 1.9) + rw * 10.0;
-  const double to = fmax(static_cast<double>(items_o) * tiles_per_item_o * 2.3 / (2 * kWideCtas), ro * tiles_per_item_o * 1.3);
+  // time of a launch = its full rounds at the loaded tile time + the last, partly filled round at a tile time interpolated
+  // towards the unloaded one, plus per-round and per-launch costs that do not overlap the matrix work
+  auto launch_us = [](long long items, int slots, int tiles, double t_full, double t_min, double per_round, double fixed) {
+    const long long full = items / slots, rest = items % slots;
+    const double part = rest ? t_min + (t_full - t_min) * static_cast<double>(rest) / slots : 0.0;
+    return (static_cast<double>(full) * t_full + part) * tiles + static_cast<double>(full + (rest ? 1 : 0)) * per_round + fixed;
+  };
+  // 256 wide: 10 us per item for the unoverlapped epilogue, 15 us per launch (pipeline fill of the stream, fallback launch);
+  // 128 wide: 6 us per round of items for the part of prologue + epilogue its three workgroups per CU do not hide
+  const double tw = launch_us(items_w, kWideCtas, tiles_per_item_w, 3.6, 1.9, 10.0, 15.0);
+  const double to = launch_us(items_o, 2 * kWideCtas, tiles_per_item_o, 2.3, 1.3, 6.0, 0.0);
   return tw < to;
 }
 

@@ -68,8 +68,9 @@ __device__ __forceinline__ void dma_unit(const char* src, unsigned lds) {
 //   phase 0, 3       two LDS-DMA instructions each: B's planes of tiles g+1 (second half) and g+2 (first half)
 //   end of phase 2   the wave's 32 x 32 fp32 block of A of tile g+1 (requested a tile ago) -> block maximum (DPP) ->
 //                    exponent -> two f16 planes -> LDS stage PAR^1; then vmcnt(0): B's tile g+1 has landed
-//   phase 3          lgkmcnt(0), THE barrier of the tile: tile g+1 is complete and tile g's stages are free; request A's
-//                    block of tile g+2, read tile g+1's first fragments and exponents
+//                    request A's block of tile g+2 (the registers are free again)
+//   phase 3          lgkmcnt(0), THE barrier of the tile: tile g+1 is complete and tile g's stages are free; read tile
+//                    g+1's first fragments and exponents
 // A's scale block is 32 x 32 (one tile), B's 32 x 64.  LDS: 2 x 32 KiB A planes + 2 x 32 KiB B planes + 16 KiB epilogue
 // staging (2 KiB per wave: 16 x 32 blocks -> 128-byte row segments; the stages stay live across an item's end) + A's block
 // exponents + 8 KiB B exponents (per wave, double-buffered chunks of 64 blocks).
@@ -356,7 +357,6 @@ __global__ __launch_bounds__(512, 1) void gemm_x3dp_kernel(const GemmArgs g, con
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        load_a(r2, kt_r2);
         read_a(0, PAR ^ 1, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) ea_v[q] = exp_lds[(PAR ^ 1) * 8 + wm * 4 + q];
@@ -384,6 +384,8 @@ __global__ __launch_bounds__(512, 1) void gemm_x3dp_kernel(const GemmArgs g, con
         asm volatile("" ::: "memory");
         store_a(r1, kt_r1, PAR ^ 1, !more1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        load_a(r2, kt_r2);      // the registers are free again: A's block of tile g+2 is requested a phase ahead of the barrier
+        asm volatile("" ::: "memory");
       }
     }
     if (new_chunk) { cb ^= 1; need_req = true; }

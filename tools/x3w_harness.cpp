@@ -212,7 +212,13 @@ int main(int argc, char** argv) {
         {D, ld, nu, 1, 0, "c5 dWext 256x4160x1M TN"},
         {1250000, D, D, 0, 1, "c5 out_fc 1.25Mx256x256 NT"},
         {10677, 2560, 256, 0, 1, "ml10m TF fwd"},
-        {69878, 256, 256, 0, 1, "ml10m out_fc"}};
+        {69878, 256, 256, 0, 1, "ml10m out_fc"},
+        {10677, 256, 2624, 0, 1, "ml10m AF fwd"},
+        {10677, 256, 2560, 0, 0, "ml10m dX"},
+        {2560, 256, 10677, 1, 0, "ml10m dW"},
+        {256, 2624, 10677, 1, 0, "ml10m dWext"},
+        {69878, 256, 256, 0, 0, "ml10m out_fc dX"},
+        {256, 256, 69878, 1, 0, "ml10m out_fc dW"}};
     if (const char* only = getenv("X3W_ONLY")) {
       std::vector<Case> sel;
       for (const Case& c : cases) if (strstr(c.name, only)) sel.push_back(c);
