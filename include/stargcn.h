@@ -383,6 +383,40 @@ int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* const* db
                              void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * (8b) aggregate -> contract in ONE kernel (csrc/agg_fused.hip): the aggregation of (8) without its R-expanded
+ *     intermediate.  Reference: the same MultiLinkGCNAggregator.hybrid_forward (aggregators.py:141-160: R FullyConnected
+ *     outputs written and re-read by R seg_weighted_pool ops).
+ *        out (n_dst, ldo) = act( sum_r (A_r x) B_r + sum_r rowsum[:, r] b_r )        x (n_src, ldx), 256 wide; out 256 wide
+ *     A workgroup owns 64 destination rows; per level the aggregate lives as two f16 planes in LDS and is multiplied by
+ *     B_r on the matrix cores (three f16 MFMAs per product, error model of sg_gemm_backend 3 with one scale per
+ *     (row, level) of the aggregate and per (level, 32 output columns) of B_r) while the next level is gathered.
+ *     weights[r] (host array of R device pointers, leading dimension ldw): trans_w = 0 -> (256 out, 256 in), B_r = W_r^T
+ *     (the forward); trans_w = 1 -> (256 in, 256 out), B_r = W_r (the data gradient over the transposed plan: out = dx,
+ *     x = dpre).  biases (host array of R device pointers) / rowsum (n_dst, R) may be NULL: no bias term.
+ *     zsave (n_dst, ldz), optional: receives the fp32 aggregates [r * 256 + k] (what the weight gradient contracts with).
+ *     Plan: sg_agg_fused_plan_build_hip reorders the edges of every 64-row tile of a (row, level)-major CSR -- segment
+ *     i * R + r at indptr[i * R + r], the c_* / t_* arrays of sg_multilink_plan -- level-major: f_ptr (tiles * R * 65
+ *     absolute edge offsets, 65 per (launch slot, level)), f_idx / f_w (nnz; the edges stay inside their tile's range),
+ *     optional f_pos (nnz: source position of every edge, for sg_agg_fused_refresh_hip after the weights were rewritten).
+ *     tile_order (tiles; NULL = identity): the tile of every launch slot, e.g. by descending edge count; must be the
+ *     same array at build and at launch.  nt_loads != 0: gathered rows are read non-temporally (sources far beyond the
+ *     Infinity Cache: keeps B_r's planes in L2).  Deterministic; no atomics.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t sg_agg_fused_tiles(int64_t n_dst);
+int sg_agg_fused_supported(int64_t in_dim, int64_t out_dim, int32_t num_links);
+int sg_agg_fused_plan_build_hip(int32_t* f_ptr, int32_t* f_idx, float* f_w, int32_t* f_pos, const int32_t* tile_order,
+                                const int32_t* indptr, const int32_t* indices, const float* weights, int64_t n_dst,
+                                int32_t num_links, int64_t nnz, void* stream);
+int sg_agg_fused_refresh_hip(float* f_w, const int32_t* f_pos, const float* weights, int64_t nnz, void* stream);
+size_t sg_agg_fused_workspace_bytes(int32_t num_links);
+int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, const float* x, int64_t ldx,
+                     const float* const* weights, int64_t ldw, int trans_w, const float* const* biases,
+                     const float* rowsum, const int32_t* f_ptr, const int32_t* f_idx, const float* f_w,
+                     const int32_t* tile_order, int64_t n_dst, int32_t num_links, int64_t nnz, int64_t in_dim,
+                     int64_t out_dim, int act, float slope, int nt_loads, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (9) per-batch edge removal on the device.  Reference: HeterGraph.remove_edges_by_id in both
  *     directions (graph.py:952-974 -> graph_sampler.cpp:154-201), then fresh degrees + support (graph.py:401-429), a
  *     new plan (layers.py:260-337) and new uploads (layers.py:366-377) on EVERY training iteration.

@@ -135,6 +135,13 @@ _SIGS = {
     "sg_multilink_agg_workspace_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT, _INT]),
     "sg_multilink_agg_fwd_hip": (_INT, [_P] * 6 + [_I64, _I64, _INT, _INT, _INT, _F32, _P, _SZ, _P]),
     "sg_multilink_agg_bwd_hip": (_INT, [_P] * 9 + [_I64, _I64, _INT, _INT, _INT, _F32, _P, _SZ, _P]),
+    "sg_agg_fused_tiles": (_I64, [_I64]),
+    "sg_agg_fused_supported": (_INT, [_I64, _I64, _c.c_int32]),
+    "sg_agg_fused_plan_build_hip": (_INT, [_P] * 8 + [_I64, _c.c_int32, _I64, _P]),
+    "sg_agg_fused_refresh_hip": (_INT, [_P, _P, _P, _I64, _P]),
+    "sg_agg_fused_workspace_bytes": (_SZ, [_c.c_int32]),
+    "sg_agg_fused_hip": (_INT, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _INT, _P, _P, _P, _P, _P, _P, _I64, _c.c_int32,
+                                _I64, _I64, _I64, _INT, _F32, _INT, _P, _SZ, _P]),
 }
 
 

@@ -1,0 +1,710 @@
+// agg_fused.hip -- aggregate -> contract in ONE kernel: the multi-link graph convolution without its R-expanded intermediate.
+//
+//   out[i, :] = act( sum_r ( sum_{e in seg(i, r)} w_e x[idx_e, :] ) B_r  +  sum_r rowsum[i, r] b_r )
+//
+// Reference: MultiLinkGCNAggregator.hybrid_forward (mxgraph/layers/aggregators.py:141-160) computes, per rating level r,
+// h_r = FullyConnected(x) (written, n_src x U) and seg_weighted_pool(h_r) and adds the R results; the unfused path of
+// this library (multilink.hip) does one gather into an R-expanded matrix (n x R*D floats: 16 GB at the config-5 shard)
+// and one GEMM that reads it back.  Here a workgroup owns a TILE of 64 destination rows; for every level r the
+// aggregate Z_r (64 x 256 fp32) exists only as two f16 planes in LDS, is multiplied by B_r (256 x 256, L2-resident
+// planes) on the matrix cores, and only `out` (and, for the backward's weight gradient, optionally Z itself) is written.
+//
+// Work split inside the workgroup (8 waves, ONE workgroup per CU, persistent over its tiles):
+//   waves 0-3  "G"  gather.  Each owns a contiguous run of the tile's rows at the current level (the level's edges split
+//              four ways by count), streams their source rows -- 1 KiB per row, one float4 per lane, NB = 16 rows in flight per
+//              wave across row, level and tile boundaries -- accumulates in fp32, and when a row is complete scales it by a
+//              power of two (row maximum -> [2^14, 2^15)), splits it into an f16 value + f16 residual and writes both to the
+//              level's LDS buffer.
+//   waves 4-7  "M"  matrix.  Each owns 64 of the 256 output columns for all 64 rows: after the barrier that publishes level
+//              r's planes it runs 16 k-steps x 12 v_mfma_f32_32x32x16_f16 (value x value, value x residual, residual x value:
+//              fp32 accuracy, gemm_f16x3.hip) into a level-local product P, with B_r's fragments loaded straight from L2 into
+//              registers (fragment-major planes, one 1 KiB unit per wave load), then folds P * 2^-(e_row + e_B) into the
+//              running result.  After the last level: bias term, activation, store.
+//   One s_barrier per (tile, level): G has finished level q+1 in buffer (q+1)&1, M has finished reading level q-1 from it.
+//   The G waves never wait for memory at a barrier: loads stay in flight across it (only LDS traffic is drained).
+// The matrix work (3 x 2 x 64 x 256 x 256 flops per tile and level = 15 % of the launch at the config-5 shard) rides
+// under the HBM time of the gather (measured: profiles/r5_fused_agg.txt).
+//
+// Plan ("f-plan"): the edges of a tile reordered level-major -- segment (tile t, level r, row j) at f_ptr[(t R + r) 64 + j]
+// -- so that a level's edges of a tile are one contiguous run.  Built on the device from the plan's (row, level)-major CSR
+// (a tile's edges are the same contiguous range in both orders: the permutation is local to the tile).
+//
+// Accuracy: Z_r rows carry one scale per (row, level) (256 elements), B_r one per (level, 32 output columns); error model
+// as gemm_f16x3.hip (block-relative 3 x 2^-22 per product term); the aggregation itself is plain fp32 FMA in edge order.
+#include "gemm_x3_shared.hpp"
+
+namespace sg {
+namespace fused {
+
+using f16x3::f16x2;
+using f16x3::f16x8;
+using f16x3::f32x16;
+using f16x3::f32x2;
+using f16x3::f32x4;
+using f16x3::wave_max_nonneg;
+
+constexpr int TM = 64;                    // destination rows per tile
+constexpr int KD = 256;                   // width of the gathered rows (contraction length per level)
+constexpr int ND = 256;                   // output width
+constexpr int KS = KD / 16;               // k steps per level
+constexpr int NJB = ND / 32;              // 32-column blocks of the output
+constexpr int NB = 16;                    // rows in flight per G wave
+constexpr int ZROW = KD * 2 + 16;         // bytes per row and plane in LDS: 528 = 132 words -> rows 4 banks apart
+constexpr int ZPLANE = TM * ZROW;
+constexpr int ZBUF = 2 * ZPLANE;          // value plane, residual plane
+constexpr int SMEM = 2 * ZBUF + 2 * TM * 4 + 2 * TM * SG_MAX_LINKS * 4;
+
+struct Args {
+  const int32_t* f_ptr;
+  const int32_t* f_idx;
+  const float* f_w;
+  const int32_t* tile_order;   // may be null
+  const float* x;
+  long long ldx;
+  const char* wplanes;         // unit (((r NJB + jb) KS + ks) 2 + plane): lane l holds B_r[n = 32 jb + (l & 31)][k = 16 ks + 8 (l >> 5) ..+7]
+  const float* wscale;         // (R NJB) 2^-e of the block
+  const float* bias;           // (R, ND) packed, or null
+  const float* rowsum;         // (n_dst, R), or null
+  float* out;
+  long long ldo;
+  float* zsave;                // (n_dst, ldz) fp32 aggregates [r KD + k], or null
+  long long ldz;
+  int n_dst, n_tiles, R;
+  int act;
+  float slope;
+};
+
+__device__ __forceinline__ unsigned wave_or(unsigned v) {
+  auto step = [&](auto ctrl, auto row_mask) __attribute__((always_inline)) {
+    v |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), decltype(ctrl)::value,
+                                                            decltype(row_mask)::value, 0xf, true));
+  };
+  using std::integral_constant;
+  step(integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});
+  step(integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});
+  step(integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});
+  step(integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});
+  step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});
+  step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});
+  return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
+struct Ctx {                    // one (item = tile x level, G wave): the rows and edges this wave owns
+  int pv, pn;                   // per lane j: first / past-the-end edge of tile row j at this level
+  unsigned long long rows;      // my non-empty rows
+  unsigned long long empt;      // my empty rows
+  int e_lo, e_hi, ng;           // my edges; groups of NB (at least one, possibly all padding)
+  int tile, r, it;              // tile = launch slot of the tile; it = ordinal of the item in this workgroup's sequence
+};
+
+template <bool ZSAVE, bool NT>
+__global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  float* sinv = reinterpret_cast<float*>(smem + 2 * ZBUF);       // [buffer][row] 2^-e of the row's planes
+  const int t = threadIdx.x, lane = t & 63, wave = rfl(t >> 6);
+  const int G = gridDim.x, b = blockIdx.x;
+  const int n_my = (a.n_tiles - b + G - 1) / G;                  // tiles b, b + G, ... (through tile_order when given)
+  const int n_items = n_my * a.R;
+  // slot = position in the launch order (tile_order[slot] = tile, or slot itself): the plan's pointers are slot-major, the
+  // tile id is only needed for output rows and comes through the scalar cache
+  auto tile_of = [&](int slot) __attribute__((always_inline)) -> int {
+    if (!a.tile_order) return slot;
+    return *((f16x3::cst_int*)(a.tile_order) + slot);
+  };
+
+  if (wave < 4) {
+    // ================================================= G: gather =====================================================
+    const int gw = wave;
+    auto load_ptrs = [&](int it, int& slot, int& r, int& pv, int& pn) __attribute__((always_inline)) {
+      const int itc = min(it, n_items - 1);
+      const int ti = itc / a.R;
+      r = itc - ti * a.R;
+      slot = b + ti * G;
+      const long long base = (static_cast<long long>(slot) * a.R + r) * (TM + 1);
+      pv = a.f_ptr[base + lane];
+      pn = a.f_ptr[base + lane + 1];
+    };
+    auto make_ctx = [&](int it, int slot, int r, int pv, int pn) __attribute__((always_inline)) {
+      Ctx c;
+      // real copies (not aliases of the F registers): the next item's pointers are loaded into those while this context lives
+      asm volatile("v_mov_b32 %0, %1" : "=v"(c.pv) : "v"(pv));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(c.pn) : "v"(pn));
+      c.tile = slot; c.r = r; c.it = it;
+      const int p0 = __builtin_amdgcn_readlane(pv, 0), pE = __builtin_amdgcn_readlane(pn, 63);
+      const long long total = pE - p0;
+      const int t1 = p0 + static_cast<int>(total / 4), t2 = p0 + static_cast<int>(total / 2), t3 = p0 + static_cast<int>(total * 3 / 4);
+      const int wj = (total > 0) ? (pv >= t1) + (pv >= t2) + (pv >= t3) : 0;
+      const unsigned long long mine = __ballot(wj == gw);
+      const unsigned long long nonempty = __ballot(pn > pv);
+      c.rows = mine & nonempty;
+      c.empt = mine & ~nonempty;
+      if (mine != 0ull) {
+        const int j_lo = __ffsll(static_cast<long long>(mine)) - 1;
+        const int j_hi = j_lo + __popcll(mine);
+        c.e_lo = __builtin_amdgcn_readlane(pv, j_lo);
+        c.e_hi = __builtin_amdgcn_readlane(pn, j_hi - 1);
+      } else {
+        c.e_lo = 0; c.e_hi = 0;
+      }
+      if (it >= n_items) { c.rows = 0ull; c.empt = 0ull; c.e_hi = c.e_lo; }      // past the end of the stream: padding only
+      c.ng = max(1, (c.e_hi - c.e_lo + NB - 1) / NB);
+      return c;
+    };
+    // (idx, w) of the NB edges of group gi, one edge per lane (lanes >= NB and edges past the end: clamped, never used)
+    auto load_meta = [&](const Ctx& c, int gi, int& m_idx, float& m_w) __attribute__((always_inline)) {
+      const int e = max(min(c.e_lo + gi * NB + lane, c.e_hi - 1), 0);
+      m_idx = a.f_idx[e];
+      m_w = a.f_w[e];
+    };
+    // bit k: edge k of the group is the last edge of one of my rows
+    auto end_mask = [&](const Ctx& c, int gi) __attribute__((always_inline)) {
+      const int gb = c.e_lo + gi * NB;
+      const int rel = c.pn - 1 - gb;
+      const bool mine = ((c.rows >> lane) & 1ull) != 0ull;
+      const unsigned bit = (mine && rel >= 0 && rel < NB) ? (1u << rel) : 0u;
+      return wave_or(bit);
+    };
+
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    auto load_row = [&](f32x4& dst, int idx) __attribute__((always_inline)) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(xb + static_cast<long long>(idx) * a.ldx * 4) + lane;
+      if (NT) dst = __builtin_nontemporal_load(p);
+      else dst = *p;
+    };
+
+    // a finished row: row maximum -> scale -> two f16 planes in the item's LDS buffer (+ the fp32 row to zsave)
+    auto emit = [&](const Ctx& c, int j, const f32x4& acc) __attribute__((always_inline)) {
+      float mx = fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+      mx = wave_max_nonneg(mx);
+      bool nonfinite = false;
+      if (__builtin_expect(!(mx <= 3.402823466e38f), 0)) {
+        nonfinite = true;
+        float mf = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float v = fabsf(acc[i]); mf = fmaxf(mf, v <= 3.402823466e38f ? v : 0.f); }
+        mx = wave_max_nonneg(mf);
+      }
+      int e = 0;
+      {
+        const unsigned bits = __float_as_uint(mx);
+        const int ex = static_cast<int>((bits >> 23) & 0xffu);
+        if (bits != 0u && ex != 0xff) e = 14 - (max(ex, 1) - 127);
+        e = min(max(e, -126), 126);
+      }
+      const float sc = __uint_as_float(static_cast<unsigned>(127 + e) << 23);
+      unsigned h1[2], h2[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f32x2 v = {acc[2 * i] * sc, acc[2 * i + 1] * sc};
+        const f16x2 hi = __builtin_convertvector(v, f16x2);
+        f32x2 res = {__builtin_fmaf(acc[2 * i], sc, -static_cast<float>(hi[0])),
+                     __builtin_fmaf(acc[2 * i + 1], sc, -static_cast<float>(hi[1]))};
+        if (nonfinite) {
+          if (fabsf(v[0]) == __builtin_inff()) res[0] = 0.f;
+          if (fabsf(v[1]) == __builtin_inff()) res[1] = 0.f;
+        }
+        const f16x2 lo = __builtin_convertvector(res, f16x2);
+        h1[i] = __builtin_bit_cast(unsigned, hi);
+        h2[i] = __builtin_bit_cast(unsigned, lo);
+      }
+      char* zb = smem + (c.it & 1) * ZBUF + j * ZROW + lane * 8;
+      *reinterpret_cast<uint2*>(zb) = make_uint2(h1[0], h1[1]);
+      *reinterpret_cast<uint2*>(zb + ZPLANE) = make_uint2(h2[0], h2[1]);
+      if (lane == 0) sinv[(c.it & 1) * TM + j] = __uint_as_float(static_cast<unsigned>(127 - e) << 23);
+      if (ZSAVE) {
+        const long long row = static_cast<long long>(tile_of(c.tile)) * TM + j;
+        if (row < a.n_dst)
+          __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.zsave + row * a.ldz + static_cast<long long>(c.r) * KD) + lane);
+      }
+    };
+    auto emit_zero = [&](const Ctx& c, int j) __attribute__((always_inline)) {
+      char* zb = smem + (c.it & 1) * ZBUF + j * ZROW + lane * 8;
+      *reinterpret_cast<uint2*>(zb) = make_uint2(0u, 0u);
+      *reinterpret_cast<uint2*>(zb + ZPLANE) = make_uint2(0u, 0u);
+      if (lane == 0) sinv[(c.it & 1) * TM + j] = 1.f;
+      if (ZSAVE) {
+        const long long row = static_cast<long long>(tile_of(c.tile)) * TM + j;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (row < a.n_dst)
+          __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(a.zsave + row * a.ldz + static_cast<long long>(c.r) * KD) + lane);
+      }
+    };
+
+    // ---- the stream: three stages one group apart -- M loads (idx, w) of group s + 2, I issues the row loads of group
+    // s + 1, C consumes group s.  Every item has at least one group, so the three stages span at most three items.
+    int tF, rF, pvF, pnF, itF = 0;                       // F: pointers of the item after stage M's
+    load_ptrs(0, tF, rF, pvF, pnF);
+    Ctx cM = make_ctx(0, tF, rF, pvF, pnF);
+    int giM = 0;
+    itF = 1;
+    load_ptrs(itF, tF, rF, pvF, pnF);
+    auto advance_m = [&]() __attribute__((always_inline)) {
+      if (giM + 1 < cM.ng) { ++giM; return; }
+      cM = make_ctx(itF, tF, rF, pvF, pnF);
+      giM = 0;
+      ++itF;
+      load_ptrs(itF, tF, rF, pvF, pnF);
+    };
+
+    int mI_idx, mM_idx;
+    float mI_w, mM_w;
+    f32x4 x[NB];
+    float w_cur[NB], w_nxt[NB];
+    unsigned end_cur, end_nxt;
+
+    // fill: group 0 -> meta; group 1 -> meta, group 0 -> rows
+    load_meta(cM, giM, mI_idx, mI_w);
+    Ctx cI = cM;
+    int giI = giM;
+    advance_m();
+    load_meta(cM, giM, mM_idx, mM_w);
+    {
+      const int gb = cI.e_lo + giI * NB;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int idx = __builtin_amdgcn_readlane(mI_idx, k);
+        const float wv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mI_w), k));
+        w_cur[k] = (gb + k < cI.e_hi) ? wv : 0.f;
+        load_row(x[k], idx);
+      }
+      end_cur = end_mask(cI, giI);
+    }
+    Ctx cC = cI;
+    int giC = giI;
+    cI = cM; giI = giM;
+    mI_idx = mM_idx; mI_w = mM_w;
+    advance_m();
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    unsigned long long rem = cC.rows;                    // my rows of the consume item that are still open
+
+    for (;;) {
+      // stage M
+      load_meta(cM, giM, mM_idx, mM_w);
+      // stage C enters an item: its empty rows (the barrier that freed this buffer ended the previous item)
+      if (giC == 0) {
+        unsigned long long em = cC.empt;
+        while (em != 0ull) {
+          const int j = __ffsll(static_cast<long long>(em)) - 1;
+          em &= em - 1ull;
+          emit_zero(cC, j);
+        }
+        rem = cC.rows;
+      }
+      const int gbI = cI.e_lo + giI * NB;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        // C: edge k of group giC
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = __builtin_fmaf(w_cur[k], x[k][v], acc[v]);
+        if ((end_cur >> k) & 1u) {
+          const int j = __ffsll(static_cast<long long>(rem)) - 1;
+          rem &= rem - 1ull;
+          emit(cC, j, acc);
+          acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // I: edge k of group giI into the registers just released
+        const int idx = __builtin_amdgcn_readlane(mI_idx, k);
+        const float wv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mI_w), k));
+        w_nxt[k] = (gbI + k < cI.e_hi) ? wv : 0.f;
+        load_row(x[k], idx);
+      }
+      end_nxt = end_mask(cI, giI);
+      // the consume item ends with this group: publish it
+      const bool item_done = (giC + 1 == cC.ng);
+      const bool last = item_done && (cC.it + 1 >= n_items);
+      if (item_done) {
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if (last) break;
+      // shift the stages
+      cC = cI; giC = giI;
+      cI = cM; giI = giM;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) w_cur[k] = w_nxt[k];
+      end_cur = end_nxt;
+      mI_idx = mM_idx; mI_w = mM_w;
+      advance_m();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // =================================================== M: matrix ======================================================
+  const int wn = wave - 4;                                 // output columns [64 wn, 64 wn + 64)
+  const int l31 = lane & 31, kh = lane >> 5;
+  float* rs_lds = reinterpret_cast<float*>(smem + 2 * ZBUF + 2 * TM * 4);      // [tile parity][row][r] support row sums
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  const char* bw = a.wplanes + lane * 16;
+  auto load_b = [&](f16x8 (&bf)[2], int r, int j, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      bf[p] = *reinterpret_cast<const f16x8*>(bw + ((((static_cast<long long>(r) * NJB + wn * 2 + j) * KS + ks) * 2 + p) << 10));
+  };
+  auto read_a = [&](f16x8 (&af)[2][2], int buf, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        af[i][p] = *reinterpret_cast<const f16x8*>(smem + buf * ZBUF + p * ZPLANE + (32 * i + l31) * ZROW + (ks * 2 + kh) * 16);
+  };
+  const bool has_bias = a.bias && a.rowsum;
+
+  int it = 0;
+  for (int ti = 0; ti < n_my; ++ti) {
+    const int tile = tile_of(b + ti * G);
+    const long long row0 = static_cast<long long>(tile) * TM;
+    if (has_bias) {       // this tile's support row sums -> LDS (each M wave a quarter; the level barriers publish them)
+      float* dst = rs_lds + (ti & 1) * TM * a.R;
+      const int cnt = TM * a.R;
+      for (int e = wn * 64 + lane; e < cnt; e += 256) {
+        const long long row = row0 + e / a.R;
+        dst[e] = row < a.n_dst ? a.rowsum[row0 * a.R + e] : 0.f;
+      }
+    }
+    for (int r = 0; r < a.R; ++r, ++it) {
+      f16x8 bF[3][2];
+      load_b(bF[0], r, 0, 0);                               // B does not depend on the gather: requested ahead of the barrier
+      load_b(bF[1], r, 0, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // item `it` is published
+      asm volatile("" ::: "memory");
+      const int buf = it & 1;
+      float sa[2][16];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinv + buf * TM + 32 * i + 8 * g4 + 4 * kh);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) sa[i][4 * g4 + v] = s4[v];
+        }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 P[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) P[i][q] = 0.f;
+        f16x8 aF[2][2][2];
+        read_a(aF[0], buf, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          // B fragments two k steps ahead (straight into the other column half at the end of this one)
+          const int s2 = j * KS + ks + 2;
+          if (s2 < 2 * KS) load_b(bF[s2 % 3], r, s2 / KS, s2 % KS);
+          if (ks + 1 < KS) read_a(aF[(ks + 1) & 1], buf, ks + 1);
+          asm volatile("" ::: "memory");                      // the requests stay HERE: two (B) / one (A) k steps ahead of their use
+          __builtin_amdgcn_sched_barrier(0);
+          const f16x8 (&af)[2][2] = aF[ks & 1];
+          const f16x8 (&bf)[2] = bF[(j * KS + ks) % 3];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) P[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[0], P[i], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) P[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[1], P[i], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) P[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[0], P[i], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // fold: acc += P * 2^-e_row * 2^-e_B
+        const float sb = a.wscale[r * NJB + wn * 2 + j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[i][j][q] = __builtin_fmaf(P[i][q] * sa[i][q], sb, acc[i][j][q]);
+      }
+    }
+    // ---- the tile's result: bias term, activation, store ----
+    if (has_bias) {
+      const float* rs = rs_lds + (ti & 1) * TM * a.R + (4 * kh) * a.R;
+      for (int r = 0; r < a.R; ++r) {
+        float bv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = a.bias[r * ND + wn * 64 + 32 * j + l31];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float s = rs[(32 * i + (q & 3) + 8 * (q >> 2)) * a.R + r];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j][q] = __builtin_fmaf(s, bv[j], acc[i][j][q]);
+          }
+      }
+    }
+    auto store_tile = [&](auto actc) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const long long row = row0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * kh;
+          if (row < a.n_dst) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              a.out[row * a.ldo + wn * 64 + 32 * j + l31] = f16x3::act_fn(acc[i][j][q], ACT, a.slope);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j][q] = 0.f;
+        }
+    };
+    switch (a.act) {
+      case SG_ACT_LEAKY: store_tile(std::integral_constant<int, SG_ACT_LEAKY>{}); break;
+      case SG_ACT_RELU: store_tile(std::integral_constant<int, SG_ACT_RELU>{}); break;
+      case SG_ACT_SIGMOID: store_tile(std::integral_constant<int, SG_ACT_SIGMOID>{}); break;
+      case SG_ACT_TANH: store_tile(std::integral_constant<int, SG_ACT_TANH>{}); break;
+      default: store_tile(std::integral_constant<int, SG_ACT_NONE>{}); break;
+    }
+  }
+}
+
+// ---- B planes: one workgroup per (level r, 32-column block jb): block maximum -> scale -> fragment-major f16 planes.
+// trans = 0: B_r[n][k] = W_r[n * ldw + k] (forward: W_r is (units, in_dim)); trans = 1: B_r[n][k] = W_r[k * ldw + n]
+// (data gradient: contraction over the units).  Also packs the level biases into (R, ND).
+struct WTable {
+  const float* w[SG_MAX_LINKS];
+  const float* b[SG_MAX_LINKS];
+};
+__global__ __launch_bounds__(256) void split_w_kernel(char* __restrict__ planes, float* __restrict__ wscale,
+                                                      float* __restrict__ bias_pack, const WTable tab, long long ldw, int trans) {
+  __shared__ float tile[32][KD + 1];
+  __shared__ float wmax[4];
+  const int r = blockIdx.x / NJB, jb = blockIdx.x - r * NJB;
+  const int t = threadIdx.x;
+  const float* W = tab.w[r];
+  float m = 0.f;
+  if (!trans) {
+    for (int e = t; e < 32 * KD; e += 256) {
+      const int n = e / KD, k = e - n * KD;
+      const float v = W[static_cast<long long>(32 * jb + n) * ldw + k];
+      tile[n][k] = v;
+      m = fmaxf(m, fabsf(v) <= 3.402823466e38f ? fabsf(v) : 0.f);
+    }
+  } else {
+    for (int e = t; e < 32 * KD; e += 256) {
+      const int k = e / 32, n = e - k * 32;
+      const float v = W[static_cast<long long>(k) * ldw + 32 * jb + n];
+      tile[n][k] = v;
+      m = fmaxf(m, fabsf(v) <= 3.402823466e38f ? fabsf(v) : 0.f);
+    }
+  }
+  m = wave_max_nonneg(m);
+  if ((t & 63) == 0) wmax[t >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  int e = 0;
+  {
+    const unsigned bits = __float_as_uint(m);
+    const int ex = static_cast<int>((bits >> 23) & 0xffu);
+    if (bits != 0u && ex != 0xff) e = 14 - (max(ex, 1) - 127);
+    e = min(max(e, -126), 126);
+  }
+  const float sc = __uint_as_float(static_cast<unsigned>(127 + e) << 23);
+  // unit (ks, plane): lane l -> row n = l & 31, k = 16 ks + 8 (l >> 5) .. + 7; thread handles (ks = t / 64 + 4 pass, lane = t % 64)
+  const int lane = t & 63;
+  const int n = lane & 31, kg = lane >> 5;
+  for (int ks = t >> 6; ks < KS; ks += 4) {
+    unsigned h1[4], h2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x0 = tile[n][16 * ks + 8 * kg + 2 * i], x1 = tile[n][16 * ks + 8 * kg + 2 * i + 1];
+      const f32x2 v = {x0 * sc, x1 * sc};
+      const f16x2 hi = __builtin_convertvector(v, f16x2);
+      f32x2 res = {__builtin_fmaf(x0, sc, -static_cast<float>(hi[0])), __builtin_fmaf(x1, sc, -static_cast<float>(hi[1]))};
+      if (fabsf(v[0]) == __builtin_inff()) res[0] = 0.f;
+      if (fabsf(v[1]) == __builtin_inff()) res[1] = 0.f;
+      const f16x2 lo = __builtin_convertvector(res, f16x2);
+      h1[i] = __builtin_bit_cast(unsigned, hi);
+      h2[i] = __builtin_bit_cast(unsigned, lo);
+    }
+    char* u = planes + ((((static_cast<long long>(r) * NJB + jb) * KS + ks) * 2) << 10) + lane * 16;
+    *reinterpret_cast<uint4*>(u) = make_uint4(h1[0], h1[1], h1[2], h1[3]);
+    *reinterpret_cast<uint4*>(u + 1024) = make_uint4(h2[0], h2[1], h2[2], h2[3]);
+  }
+  if (t == 0) wscale[r * NJB + jb] = __uint_as_float(static_cast<unsigned>(127 - e) << 23);
+  if (bias_pack && t < 32) bias_pack[r * ND + 32 * jb + t] = tab.b[r] ? tab.b[r][32 * jb + t] : 0.f;
+}
+
+// ---- f-plan: one workgroup per launch slot (tile = tile_order[slot], or the slot itself).  The tile's edges keep their
+// range of the (row, level)-major CSR (a tile's rows are contiguous there) and are permuted inside it to level-major:
+// segment (r, j) of the tile = source segment (tile * 64 + j) * R + r.  f_ptr: 65 absolute edge offsets per (slot, level).
+__global__ __launch_bounds__(256) void plan_kernel(int32_t* __restrict__ f_ptr, int32_t* __restrict__ f_idx,
+                                                   float* __restrict__ f_w, int32_t* __restrict__ f_pos,
+                                                   const int32_t* __restrict__ tile_order,
+                                                   const int32_t* __restrict__ indptr, const int32_t* __restrict__ idx,
+                                                   const float* __restrict__ w, int n_dst, int R) {
+  __shared__ int s_len[SG_MAX_LINKS * TM + 1];
+  __shared__ int s_src[SG_MAX_LINKS * TM];
+  __shared__ int s_part[256];
+  const int slot = blockIdx.x, t = threadIdx.x;
+  const int tile = tile_order ? tile_order[slot] : slot;
+  const int nseg = R * TM;
+  const int row0 = tile * TM;
+  const int base = indptr[static_cast<long long>(row0) * R];
+  for (int s = t; s < nseg; s += 256) {
+    const int r = s / TM, j = s - r * TM;
+    const int row = row0 + j;
+    int len = 0, src = 0;
+    if (row < n_dst) {
+      const long long cs = static_cast<long long>(row) * R + r;
+      src = indptr[cs];
+      len = indptr[cs + 1] - src;
+    }
+    s_len[s] = len;
+    s_src[s] = src;
+  }
+  __syncthreads();
+  // exclusive scan of s_len (nseg <= 2048): thread t owns segments [t * per, (t + 1) * per)
+  const int per = (nseg + 255) / 256;
+  int sum = 0;
+  for (int s = t * per; s < min(nseg, (t + 1) * per); ++s) sum += s_len[s];
+  s_part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) { const int v = s_part[i]; s_part[i] = run; run += v; }
+    s_len[nseg] = run;
+  }
+  __syncthreads();
+  int run = s_part[t];
+  for (int s = t * per; s < min(nseg, (t + 1) * per); ++s) { const int v = s_len[s]; s_len[s] = run; run += v; }
+  __syncthreads();
+  for (int s = t; s < nseg; s += 256) {
+    const int r = s / TM, j = s - r * TM;
+    int32_t* row_ptr = f_ptr + (static_cast<long long>(slot) * R + r) * (TM + 1);
+    row_ptr[j] = base + s_len[s];
+    if (j == TM - 1) row_ptr[TM] = base + s_len[s + 1];
+  }
+  // copy the edges: one wave per segment, round-robin
+  const int lane = t & 63, wv = t >> 6;
+  for (int s = wv; s < nseg; s += 4) {
+    const int dst = base + s_len[s], src = s_src[s];
+    const int len = s_len[s + 1] - s_len[s];
+    for (int e = lane; e < len; e += 64) {
+      f_idx[dst + e] = idx[src + e];
+      f_w[dst + e] = w[src + e];
+      if (f_pos) f_pos[dst + e] = src + e;
+    }
+  }
+}
+
+__global__ void refresh_kernel(float* __restrict__ f_w, const int32_t* __restrict__ f_pos, const float* __restrict__ w, long long nnz) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < nnz) f_w[i] = w[f_pos[i]];
+}
+
+inline size_t al256(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
+
+}  // namespace fused
+}  // namespace sg
+
+using namespace sg;
+
+SG_API int64_t sg_agg_fused_tiles(int64_t n_dst) { return (n_dst + fused::TM - 1) / fused::TM; }
+
+SG_API int sg_agg_fused_supported(int64_t in_dim, int64_t out_dim, int32_t num_links) {
+  return in_dim == fused::KD && out_dim == fused::ND && num_links >= 1 && num_links <= SG_MAX_LINKS;
+}
+
+// f_ptr: tiles * R * 65 entries; f_idx, f_w (, f_pos: position of every edge in the source order, may be null): nnz.
+// tile_order (tiles, may be null): the tile of every launch slot -- a permutation of 0 .. tiles - 1, e.g. by descending work.
+SG_API int sg_agg_fused_plan_build_hip(int32_t* f_ptr, int32_t* f_idx, float* f_w, int32_t* f_pos, const int32_t* tile_order,
+                                       const int32_t* indptr,
+                                       const int32_t* indices, const float* weights, int64_t n_dst, int32_t num_links,
+                                       int64_t nnz, void* stream) {
+  if (num_links < 1 || num_links > SG_MAX_LINKS || n_dst < 0 || nnz < 0) return fail(SG_ERR_INVALID, "bad size");
+  if (n_dst == 0) return SG_OK;
+  if (!f_ptr || !indptr || (nnz > 0 && (!f_idx || !f_w || !indices || !weights))) return fail(SG_ERR_INVALID, "null pointer argument");
+  const int64_t tiles = sg_agg_fused_tiles(n_dst);
+  if (tiles * num_links * (fused::TM + 1) >= (1ll << 31) - 1 || nnz >= (1ll << 31) - 64) return fail(SG_ERR_INVALID, "plan too large for int32 indices");
+  hipLaunchKernelGGL(fused::plan_kernel, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, static_cast<hipStream_t>(stream), f_ptr,
+                     f_idx, f_w, f_pos, tile_order, indptr, indices, weights, static_cast<int>(n_dst), num_links);
+  return check_launch("fused::plan_kernel");
+}
+
+SG_API int sg_agg_fused_refresh_hip(float* f_w, const int32_t* f_pos, const float* weights, int64_t nnz, void* stream) {
+  if (nnz <= 0) return SG_OK;
+  if (!f_w || !f_pos || !weights) return fail(SG_ERR_INVALID, "null pointer argument");
+  hipLaunchKernelGGL(fused::refresh_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), f_w, f_pos, weights, static_cast<long long>(nnz));
+  return check_launch("fused::refresh_kernel");
+}
+
+SG_API size_t sg_agg_fused_workspace_bytes(int32_t num_links) {
+  const size_t R = static_cast<size_t>(num_links);
+  return fused::al256(R * fused::NJB * fused::KS * 2 * 1024) + fused::al256(R * fused::NJB * 4) + fused::al256(R * fused::ND * 4) + 256;
+}
+
+// out (n_dst, ldo) = act( sum_r (A_r x) B_r + sum_r rowsum[:, r] b_r ),  x (n_src, ldx) of width 256, out width 256.
+// weights[r]: trans_w = 0 -> (256 out, 256 in) row-major with leading dimension ldw (B_r = W_r^T); trans_w = 1 -> (256 in, 256 out)
+// (B_r = W_r).  biases (host array of R device pointers) and rowsum may be null (no bias term).  zsave (n_dst, ldz) receives the
+// fp32 aggregates [r * 256 + k] when not null.  f_*: the level-major plan of sg_agg_fused_plan_build_hip; tile_order may be null.
+SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, const float* x, int64_t ldx,
+                            const float* const* weights, int64_t ldw, int trans_w, const float* const* biases,
+                            const float* rowsum, const int32_t* f_ptr, const int32_t* f_idx, const float* f_w,
+                            const int32_t* tile_order, int64_t n_dst, int32_t num_links, int64_t nnz, int64_t in_dim,
+                            int64_t out_dim, int act, float slope, int nt_loads, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+  if (!sg_agg_fused_supported(in_dim, out_dim, num_links))
+    return fail(SG_ERR_UNSUPPORTED, "fused aggregation handles in_dim = out_dim = 256 (got %lld, %lld)", (long long)in_dim, (long long)out_dim);
+  if (n_dst == 0) return SG_OK;
+  if (nnz < 1) return fail(SG_ERR_UNSUPPORTED, "fused aggregation needs at least one edge");
+  if (!out || !x || !weights || !f_ptr || !f_idx || !f_w) return fail(SG_ERR_INVALID, "null pointer argument");
+  if (act < SG_ACT_NONE || act > SG_ACT_TANH) return fail(SG_ERR_INVALID, "bad activation %d", act);
+  if ((ldx & 3) || !aligned(x, 16) || (zsave && ((ldz & 3) || !aligned(zsave, 16))))
+    return fail(SG_ERR_INVALID, "rows must be 16-byte aligned");
+  if (!workspace || workspace_bytes < sg_agg_fused_workspace_bytes(num_links)) return fail(SG_ERR_WORKSPACE, "fused aggregation workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  const size_t R = static_cast<size_t>(num_links);
+  char* planes = base;
+  float* wscale = reinterpret_cast<float*>(base + fused::al256(R * fused::NJB * fused::KS * 2 * 1024));
+  float* bias_pack = reinterpret_cast<float*>(reinterpret_cast<char*>(wscale) + fused::al256(R * fused::NJB * 4));
+  fused::WTable tab{};
+  for (int r = 0; r < num_links; ++r) {
+    if (!weights[r]) return fail(SG_ERR_INVALID, "weights[%d] is null", r);
+    tab.w[r] = weights[r];
+    tab.b[r] = biases ? biases[r] : nullptr;
+  }
+  const bool has_bias = biases && rowsum;
+  hipLaunchKernelGGL(fused::split_w_kernel, dim3(static_cast<unsigned>(R * fused::NJB)), dim3(256), 0, st, planes, wscale,
+                     has_bias ? bias_pack : static_cast<float*>(nullptr), tab, static_cast<long long>(ldw), trans_w);
+  if (check_launch("fused::split_w_kernel") != SG_OK) return SG_ERR_HIP;
+
+  fused::Args a{};
+  a.f_ptr = f_ptr; a.f_idx = f_idx; a.f_w = f_w; a.tile_order = tile_order;
+  a.x = x; a.ldx = ldx;
+  a.wplanes = planes; a.wscale = wscale;
+  a.bias = has_bias ? bias_pack : nullptr; a.rowsum = has_bias ? rowsum : nullptr;
+  a.out = out; a.ldo = ldo; a.zsave = zsave; a.ldz = ldz;
+  a.n_dst = static_cast<int>(n_dst); a.n_tiles = static_cast<int>(sg_agg_fused_tiles(n_dst)); a.R = num_links;
+  a.act = act; a.slope = slope;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+    return fail(SG_ERR_HIP, "device query");
+  const unsigned grid = static_cast<unsigned>(a.n_tiles < cus ? a.n_tiles : cus);
+  auto launch = [&](auto kern) {
+    static_cast<void>(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, fused::SMEM));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), fused::SMEM, st, a);
+  };
+  if (zsave) { if (nt_loads) launch(fused::agg_contract_kernel<true, true>); else launch(fused::agg_contract_kernel<true, false>); }
+  else { if (nt_loads) launch(fused::agg_contract_kernel<false, true>); else launch(fused::agg_contract_kernel<false, false>); }
+  return check_launch("fused::agg_contract_kernel");
+}

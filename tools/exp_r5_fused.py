@@ -1,0 +1,184 @@
+"""Round 5: the fused aggregate -> contract kernel (csrc/agg_fused.hip) -- correctness against float64 on small graphs and
+timing at the config-5 shard shape against the unfused pair (gather into the R-expanded matrix + the 256-wide GEMM).
+  python tools/exp_r5_fused.py check
+  python tools/exp_r5_fused.py time [n_dst n_src nnz R]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from star_gcn_amd import _lib as L      # noqa: E402
+from star_gcn_amd import ops            # noqa: E402
+
+D = 256
+
+
+def make_graph(n_dst, n_src, nnz, R, dev, seed=0, hub=0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    dst = torch.randint(0, n_dst, (nnz,), device=dev, generator=g)
+    if hub:
+        dst[:hub] = n_dst // 3
+    lvl = torch.randint(0, R, (nnz,), device=dev, generator=g)
+    key = dst * R + lvl
+    key, _ = torch.sort(key)
+    counts = torch.bincount(key, minlength=n_dst * R)
+    indptr = torch.zeros(n_dst * R + 1, dtype=torch.int32, device=dev)
+    indptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    idx = torch.randint(0, n_src, (nnz,), device=dev, generator=g, dtype=torch.int32)
+    w = torch.rand(nnz, device=dev, generator=g) + 0.1
+    return indptr, idx, w
+
+
+def build_plan(indptr, idx, w, n_dst, R, order=None, with_pos=False):
+    lib = L.lib()
+    dev = idx.device
+    tiles = lib.sg_agg_fused_tiles(n_dst)
+    f_ptr = torch.empty(tiles * R * 65, dtype=torch.int32, device=dev)
+    f_idx = torch.empty_like(idx)
+    f_w = torch.empty_like(w)
+    f_pos = torch.empty_like(idx) if with_pos else None
+    L.check(lib.sg_agg_fused_plan_build_hip(L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), L.ptr(f_pos), L.ptr(order), L.ptr(indptr),
+                                            L.ptr(idx), L.ptr(w), n_dst, R, idx.numel(), L.stream_ptr()), "plan_build")
+    return f_ptr, f_idx, f_w, f_pos
+
+
+def fused(x, Ws, bs, rowsum, plan, order, n_dst, R, nnz, act, trans, zsave=None, nt=0):
+    lib = L.lib()
+    f_ptr, f_idx, f_w, _ = plan
+    out = torch.empty(n_dst, D, dtype=torch.float32, device=x.device)
+    ws, wsn = L.workspace(lib.sg_agg_fused_workspace_bytes(R), x.device)
+    wp = ops._ptr_array(Ws)
+    bp = ops._ptr_array(bs) if bs is not None else None
+    L.check(lib.sg_agg_fused_hip(L.ptr(out), D, L.ptr(zsave), zsave.shape[1] if zsave is not None else 0, L.ptr(x), x.shape[1],
+                                 wp, D, trans, bp, L.ptr(rowsum), L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), L.ptr(order), n_dst, R,
+                                 nnz, D, D, ops._act_id(act), 0.1, nt, L.ptr(ws), wsn, L.stream_ptr()), "sg_agg_fused_hip")
+    return out
+
+
+def reference(x, Ws, bs, indptr, idx, w, n_dst, R, act, trans):
+    dev = x.device
+    seg = torch.repeat_interleave(torch.arange(n_dst * R, device=dev), (indptr[1:] - indptr[:-1]).long())
+    Z = torch.zeros(n_dst * R, D, dtype=torch.float64, device=dev)
+    Z.index_add_(0, seg, x.double()[idx.long()] * w.double()[:, None])
+    Z = Z.view(n_dst, R, D)
+    rs = torch.zeros(n_dst * R, dtype=torch.float64, device=dev).index_add_(0, seg, w.double()).view(n_dst, R)
+    out = torch.zeros(n_dst, D, dtype=torch.float64, device=dev)
+    mag = torch.zeros(n_dst, D, dtype=torch.float64, device=dev)
+    for r in range(R):
+        B = Ws[r].double() if trans else Ws[r].double().t()
+        out += Z[:, r] @ B
+        mag += Z[:, r].abs() @ B.abs()
+        if bs is not None:
+            out += rs[:, r:r + 1] * bs[r].double()[None]
+            mag += (rs[:, r:r + 1] * bs[r].double()[None]).abs()
+    if act == "leaky":
+        out = torch.where(out > 0, out, 0.1 * out)
+    return out, mag, Z, rs
+
+
+def check():
+    dev = torch.device("cuda")
+    torch.manual_seed(1)
+    worst = 0.0
+    for (n_dst, n_src, nnz, R, hub, trans, bias, act, perm, zs) in [
+            (1000, 800, 60000, 5, 0, 0, True, "leaky", False, False),
+            (1000, 800, 60000, 5, 3000, 1, False, None, True, True),
+            (64, 50, 10, 1, 0, 0, True, None, False, True),
+            (130, 4000, 200000, 16, 20000, 0, True, "leaky", True, False),
+            (5000, 3000, 400000, 10, 0, 1, True, None, True, True),
+            (33000, 9000, 3000000, 16, 100000, 0, True, "leaky", True, True)]:
+        indptr, idx, w = make_graph(n_dst, n_src, nnz, R, dev, seed=nnz, hub=hub)
+        x = torch.randn(n_src, D, device=dev) * torch.exp(torch.randn(n_src, 1, device=dev))
+        Ws = [torch.randn(D, D, device=dev) / 16 for _ in range(R)]
+        bs = [torch.randn(D, device=dev) for _ in range(R)] if bias else None
+        tiles = (n_dst + 63) // 64
+        order = torch.randperm(tiles, device=dev).to(torch.int32) if perm else None
+        plan = build_plan(indptr, idx, w, n_dst, R, order, with_pos=True)
+        ref, mag, Z, rs = reference(x, Ws, bs, indptr, idx, w, n_dst, R, act, trans)
+        zsave = torch.full((n_dst, R * D + 64), -7.0, device=dev) if zs else None
+        for nt in (0, 1):
+            out = fused(x, Ws, bs, rs.float().contiguous() if bias else None, plan, order, n_dst, R, nnz, act, trans, zsave, nt)
+            torch.cuda.synchronize()
+            err = ((out.double() - ref).abs() / mag.clamp_min(1e-30)).max().item()
+            worst = max(worst, err)
+            msg = "n_dst %6d R %2d nnz %8d trans %d bias %d perm %d nt %d: max |err| / sum|a||b| = %.3g" % (n_dst, R, nnz, trans, bias, perm, nt, err)
+            if zs:
+                zerr = ((zsave[:, :R * D].double().view(n_dst, R, D) - Z).abs().max() / Z.abs().max()).item()
+                msg += "   zsave rel err %.3g, pad untouched %s" % (zerr, bool((zsave[:, R * D:] == -7.0).all()))
+            print(msg, flush=True)
+        # refresh path: new weights through f_pos
+        w2 = torch.rand_like(w) + 0.5
+        f_ptr, f_idx, f_w, f_pos = plan
+        L.check(L.lib().sg_agg_fused_refresh_hip(L.ptr(f_w), L.ptr(f_pos), L.ptr(w2), nnz, L.stream_ptr()), "refresh")
+        ref2, mag2, _, rs2 = reference(x, Ws, bs, indptr, idx, w2, n_dst, R, act, trans)
+        out2 = fused(x, Ws, bs, rs2.float().contiguous() if bias else None, plan, order, n_dst, R, nnz, act, trans)
+        err2 = ((out2.double() - ref2).abs() / mag2.clamp_min(1e-30)).max().item()
+        print("   after refresh: %.3g" % err2, flush=True)
+        worst = max(worst, err2)
+    print("WORST %.3g (%s)" % (worst, "ok" if worst < 2e-6 else "FAIL"))
+
+
+def timeit(fn, n=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def time_case(n_dst, n_src, nnz, R, skew=False):
+    dev = torch.device("cuda")
+    indptr, idx, w = make_graph(n_dst, n_src, nnz, R, dev, seed=3)
+    x = torch.randn(n_src, D, device=dev)
+    Ws = [torch.randn(D, D, device=dev) / 16 for _ in range(R)]
+    bs = [torch.randn(D, device=dev) for _ in range(R)]
+    lens = (indptr[1:] - indptr[:-1]).view(n_dst, R).sum(1)
+    tiles = (n_dst + 63) // 64
+    pad = tiles * 64 - n_dst
+    work = torch.cat([lens, lens.new_zeros(pad)]).view(tiles, 64).sum(1)
+    order = torch.argsort(work, descending=True).to(torch.int32)
+    rs = torch.zeros(n_dst * R, device=dev).index_add_(0, torch.repeat_interleave(
+        torch.arange(n_dst * R, device=dev), (indptr[1:] - indptr[:-1]).long()), w).view(n_dst, R).contiguous()
+    gb = nnz * (8 + 4 * D) / 1e9
+    print("shape: n_dst %d n_src %d nnz %d R %d; algorithmic %.1f GB; max tile work %d, mean %.0f" %
+          (n_dst, n_src, nnz, R, gb, int(work.max()), float(work.float().mean())), flush=True)
+    for name, od in (("identity order", None), ("work-sorted order", order)):
+        plan = build_plan(indptr, idx, w, n_dst, R, od)
+        for nt in (0, 1):
+            t = timeit(lambda: fused(x, Ws, bs, rs, plan, od, n_dst, R, nnz, "leaky", 0, None, nt))
+            print("fused  %-18s nt %d: %.3f ms = %.2f TB/s algorithmic" % (name, nt, t, gb / t), flush=True)
+        del plan
+    plan = build_plan(indptr, idx, w, n_dst, R, order)
+    zsave = torch.empty(n_dst, R * D + 64, device=dev)
+    for nt in (0, 1):
+        t = timeit(lambda: fused(x, Ws, bs, rs, plan, order, n_dst, R, nnz, "leaky", 0, zsave, nt))
+        print("fused + zsave (work-sorted) nt %d: %.3f ms" % (nt, t), flush=True)
+    del plan
+    # the unfused pair: gather into the R-expanded matrix, then the contraction
+    zext = zsave
+    ld = R * D + 64
+    t_g = timeit(lambda: ops.gather_sum(zext, x, idx, indptr, w, n_dst * R, D, dst_group=R, dst_ld=ld))
+    wext = torch.randn(D, ld, device=dev) / 16
+    out = torch.empty(n_dst, D, device=dev)
+    t_m = timeit(lambda: ops.gemm(zext, wext, trans_b=True, act="leaky", out=out))
+    print("unfused: gather %.3f ms (%.2f TB/s) + contraction %.3f ms = %.3f ms" % (t_g, gb / t_g, t_m, t_g + t_m), flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "check":
+        check()
+    else:
+        a = [int(v) for v in sys.argv[2:6]] if len(sys.argv) >= 6 else [1_000_000, 1_250_000, 125_000_000, 16]
+        time_case(*a)
