@@ -110,7 +110,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--shape", default="ml-10m")
     p.add_argument("--dim", type=int, default=256)
-    p.add_argument("--order", default="auto", choices=["auto", "transform_first", "aggregate_first"])
+    p.add_argument("--order", default="auto", choices=["auto", "transform_first", "aggregate_first", "fused"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-hbm-leg", action="store_true")
     p.add_argument("--no-ceiling", action="store_true")

@@ -307,6 +307,7 @@ int sg_take_plan_cpu(int32_t* t_indptr, int32_t* t_pos, int32_t* inv_ids, int32_
 #define SG_ORDER_AUTO 0
 #define SG_ORDER_TRANSFORM_FIRST 1
 #define SG_ORDER_AGGREGATE_FIRST 2
+#define SG_ORDER_FUSED 3                /* aggregate and contract in one kernel (8b); needs plan->fused, 256-wide in / out, 'sum' */
 #define SG_ACCUM_SUM 0
 #define SG_ACCUM_STACK 1
 #define SG_MAX_LINKS 32
@@ -340,6 +341,13 @@ int sg_seg_gather_sum_phased_hip(float* dst, int64_t dst_group, int64_t dst_ld, 
                                  int64_t src_ld, const float* weights, const sg_gather_phases* ph, int64_t seg_num,
                                  int64_t feat_dim, int req, int act, float slope, void* workspace, size_t workspace_bytes,
                                  void* stream, int64_t src_bytes);
+/* Level-major edge order of one CSR of the plan for the fused kernel of (8b) (sg_agg_fused_plan_build_hip); zero = absent */
+typedef struct sg_fused_plan {
+  const int32_t* f_ptr;                 /* tiles * R * 65 */
+  const int32_t* f_idx;                 /* nnz */
+  const float* f_w;                     /* nnz */
+  const int32_t* tile_order;            /* tiles, or NULL */
+} sg_fused_plan;
 typedef struct sg_multilink_plan {      /* all pointers are DEVICE pointers; see sg_multilink_fuse_cpu */
   const int32_t* c_indptr;              /* n_dst*R+1 */
   const int32_t* c_idx;                 /* nnz: source node */
@@ -360,8 +368,17 @@ typedef struct sg_multilink_plan {      /* all pointers are DEVICE pointers; see
                                          * field was `reserved`, documented as 0) or one that does not zero the struct can
                                          * never make it read garbage pointers. */
   sg_gather_phases phases[SG_NUM_VIEWS]; /* optional (zero = absent): source-range phases of the views, by SG_VIEW_* */
+  sg_fused_plan fused[2];               /* optional: [0] over (c_indptr, c_idx, c_w) -- SG_ORDER_FUSED forward; [1] over
+                                         * (t_indptr, t_idx, t_w) -- its data gradient */
 } sg_multilink_plan;
 int sg_multilink_agg_resolve_order(const sg_multilink_plan* plan, int order);
+/* The order sg_multilink_agg_{fwd,bwd}_hip run for these sizes.  SG_ORDER_AUTO resolves to SG_ORDER_FUSED when the fused
+ * kernel handles the widths ('sum', in_dim = units_per_level = 256), the graph is large enough for the R-expanded matrix to
+ * cost HBM time (nnz >= 2^24 and the smaller node side's expanded matrix beyond the 256 MB Infinity Cache; SG_FUSED=0 / 1
+ * in the environment forces never / whenever supported), and otherwise to the rule of sg_multilink_agg_resolve_order.
+ * The caller then attaches plan->fused (both entries) before the launch. */
+int sg_multilink_agg_resolve_order2(const sg_multilink_plan* plan, int order, int64_t in_dim, int64_t units_per_level,
+                                    int accum);
 /* Which gather view (SG_VIEW_*) the fused entries would issue as two source-range phases for these sizes (backward = 0 / 1),
  * or -1 when they would not -- feature width below one 256-byte column slice, gathered matrix outside 24 MB .. 256 MB,
  * SG_GATHER_PHASES=0.  The caller builds phases (sg_gather_phases_build_hip) for THAT view only: a view that can never be
@@ -415,6 +432,10 @@ int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, const f
                      const int32_t* tile_order, int64_t n_dst, int32_t num_links, int64_t nnz, int64_t in_dim,
                      int64_t out_dim, int act, float slope, int nt_loads, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* measurement aid for bench.py, as sg_gather_profile_*: HIP events around every fused launch on its own stream.  read():
+ * (elapsed ms, edges, 1 when the launch also wrote the aggregates) per launch, in launch order; clears the records. */
+int sg_agg_fused_profile_enable(int on);
+int64_t sg_agg_fused_profile_read(float* ms, int64_t* nnz, int32_t* zsave, int64_t capacity);
 
 /* ------------------------------------------------------------------------------------------------
  * (9) per-batch edge removal on the device.  Reference: HeterGraph.remove_edges_by_id in both

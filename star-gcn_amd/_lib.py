@@ -130,6 +130,7 @@ _SIGS = {
     "sg_sample_fix_neighbor_workspace_bytes": (_SZ, [_I64]),
     "sg_sample_fix_neighbor_hip": (_INT, [_P] * 4 + [_I64, _I64, _c.c_uint64, _P, _SZ, _P]),
     "sg_multilink_agg_resolve_order": (_INT, [_P, _INT]),
+    "sg_multilink_agg_resolve_order2": (_INT, [_P, _INT, _I64, _I64, _INT]),
     "sg_multilink_agg_phased_view": (_INT, [_P, _I64, _I64, _INT, _INT, _INT]),
     "sg_multilink_agg_saved_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT]),
     "sg_multilink_agg_workspace_bytes": (_SZ, [_P, _I64, _I64, _INT, _INT, _INT]),
@@ -142,6 +143,8 @@ _SIGS = {
     "sg_agg_fused_workspace_bytes": (_SZ, [_c.c_int32]),
     "sg_agg_fused_hip": (_INT, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _INT, _P, _P, _P, _P, _P, _P, _I64, _c.c_int32,
                                 _I64, _I64, _I64, _INT, _F32, _INT, _P, _SZ, _P]),
+    "sg_agg_fused_profile_enable": (_INT, [_INT]),
+    "sg_agg_fused_profile_read": (_I64, [_P, _P, _P, _I64]),
 }
 
 
@@ -155,12 +158,17 @@ class GatherPhasesStruct(_c.Structure):
                 ("nnz_p", _I64 * 2)]
 
 
+class FusedPlanStruct(_c.Structure):
+    """`sg_fused_plan` of include/stargcn.h."""
+    _fields_ = [("f_ptr", _P), ("f_idx", _P), ("f_w", _P), ("tile_order", _P)]
+
+
 class MultiLinkPlanStruct(_c.Structure):
     """`sg_multilink_plan` of include/stargcn.h (device pointers of a resident MultiLinkPlan)."""
     _fields_ = [(n, _P) for n in ("c_indptr", "c_idx", "c_q", "c_w", "t_indptr", "t_idx", "t_q", "t_w", "d_indptr",
                                   "s_indptr", "rowsum")] + \
                [("n_dst", _I64), ("n_src", _I64), ("nnz", _I64), ("num_links", _c.c_int32), ("struct_bytes", _c.c_int32),
-                ("phases", GatherPhasesStruct * NUM_VIEWS)]
+                ("phases", GatherPhasesStruct * NUM_VIEWS), ("fused", FusedPlanStruct * 2)]
 
 _lib = None
 

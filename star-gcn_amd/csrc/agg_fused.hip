@@ -33,8 +33,32 @@
 // as gemm_f16x3.hip (block-relative 3 x 2^-22 per product term); the aggregation itself is plain fp32 FMA in edge order.
 #include "gemm_x3_shared.hpp"
 
+#include <mutex>
+#include <vector>
+
 namespace sg {
 namespace fused {
+
+// measurement aid (bench.py): HIP events around every fused launch on its own stream while sg_agg_fused_profile_enable is on
+struct ProfRec { hipEvent_t a, b; int64_t nnz; int zsave; };
+static std::mutex g_mu;
+static bool g_on = false;
+static std::vector<ProfRec> g_recs;
+static long prof_begin(hipStream_t st, int64_t nnz, int zsave) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_on) return -1;
+  ProfRec r{};
+  r.nnz = nnz; r.zsave = zsave;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+  (void)hipEventRecord(r.a, st);
+  g_recs.push_back(r);
+  return static_cast<long>(g_recs.size()) - 1;
+}
+static void prof_end(long rec, hipStream_t st) {
+  if (rec < 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (rec < static_cast<long>(g_recs.size())) (void)hipEventRecord(g_recs[rec].b, st);
+}
 
 using f16x3::f16x2;
 using f16x3::f16x8;
@@ -704,7 +728,41 @@ SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, 
     static_cast<void>(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, fused::SMEM));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), fused::SMEM, st, a);
   };
+  const long rec = fused::prof_begin(st, nnz, zsave ? 1 : 0);
   if (zsave) { if (nt_loads) launch(fused::agg_contract_kernel<true, true>); else launch(fused::agg_contract_kernel<true, false>); }
   else { if (nt_loads) launch(fused::agg_contract_kernel<false, true>); else launch(fused::agg_contract_kernel<false, false>); }
+  fused::prof_end(rec, st);
   return check_launch("fused::agg_contract_kernel");
+}
+
+// measurement aid: enable(1) clears old records and returns the previous state; read() synchronises the recorded events and
+// returns up to `capacity` (elapsed ms, edges, 1 if the launch also wrote the aggregates) triples in launch order
+SG_API int sg_agg_fused_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(fused::g_mu);
+  const int was = fused::g_on ? 1 : 0;
+  if (on && !was) {
+    for (auto& r : fused::g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    fused::g_recs.clear();
+  }
+  fused::g_on = on != 0;
+  return was;
+}
+SG_API int64_t sg_agg_fused_profile_read(float* ms, int64_t* nnz, int32_t* zsave, int64_t capacity) {
+  std::lock_guard<std::mutex> lk(fused::g_mu);
+  int64_t n = 0;
+  for (auto& r : fused::g_recs) {
+    if (n < capacity) {
+      float t = 0.f;
+      (void)hipEventSynchronize(r.b);
+      if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) t = -1.f;
+      if (ms) ms[n] = t;
+      if (nnz) nnz[n] = r.nnz;
+      if (zsave) zsave[n] = r.zsave;
+      ++n;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  fused::g_recs.clear();
+  return n;
 }

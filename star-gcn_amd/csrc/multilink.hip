@@ -112,16 +112,48 @@ int resolve_order(const sg_multilink_plan* p, int order) {
   if (order == SG_ORDER_AUTO) return p->n_src <= p->n_dst ? SG_ORDER_TRANSFORM_FIRST : SG_ORDER_AGGREGATE_FIRST;
   return order;
 }
+// SG_FUSED: 0 never, 1 whenever the fused kernel handles the widths, unset / other: the size rule
+int fused_mode() {
+  static const int m = [] { const char* e = getenv("SG_FUSED"); return e ? atoi(e) : -1; }();
+  return m;
+}
+int fused_nt() {       // SG_FUSED_NT=1: gathered rows read non-temporally (measured slower at the config-5 shard: off)
+  static const int m = [] { const char* e = getenv("SG_FUSED_NT"); return e ? atoi(e) : 0; }();
+  return m;
+}
+bool has_fused(const sg_multilink_plan* p, int which) {
+  return p->struct_bytes >= static_cast<int32_t>(offsetof(sg_multilink_plan, fused) + sizeof(p->fused)) &&
+         p->fused[which].f_ptr && p->fused[which].f_idx && p->fused[which].f_w;
+}
+// the order for these widths; AUTO prefers the fused kernel where the R-expanded matrix would cost HBM time
+int resolve_order2(const sg_multilink_plan* p, int order, int64_t in_dim, int64_t upl, int accum) {
+  if (order != SG_ORDER_AUTO) return order;
+  if (accum == SG_ACCUM_SUM && p->nnz > 0 && p->n_dst > 0 && p->n_src > 0 && sg_agg_fused_supported(in_dim, upl, p->num_links)) {
+    const int mode = fused_mode();
+    const int64_t small_side = p->n_src < p->n_dst ? p->n_src : p->n_dst;
+    const bool big = p->nnz >= (1ll << 24) && small_side * p->num_links * in_dim * 4 > (256ll << 20);
+    if (mode == 1 || (mode != 0 && big)) return SG_ORDER_FUSED;
+  }
+  return resolve_order(p, order);
+}
 
 int make_dims(Dims* d, const sg_multilink_plan* p, int64_t in_dim, int64_t upl, int order, int accum) {
   if (!p) return fail(SG_ERR_INVALID, "plan is null");
   if (p->num_links < 1 || p->num_links > SG_MAX_LINKS)
     return fail(SG_ERR_INVALID, "num_links %d outside [1, %d]", p->num_links, SG_MAX_LINKS);
   if (p->n_dst < 0 || p->n_src < 0 || p->nnz < 0 || in_dim < 1 || upl < 1) return fail(SG_ERR_INVALID, "negative / empty size");
-  if (order < SG_ORDER_AUTO || order > SG_ORDER_AGGREGATE_FIRST) return fail(SG_ERR_INVALID, "order %d", order);
+  if (order < SG_ORDER_AUTO || order > SG_ORDER_FUSED) return fail(SG_ERR_INVALID, "order %d", order);
   if (accum != SG_ACCUM_SUM && accum != SG_ACCUM_STACK) return fail(SG_ERR_INVALID, "accum %d", accum);
   d->n_dst = p->n_dst; d->n_src = p->n_src; d->nnz = p->nnz; d->D = in_dim; d->U = upl; d->R = p->num_links;
-  d->order = resolve_order(p, order);
+  d->order = resolve_order2(p, order, in_dim, upl, accum);
+  if (d->order == SG_ORDER_FUSED) {
+    const bool can = accum == SG_ACCUM_SUM && p->nnz > 0 && sg_agg_fused_supported(in_dim, upl, p->num_links) &&
+                     has_fused(p, 0) && has_fused(p, 1);
+    if (!can && order == SG_ORDER_AUTO) d->order = resolve_order(p, SG_ORDER_AUTO);     // a caller that attached no f-plans
+    else if (!can)
+      return fail(SG_ERR_UNSUPPORTED, "SG_ORDER_FUSED needs accum 'sum', in_dim = units_per_level = 256, at least one edge and "
+                                      "plan->fused[0..1] (sg_agg_fused_plan_build_hip)");
+  }
   d->stack = accum == SG_ACCUM_STACK;
   d->RU = d->R * upl;
   d->outw = d->stack ? d->RU : upl;
@@ -145,7 +177,16 @@ Layout make_layout(const Dims& d, bool backward) {
   auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
   const size_t f = sizeof(float);
   size_t sc = 0;
-  if (d.order == SG_ORDER_TRANSFORM_FIRST) {
+  if (d.order == SG_ORDER_FUSED) {
+    sc = sg_agg_fused_workspace_bytes(d.R);
+    if (backward) {
+      L.a = take(d.n_dst * d.outw * f);                                              // dpre
+      L.b = take(d.n_src * d.RU * f);                                                // dH (written by the fused data gradient)
+      L.c = take((d.RU * d.D + d.RU) * f);                                           // dWcat | dbcat
+      sc = max2(sc, max2(sg_seg_weighted_pool_workspace_bytes(1, d.n_src * d.R, d.nnz, d.U),
+                         max2(sg_gemm_f32_workspace_bytes(d.RU, d.D, d.n_src, 1), sg_gemm_f32_workspace_bytes(d.R, d.U, d.n_dst, 1))));
+    }
+  } else if (d.order == SG_ORDER_TRANSFORM_FIRST) {
     L.wpack = take(d.RU * d.D * f);
     L.bpack = take(d.RU * f);
     if (!backward) {
@@ -241,7 +282,7 @@ SG_API int sg_multilink_agg_phased_view(const sg_multilink_plan* plan, int64_t i
   Dims d;
   const int rc = make_dims(&d, plan, in_dim, units_per_level, order, accum);
   if (rc != SG_OK) return rc;
-  if (!sg::phases_on() || d.n_dst == 0 || d.n_src == 0) return -1;
+  if (!sg::phases_on() || d.n_dst == 0 || d.n_src == 0 || d.order == SG_ORDER_FUSED) return -1;
   int view;
   int64_t C, src_bytes;
   if (d.order == SG_ORDER_TRANSFORM_FIRST) {
@@ -261,11 +302,18 @@ SG_API int sg_multilink_agg_resolve_order(const sg_multilink_plan* plan, int ord
   return resolve_order(plan, order);
 }
 
+SG_API int sg_multilink_agg_resolve_order2(const sg_multilink_plan* plan, int order, int64_t in_dim, int64_t units_per_level,
+                                           int accum) {
+  if (!plan) return fail(SG_ERR_INVALID, "plan is null");
+  if (order < SG_ORDER_AUTO || order > SG_ORDER_FUSED) return fail(SG_ERR_INVALID, "order %d", order);
+  return resolve_order2(plan, order, in_dim, units_per_level, accum);
+}
+
 SG_API size_t sg_multilink_agg_saved_bytes(const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level,
                                            int order, int accum) {
   Dims d;
   if (make_dims(&d, plan, in_dim, units_per_level, order, accum) != SG_OK) return 0;
-  return d.order == SG_ORDER_AGGREGATE_FIRST ? static_cast<size_t>(d.n_dst) * d.ld * sizeof(float) : 0;
+  return d.order == SG_ORDER_AGGREGATE_FIRST ? static_cast<size_t>(d.n_dst) * d.ld * sizeof(float) : 0;   // (fused: nothing)
 }
 
 SG_API size_t sg_multilink_agg_workspace_bytes(const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level,
@@ -292,6 +340,14 @@ SG_API int sg_multilink_agg_fwd_hip(float* out, void* saved, const float* x, con
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
   void* scratch = base + L.scratch;
+
+  if (d.order == SG_ORDER_FUSED) {
+    if (d.n_src == 0) return fail(SG_ERR_INVALID, "fused aggregation with edges but no source rows");
+    if (biases && !plan->rowsum) return fail(SG_ERR_INVALID, "the fused order needs plan->rowsum for the bias term");
+    const sg_fused_plan& fp = plan->fused[0];
+    return sg_agg_fused_hip(out, d.U, nullptr, 0, x, d.D, weights, d.D, 0, biases, plan->rowsum, fp.f_ptr, fp.f_idx, fp.f_w,
+                            fp.tile_order, d.n_dst, d.R, d.nnz, d.D, d.U, act, slope, fused_nt(), scratch, L.scratch_bytes, stream);
+  }
 
   if (d.order == SG_ORDER_TRANSFORM_FIRST) {
     float* wcat = reinterpret_cast<float*>(base + L.wpack);
@@ -358,6 +414,41 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
   }
   PtrTable nob;
   for (int r = 0; r < SG_MAX_LINKS; ++r) nob.p[r] = nullptr;
+
+  if (d.order == SG_ORDER_FUSED) {
+    // dx[n] = sum_r (A_r^T dpre)[n] W_r in one kernel over the transposed plan, which also leaves dH = [A_r^T dpre]_r for
+    // the weight gradient dW_r = dH_r^T x; the bias gradient is db_r = sum_i rowsum[i, r] dpre[i] (= the column sums of dH_r)
+    float* dh = reinterpret_cast<float*>(base + L.b);
+    float* dwcat = reinterpret_cast<float*>(base + L.c);
+    float* dbcat = dwcat + d.RU * d.D;
+    if (d.n_src == 0 || d.n_dst == 0) return fail(SG_ERR_INVALID, "fused aggregation with edges but no rows");
+    if (want_b && !plan->rowsum) return fail(SG_ERR_INVALID, "the fused order needs plan->rowsum for the bias gradient");
+    if (dx) {
+      const sg_fused_plan& fp = plan->fused[1];
+      SG_TRY(sg_agg_fused_hip(dx, d.D, want_w ? dh : nullptr, d.RU, dpre, d.U, weights, d.D, 1, nullptr, nullptr, fp.f_ptr,
+                              fp.f_idx, fp.f_w, fp.tile_order, d.n_src, d.R, d.nnz, d.U, d.D, SG_ACT_NONE, 0.f, fused_nt(),
+                              scratch, L.scratch_bytes, stream));
+    } else if (want_w) {
+      SG_TRY(gather_view(plan, SG_VIEW_T_IDX_T, dh, d.R, d.RU, dpre, 1, d.U, plan->t_w, plan->t_idx, plan->t_indptr,
+                         d.n_src * d.R, d.nnz, d.U, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream, d.n_dst * d.outw * 4));
+    }
+    if (want_w) {
+      if (!x) return fail(SG_ERR_INVALID, "x is null");
+      SG_TRY(sg_gemm_f32_hip(dwcat, d.D, dh, d.RU, 1, x, d.D, 0, d.RU, d.D, d.n_src, nullptr, SG_ACT_NONE, 0.f, 0,
+                             scratch, L.scratch_bytes, stream));
+    }
+    if (want_b)
+      SG_TRY(sg_gemm_f32_hip(dbcat, d.U, plan->rowsum, d.R, 1, dpre, d.U, 0, d.R, d.U, d.n_dst, nullptr, SG_ACT_NONE, 0.f, 0,
+                             scratch, L.scratch_bytes, stream));
+    if (want_w || want_b) {
+      hipLaunchKernelGGL(unpack_cat_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, dw, db,
+                         want_w ? dwcat : static_cast<const float*>(nullptr),
+                         want_b ? dbcat : static_cast<const float*>(nullptr), d.R, static_cast<int>(d.U),
+                         static_cast<int>(d.D));
+      SG_TRY(check_launch("unpack_cat_kernel"));
+    }
+    return SG_OK;
+  }
 
   if (d.order == SG_ORDER_TRANSFORM_FIRST) {
     float* wcat = reinterpret_cast<float*>(base + L.wpack);

@@ -92,11 +92,11 @@ def multilink_aggregate(x, weights, biases, plan, accum="stack", act=None, slope
     """act( accum_r  A_r (x W_r^T + b_r) )  for the R levels of `plan`; weights[r] (U', D), biases[r] (U')."""
     if accum not in ("sum", "stack"):
         raise NotImplementedError(accum)
-    if order not in ("auto", "transform_first", "aggregate_first"):
-        raise L.StarGCNError("order must be 'auto', 'transform_first' or 'aggregate_first'")
+    if order not in ("auto", "transform_first", "aggregate_first", "fused"):
+        raise L.StarGCNError("order must be 'auto', 'transform_first', 'aggregate_first' or 'fused'")
     if len(weights) != plan.R or len(biases) != plan.R:
         raise L.StarGCNError("need one weight/bias per link level (%d)" % plan.R)
-    order = ops.multilink_resolve_order(plan, order)
+    order = ops.multilink_resolve_order(plan, order, x.shape[1], weights[0].shape[0], accum)
     return _MultiLinkAgg.apply(x, plan, accum, act, slope, order, *weights, *biases)
 
 

@@ -302,7 +302,8 @@ def masked_embed(table, ids, noise=None):
     return out
 
 
-_ORDER = {"auto": 0, "transform_first": 1, "aggregate_first": 2}
+_ORDER = {"auto": 0, "transform_first": 1, "aggregate_first": 2, "fused": 3}
+_ORDER_NAMES = ("auto", "transform_first", "aggregate_first", "fused")
 _ACCUM = {"sum": 0, "stack": 1}
 
 
@@ -312,10 +313,27 @@ def _ptr_array(tensors):
     return arr
 
 
-def multilink_resolve_order(plan, order):
-    rc = L.lib().sg_multilink_agg_resolve_order(_byref(plan.c_struct(False)), _ORDER[order])
-    L.check(min(rc, 0), "sg_multilink_agg_resolve_order")
-    return ("auto", "transform_first", "aggregate_first")[rc]
+def multilink_resolve_order(plan, order, in_dim=None, units_per_level=None, accum="sum"):
+    """The order the native entries run: with the widths given, the library's full rule (sg_multilink_agg_resolve_order2:
+    'auto' becomes 'fused' for 256-wide 'sum' aggregations over graphs whose R-expanded matrix would cost HBM time, and the
+    plan's fused edge orders are built here if so); without them the size rule of the two unfused orders."""
+    if in_dim is None:
+        rc = L.lib().sg_multilink_agg_resolve_order(_byref(plan.c_struct(False)), _ORDER[order])
+        L.check(min(rc, 0), "sg_multilink_agg_resolve_order")
+        return _ORDER_NAMES[rc]
+    rc = L.lib().sg_multilink_agg_resolve_order2(_byref(plan.c_struct(False)), _ORDER[order], int(in_dim), int(units_per_level),
+                                                 _ACCUM[accum])
+    L.check(min(rc, 0), "sg_multilink_agg_resolve_order2")
+    name = _ORDER_NAMES[rc]
+    if name == "fused" and not plan.ensure_fused():
+        if order == "fused":
+            raise L.StarGCNError("the plan's fused edge orders are not built and cannot be built during stream capture "
+                                 "(run one eager step first)")
+        import warnings
+        warnings.warn("MultiLinkPlan: fused edge orders cannot be built during stream capture; this graph replays the unfused "
+                      "order (run one eager step first)")
+        return multilink_resolve_order(plan, "auto")
+    return name
 
 
 def _gather_view(plan, order, accum, backward):
@@ -356,6 +374,8 @@ def multilink_agg_fwd(x, weights, biases, plan, accum, act, slope, order):
     D, upl = x.shape[1], weights[0].shape[0]
     o, a = _ORDER[order], _ACCUM[accum]
     _ensure_phases(plan, D, upl, o, a, 0)
+    if order == "fused" and not plan.ensure_fused():
+        raise L.StarGCNError("fused edge orders missing during stream capture")
     st = plan.c_struct(order != "transform_first")
     outw = upl * (plan.R if accum == "stack" else 1)
     out = torch.empty((plan.n_dst, outw), dtype=torch.float32, device=x.device)

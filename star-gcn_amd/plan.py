@@ -204,6 +204,9 @@ class MultiLinkPlan(object):
             st.rowsum = self.rowsum.data_ptr() if need_rowsum else None
             st.n_dst, st.n_src, st.nnz, st.num_links = self.n_dst, self.n_src, self.nnz, self.R
             st.struct_bytes = ctypes.sizeof(L.MultiLinkPlanStruct)
+            for which, fp in enumerate(getattr(self, "_fused", None) or ()):
+                e = st.fused[which]
+                e.f_ptr, e.f_idx, e.f_w, e.tile_order = (t.data_ptr() for t in fp)
             for view, ph in getattr(self, "_phases", {}).items():
                 if ph is None:
                     continue
@@ -263,6 +266,41 @@ class MultiLinkPlan(object):
         self._struct = None
         return True
 
+    def ensure_fused(self, rebuild=False):
+        """The two level-major edge orders the fused aggregate -> contract kernel walks (csrc/agg_fused.hip,
+        sg_agg_fused_plan_build_hip): [0] over (c_indptr, c_idx, c_w) for the forward, [1] over (t_indptr, t_idx, t_w) for
+        the data gradient; 8 bytes per edge each, resident with the plan.  The launch order of the 64-row tiles is by
+        descending edge count (the persistent workgroups take the heavy tiles first).  Returns False when they are missing and
+        cannot be built now (stream capture)."""
+        if getattr(self, "_fused", None) is not None and not rebuild:
+            return True
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        lib = L.lib()
+        old = getattr(self, "_fused", None)
+        built = []
+        for which, (ip, idx, w, rows) in enumerate(((self.c_indptr, self.c_idx, self.c_w, self.n_dst),
+                                                    (self.t_indptr, self.t_idx, self.t_w, self.n_src))):
+            dev = idx.device
+            tiles = int(lib.sg_agg_fused_tiles(rows))
+            if old is not None:
+                f_ptr, f_idx, f_w, order = old[which]
+            else:
+                R = self.R
+                per_row = (ip[R::R] - ip[:-1:R]).to(torch.int64) if rows > 0 else torch.zeros(0, dtype=torch.int64, device=dev)
+                work = torch.zeros(max(tiles, 1) * 64, dtype=torch.int64, device=dev)
+                work[:rows] = per_row
+                order = torch.argsort(work.view(-1, 64).sum(1), descending=True, stable=True).to(torch.int32)
+                f_ptr = torch.empty(max(tiles, 1) * R * 65, dtype=torch.int32, device=dev)
+                f_idx, f_w = torch.empty_like(idx), torch.empty_like(w)
+            L.check(lib.sg_agg_fused_plan_build_hip(L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), None, L.ptr(order), L.ptr(ip),
+                                                    L.ptr(idx), L.ptr(w), rows, self.R, self.nnz, L.stream_ptr()),
+                    "sg_agg_fused_plan_build_hip")
+            built.append((f_ptr, f_idx, f_w, order))
+        self._fused = tuple(built)
+        self._struct = None
+        return True
+
     def prepare_phases(self, in_dim, units_per_level, order="auto", accum="sum"):
         """Build, NOW, the phases the forward and the backward call of an aggregator with these widths will use -- at plan
         construction or warm-up instead of inside the first timed / captured step (the build reads two counters back)."""
@@ -277,6 +315,8 @@ class MultiLinkPlan(object):
         if self._rowsum is not None and self.nnz > 0:
             from . import ops
             ops.seg_sum(self.c_w.view(1, -1), self.c_indptr, out=self._rowsum.view(1, -1))
+        if getattr(self, "_fused", None) is not None:      # the fused kernel reads its own copy of the weights: same buffers, new values
+            self.ensure_fused(rebuild=True)
 
     @property
     def rowsum(self):

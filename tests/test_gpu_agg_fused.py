@@ -1,0 +1,186 @@
+"""GPU parity of the fused aggregate -> contract kernel (csrc/agg_fused.hip; order='fused' of the multi-link aggregator)
+against the float64 layer oracle in the reference's operation order (oracle/model.py; reference aggregators.py:111-163:
+R FullyConnected + R seg_weighted_pool + add_n + activation), through autograd (forward, data gradient, weight and bias
+gradients), through the raw C ABI, and -- at the MovieLens-10M size -- against the float64 definition on sampled rows and
+against the unfused orders.  fp32 tolerance 1e-5 of each tensor's scale (north star)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as OM
+from tests.test_abi_and_host import make_multilink
+from tests.test_gpu_dense_multilink import _rows_vs_definition, rel_close
+
+pytestmark = pytest.mark.gpu
+
+D = 256
+
+CASES = [  # n_dst, n_src, nnz, R
+    (60, 45, 900, 5),
+    (300, 40, 6000, 10),          # ragged last tile, few sources (every row re-read)
+    (64, 500, 4000, 3),           # exactly one tile
+    (65, 70, 50, 4),              # mostly empty (row, level) segments
+    (1000, 700, 90000, 16),
+    (130, 90, 3000, 1),           # one level
+]
+
+
+@pytest.mark.parametrize("n_dst,n_src,nnz,R", CASES)
+@pytest.mark.parametrize("act", ["leaky", None])
+def test_fused_order_matches_reference_order(n_dst, n_src, nnz, R, act):
+    from star_gcn_amd import functional as F
+    from star_gcn_amd.plan import MultiLinkPlan
+    rng = np.random.default_rng(n_dst + nnz + R)
+    eps, ips, sps = make_multilink(rng, n_dst, n_src, nnz, R)
+    g = torch.Generator().manual_seed(R + nnz)
+    x = torch.randn(n_src, D, generator=g) * 0.1 * torch.exp(torch.randn(n_src, 1, generator=g))    # rows of very different scale
+    ws = [torch.randn(D, D, generator=g) * (3.0 / D) ** 0.5 for _ in range(R)]
+    bs = [torch.randn(D, generator=g) * 0.1 for _ in range(R)]
+    gy = torch.randn(n_dst, D, generator=g)
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    br = [b.double().requires_grad_(True) for b in bs]
+    ref = OM.multilink_aggregator(xr, wr, br, eps, ips, sps, accum="sum", act=act)
+    ref.backward(gy.double())
+    plan = MultiLinkPlan(eps, ips, sps, n_src, "cuda")
+    xd = x.cuda().requires_grad_(True)
+    wd = [w.cuda().requires_grad_(True) for w in ws]
+    bd = [b.cuda().requires_grad_(True) for b in bs]
+    out = F.multilink_aggregate(xd, wd, bd, plan, accum="sum", act=act, slope=0.1, order="fused")
+    out.backward(gy.cuda())
+    rel_close(out, ref, 1e-5, "out")
+    rel_close(xd.grad, xr.grad, 1e-5, "dx")
+    for r in range(R):
+        rel_close(wd[r].grad, wr[r].grad, 2e-5, "dW%d" % r)
+        rel_close(bd[r].grad, br[r].grad, 2e-5, "db%d" % r)
+    # the data gradient alone (frozen parameters): the kernel variant that does not save the aggregates
+    xd2 = x.cuda().requires_grad_(True)
+    out2 = F.multilink_aggregate(xd2, [w.cuda() for w in ws], [b.cuda() for b in bs], plan, accum="sum", act=act, order="fused")
+    out2.backward(gy.cuda())
+    assert torch.equal(out2, out) and torch.equal(xd2.grad, xd.grad)          # deterministic, and the same with / without zsave
+
+
+def test_fused_order_is_refused_where_it_does_not_apply():
+    from star_gcn_amd import _lib as L
+    from star_gcn_amd import functional as F
+    from star_gcn_amd.plan import MultiLinkPlan
+    rng = np.random.default_rng(5)
+    eps, ips, sps = make_multilink(rng, 40, 30, 500, 3)
+    plan = MultiLinkPlan(eps, ips, sps, 30, "cuda")
+    x = torch.randn(30, 64, device="cuda")
+    ws = [torch.randn(64, 64, device="cuda") for _ in range(3)]
+    bs = [torch.zeros(64, device="cuda") for _ in range(3)]
+    with pytest.raises(L.StarGCNError):
+        F.multilink_aggregate(x, ws, bs, plan, accum="sum", order="fused")       # width 64
+    x = torch.randn(30, 256, device="cuda")
+    ws = [torch.randn(256, 256, device="cuda") for _ in range(3)]
+    bs = [torch.zeros(256, device="cuda") for _ in range(3)]
+    with pytest.raises(L.StarGCNError):
+        F.multilink_aggregate(x, ws, bs, plan, accum="stack", order="fused")     # concat accumulation
+    # 'auto' stays unfused on a small graph (the R-expanded matrix is cache-resident), and says so
+    from star_gcn_amd import ops
+    assert ops.multilink_resolve_order(plan, "auto", 256, 256, "sum") in ("transform_first", "aggregate_first")
+
+
+def test_fused_kernel_raw_c_abi_rows_of_other_pitch_and_saved_aggregates():
+    """sg_agg_fused_plan_build_hip + sg_agg_fused_hip called directly: strided x / out / zsave rows, a permuted launch order,
+    trans_w = 1 (the data-gradient form), no bias; compared with float64; then the weights are rewritten and the plan
+    refreshed through f_pos (sg_agg_fused_refresh_hip)."""
+    from star_gcn_amd import _lib as L
+    from star_gcn_amd import ops
+    lib = L.lib()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(11)
+    n_dst, n_src, nnz, R = 777, 300, 50000, 7
+    key, _ = torch.sort(torch.randint(0, n_dst * R, (nnz,), device=dev, generator=g))
+    indptr = torch.zeros(n_dst * R + 1, dtype=torch.int32, device=dev)
+    indptr[1:] = torch.cumsum(torch.bincount(key, minlength=n_dst * R), 0).to(torch.int32)
+    idx = torch.randint(0, n_src, (nnz,), device=dev, generator=g, dtype=torch.int32)
+    w = torch.rand(nnz, device=dev, generator=g) + 0.1
+    xbig = torch.randn(n_src, D + 32, device=dev, generator=g)
+    x = xbig[:, :D]
+    Ws = [torch.randn(D, D, device=dev, generator=g) / 16 for _ in range(R)]
+    tiles = int(lib.sg_agg_fused_tiles(n_dst))
+    assert tiles == (n_dst + 63) // 64 and lib.sg_agg_fused_supported(256, 256, R) == 1 and lib.sg_agg_fused_supported(128, 256, R) == 0
+    order = torch.randperm(tiles, device=dev, generator=g).to(torch.int32)
+    f_ptr = torch.empty(tiles * R * 65, dtype=torch.int32, device=dev)
+    f_idx, f_w, f_pos = torch.empty_like(idx), torch.empty_like(w), torch.empty_like(idx)
+    L.check(lib.sg_agg_fused_plan_build_hip(L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), L.ptr(f_pos), L.ptr(order), L.ptr(indptr),
+                                            L.ptr(idx), L.ptr(w), n_dst, R, nnz, L.stream_ptr()), "plan")
+    assert torch.equal(torch.sort(f_pos)[0], torch.arange(nnz, device=dev, dtype=torch.int32))      # a permutation of the edges
+    assert torch.equal(f_idx, idx[f_pos.long()]) and torch.equal(f_w, w[f_pos.long()])
+
+    def run(wts):
+        out = torch.full((n_dst, D + 64), 3.0, device=dev)
+        zs = torch.full((n_dst, R * D + 128), -7.0, device=dev)
+        ws, wsn = L.workspace(lib.sg_agg_fused_workspace_bytes(R), dev)
+        L.check(lib.sg_agg_fused_hip(L.ptr(out), out.shape[1], L.ptr(zs), zs.shape[1], L.ptr(x), xbig.shape[1], ops._ptr_array(Ws), D,
+                                     1, None, None, L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), L.ptr(order), n_dst, R, nnz, D, D, 0,
+                                     0.0, 0, L.ptr(ws), wsn, L.stream_ptr()), "fused")
+        seg = torch.repeat_interleave(torch.arange(n_dst * R, device=dev), (indptr[1:] - indptr[:-1]).long())
+        Z = torch.zeros(n_dst * R, D, dtype=torch.float64, device=dev)
+        Z.index_add_(0, seg, x.double()[idx.long()] * wts.double()[:, None])
+        Z = Z.view(n_dst, R, D)
+        ref = sum(Z[:, r] @ Ws[r].double() for r in range(R))
+        rel_close(out[:, :D], ref, 1e-5, "out")
+        rel_close(zs[:, :R * D], Z.view(n_dst, R * D), 1e-6, "saved aggregates")
+        assert bool((out[:, D:] == 3.0).all()) and bool((zs[:, R * D:] == -7.0).all())     # nothing outside the rows' 256 floats
+
+    run(w)
+    w2 = torch.rand(nnz, device=dev, generator=g) + 0.5
+    L.check(lib.sg_agg_fused_refresh_hip(L.ptr(f_w), L.ptr(f_pos), L.ptr(w2), nnz, L.stream_ptr()), "refresh")
+    run(w2)
+    # argument checks
+    ws, wsn = L.workspace(lib.sg_agg_fused_workspace_bytes(R), dev)
+    out = torch.empty(n_dst, D, device=dev)
+    rc = lib.sg_agg_fused_hip(L.ptr(out), D, None, 0, L.ptr(x), xbig.shape[1], ops._ptr_array(Ws), D, 0, None, None, L.ptr(f_ptr),
+                              L.ptr(f_idx), L.ptr(f_w), None, n_dst, R, nnz, 128, D, 0, 0.0, 0, L.ptr(ws), wsn, L.stream_ptr())
+    assert rc == -4 and b"256" in lib.sg_last_error()          # SG_ERR_UNSUPPORTED
+    rc = lib.sg_agg_fused_hip(L.ptr(out), D, None, 0, L.ptr(x), xbig.shape[1], ops._ptr_array(Ws), D, 0, None, None, L.ptr(f_ptr),
+                              L.ptr(f_idx), L.ptr(f_w), None, n_dst, R, nnz, D, D, 0, 0.0, 0, L.ptr(ws), ctypes.c_size_t(16),
+                              L.stream_ptr())
+    assert rc < 0 and b"workspace" in lib.sg_last_error()
+
+
+def test_fused_order_at_ml10m_size_against_the_definition_and_the_unfused_orders():
+    """BASELINE config 4 size (69878 x 10677, 10 M ratings, 10 levels, dim 256), both directions of the bipartite graph
+    (heavy item rows up to 35 k ratings): >= 64 sampled output rows and gradient rows against the float64 definition,
+    agreement with the transform-first order, the adjoint identity through autograd, and the weight / bias gradients
+    against the unfused order."""
+    import star_gcn_amd.synthetic as S
+    from star_gcn_amd import functional as F
+    from star_gcn_amd.plan import MultiLinkPlan
+    graph, eu, ei, vals = S.make_graph("ml-10m")
+    for dst, src in (("user", "movie"), ("movie", "user")):
+        m = graph[dst, src]
+        eps, _, ips, sps = m.sample_neighbors(symm=True, use_multi_link=True, num_neighbors=-1)
+        plan = MultiLinkPlan(eps, ips, sps, m.shape[1], "cuda")
+        R = plan.R
+        g = torch.Generator(device="cuda").manual_seed(3)
+        x1 = torch.randn(plan.n_src, D, device="cuda", generator=g) * 0.1
+        ws = [torch.randn(D, D, device="cuda", generator=g) * (3.0 / D) ** 0.5 for _ in range(R)]
+        bs = [torch.randn(D, device="cuda", generator=g) * 0.1 for _ in range(R)]
+        y = torch.randn(plan.n_dst, D, device="cuda", generator=g)
+        res = {}
+        for order in ("fused", "transform_first"):
+            xg = x1.clone().requires_grad_(True)
+            wg = [w.clone().requires_grad_(True) for w in ws]
+            bg = [b.clone().requires_grad_(True) for b in bs]
+            out = F.multilink_aggregate(xg, wg, bg, plan, accum="sum", act=None, order=order)
+            out.backward(y)
+            res[order] = (out.detach(), xg.grad, [w.grad for w in wg], [b.grad for b in bg])
+        out, dx, dws, dbs = res["fused"]
+        nd, ns, _w = _rows_vs_definition(plan, x1, ws, bs, out, y, dx, 64, 4, 1e-5)
+        assert nd >= 64 and ns >= 64
+        o2, dx2, dws2, dbs2 = res["transform_first"]
+        assert float((out - o2).abs().max()) <= 1e-5 * float(o2.abs().max())
+        assert float((dx - dx2).abs().max()) <= 1e-5 * float(dx2.abs().max())
+        for r in range(R):
+            assert float((dws[r] - dws2[r]).abs().max()) <= 2e-5 * max(float(dws2[r].abs().max()), 1e-3), r
+            assert float((dbs[r] - dbs2[r]).abs().max()) <= 2e-5 * max(float(dbs2[r].abs().max()), 1e-3), r
+        const = F.multilink_aggregate(torch.zeros_like(x1), ws, bs, plan, accum="sum", act=None, order="fused")
+        terms = (out - const).double() * y.double()
+        lhs, rhs = float(terms.sum()), float((dx.double() * x1.double()).sum())
+        assert abs(lhs - rhs) <= 1e-9 * float(terms.abs().sum()), (dst, lhs, rhs, float(terms.abs().sum()))
