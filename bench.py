@@ -263,6 +263,7 @@ def timed_steps(step, steps, warmup, dev, dist_on):
         dist.barrier()
     torch.cuda.synchronize()
     ops.gather_profile(True)      # HIP events around every gather launch, on the launch stream, inside the library
+    ops.fused_profile(True)       # ... and around every fused aggregate -> contract launch (csrc/agg_fused.hip)
     SD.STATS.reset()
     SD.STATS.enabled = dist_on
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]     # step boundaries on the compute stream
@@ -278,6 +279,8 @@ def timed_steps(step, steps, warmup, dev, dist_on):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.gather_profile(False)
+    ops.fused_profile(False)
+    timed_steps.last_fused = ops.fused_profile_read()
     SD.STATS.enabled = False
     per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(steps))
     timed_steps.last_median_ms = per_step[len(per_step) // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
@@ -372,6 +375,32 @@ def gather_roofline(timeline, E_local, D, steps):
             "_classes": {k: (n, tt / n, ne / n) for k, (n, tt, ne) in classes.items()}}
 
 
+def fused_roofline(records, E_local, D, steps, rows_saved_bytes):
+    """HIP-event times of the fused aggregate -> contract launches (csrc/agg_fused.hip) -> algorithmic rate.  One launch is
+    one whole aggregation (every edge visited once: idx + support + one fp32 row = 8 + 4 D bytes) AND its
+    per-level contraction; the launches of the backward also write the fp32 aggregates the weight gradient contracts with
+    (`rows_saved_bytes` per launch, counted separately -- `achieved` uses the per-edge figure only, as in earlier rounds)."""
+    recs = [(t, n, z) for t, n, z in records if t > 0 and n == E_local]
+    if not recs:
+        return None
+    total_t = sum(t for t, _, _ in recs)
+    b_edge = (8 + 4 * D) * E_local
+    out = {"kernel": "agg_contract_kernel (aggregation + per-level contraction in one launch)", "unit": "GB/s",
+           "achieved": b_edge * len(recs) / total_t / 1e9, "launches_per_step": len(recs) / steps,
+           "aggregations_per_step": len(recs) / steps, "avg_launch_ms": total_t / len(recs) * 1e3,
+           "avg_aggregation_ms": total_t / len(recs) * 1e3, "algorithmic_bytes_per_launch": b_edge,
+           "algorithmic_bytes_per_aggregation": b_edge, "per_class": []}
+    for z, name in ((0, "forward (writes only the 256-wide output)"), (1, "data gradient (also writes the fp32 aggregates)")):
+        c = [t for t, _, zz in recs if zz == z]
+        if c:
+            extra = rows_saved_bytes if z else 0
+            out["per_class"].append({"launch": name, "launches_per_step": len(c) / steps, "avg_launch_ms": sum(c) / len(c) * 1e3,
+                                     "achieved_gbs": b_edge * len(c) / sum(c) / 1e9,
+                                     "achieved_gbs_incl_saved_aggregates": (b_edge + extra) * len(c) / sum(c) / 1e9,
+                                     "saved_aggregate_bytes_per_launch": extra})
+    return out
+
+
 def measure_stream_ceiling(dev, n_bytes, workgroups, bursts=256, strided=False):
     """streaming read of a resident buffer of n_bytes with the gather's launch geometry (one wave per workgroup, 256 row
     reads of 1 KiB per wave, 4 in flight) -> GB/s, median of 5 launches after a warming one, HIP events on the current stream.
@@ -412,7 +441,7 @@ def _sha16(path):
         return None
 
 
-def profile_record(name):
+def profile_record(name, source_file="seg_gather.hip"):
     """PMC traffic of the gather (profiles/pmc_traffic.json, reduced from committed rocprofv3 --pmc passes).  The record
     carries the sha of the kernel source it was measured on; when csrc/seg_gather.hip has changed since, the counters
     describe another kernel and `traffic` is reported as null instead of going stale silently."""
@@ -423,10 +452,10 @@ def profile_record(name):
         return None
     if not rec:
         return None
-    now = _sha16(os.path.join(ROOT, "star-gcn_amd", "csrc", "seg_gather.hip"))
+    now = _sha16(os.path.join(ROOT, "star-gcn_amd", "csrc", source_file))
     if rec.get("kernel_source_sha16") != now:
-        return {"stale": True, "source": "%s measured on seg_gather.hip %s, current source is %s: traffic withheld" %
-                (rec.get("source", "profiles/pmc_traffic.json"), rec.get("kernel_source_sha16"), now)}
+        return {"stale": True, "source": "%s measured on %s %s, current source is %s: traffic withheld" %
+                (rec.get("source", "profiles/pmc_traffic.json"), source_file, rec.get("kernel_source_sha16"), now)}
     return rec
 
 
@@ -483,7 +512,19 @@ def hbm_leg(args, dev):
            "graph_gen_s": round(t_gen, 2), "plan_build_s": round(t_plan, 2),
            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
            "smallest_gathered_matrix_mb": src_small // 2 ** 20}
-    if roof:
+    froof = fused_roofline(getattr(timed_steps, "last_fused", []), E, D, args.hbm_steps, max(nu, ni) * R * D * 4)
+    if froof:       # the step ran the fused order (the default at this size): that kernel is the dominant one
+        rec = profile_record("hbm-config5-shard-fused:%d" % D, "agg_fused.hip")
+        live = rec and not rec.get("stale")
+        froof.update(bound="hbm", peak=HBM_PEAK / 1e9, frac=froof["achieved"] * 1e9 / HBM_PEAK,
+                     traffic=(rec["traffic_bytes_per_launch_mean"] * (E / rec["edges_per_launch"]) if live else None),
+                     traffic_source=(rec.get("source") if rec else None))
+        if roof:      # aggregations that still ran as gather + GEMM (none at the default routing)
+            roof.pop("_classes", None)
+            froof["unfused_gather_launches"] = roof
+        out["roofline"] = froof
+        out["step_roofline_frac"] = out["edges_per_s"] * 8 * (8 + 4 * D) / HBM_PEAK
+    elif roof:
         rec = profile_record("hbm-config5-shard:%d" % D)
         live = rec and not rec.get("stale")
         roof.update(bound="hbm", peak=HBM_PEAK / 1e9, frac=roof["achieved"] * 1e9 / HBM_PEAK,

@@ -131,7 +131,11 @@ int resolve_order2(const sg_multilink_plan* p, int order, int64_t in_dim, int64_
   if (accum == SG_ACCUM_SUM && p->nnz > 0 && p->n_dst > 0 && p->n_src > 0 && sg_agg_fused_supported(in_dim, upl, p->num_links)) {
     const int mode = fused_mode();
     const int64_t small_side = p->n_src < p->n_dst ? p->n_src : p->n_dst;
-    const bool big = p->nnz >= (1ll << 24) && small_side * p->num_links * in_dim * 4 > (256ll << 20);
+    // 64-row tiles over 256 persistent workgroups need a few thousand tiles on BOTH node sides to balance (the data gradient
+    // walks the other side), and the fusion only pays where the R-expanded matrix would travel through HBM.  Measured: the
+    // config-5 shard (1.25 M x 1 M, 125 M edges) 305 -> 272 ms per step; the MovieLens-10M shape (10 677 items = 167 tiles,
+    // cache-resident sources) 9.2 -> 23 ms -- the column-sliced gather lives on L2 hits the tile kernel cannot have
+    const bool big = p->nnz >= (1ll << 24) && small_side >= (1ll << 17) && small_side * p->num_links * in_dim * 4 > (256ll << 20);
     if (mode == 1 || (mode != 0 && big)) return SG_ORDER_FUSED;
   }
   return resolve_order(p, order);

@@ -28,6 +28,21 @@ def gather_profile_read(capacity=1 << 16, with_src_bytes=False):
     return [(ms[i] * 1e-3, int(nnz[i]), int(fd[i])) for i in range(n)]
 
 
+def fused_profile(enable):
+    """bench.py: HIP-event bracketing of the fused aggregate -> contract launches on/off (sg_agg_fused_profile_enable)."""
+    return L.lib().sg_agg_fused_profile_enable(int(bool(enable)))
+
+
+def fused_profile_read(capacity=1 << 14):
+    """-> list of (seconds, edges, 1 if the launch also wrote the aggregates) per fused launch since the profile was enabled."""
+    import ctypes
+    ms = (ctypes.c_float * capacity)()
+    nnz = (ctypes.c_int64 * capacity)()
+    zs = (ctypes.c_int32 * capacity)()
+    n = L.lib().sg_agg_fused_profile_read(ms, nnz, zs, capacity)
+    return [(ms[i] * 1e-3, int(nnz[i]), int(zs[i])) for i in range(n)]
+
+
 def gemm_profile(enable):
     """bench.py: HIP-event bracketing of every GEMM call on/off (sg_gemm_profile_enable)."""
     return L.lib().sg_gemm_profile_enable(int(bool(enable)))

@@ -137,7 +137,7 @@ def test_fused_kernel_raw_c_abi_rows_of_other_pitch_and_saved_aggregates():
     out = torch.empty(n_dst, D, device=dev)
     rc = lib.sg_agg_fused_hip(L.ptr(out), D, None, 0, L.ptr(x), xbig.shape[1], ops._ptr_array(Ws), D, 0, None, None, L.ptr(f_ptr),
                               L.ptr(f_idx), L.ptr(f_w), None, n_dst, R, nnz, 128, D, 0, 0.0, 0, L.ptr(ws), wsn, L.stream_ptr())
-    assert rc == -4 and b"256" in lib.sg_last_error()          # SG_ERR_UNSUPPORTED
+    assert rc == -2 and b"256" in lib.sg_last_error()          # SG_ERR_UNSUPPORTED
     rc = lib.sg_agg_fused_hip(L.ptr(out), D, None, 0, L.ptr(x), xbig.shape[1], ops._ptr_array(Ws), D, 0, None, None, L.ptr(f_ptr),
                               L.ptr(f_idx), L.ptr(f_w), None, n_dst, R, nnz, D, D, 0, 0.0, 0, L.ptr(ws), ctypes.c_size_t(16),
                               L.stream_ptr())
