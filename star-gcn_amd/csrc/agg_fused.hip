@@ -72,11 +72,33 @@ constexpr int KD = 256;                   // width of the gathered rows (contrac
 constexpr int ND = 256;                   // output width
 constexpr int KS = KD / 16;               // k steps per level
 constexpr int NJB = ND / 32;              // 32-column blocks of the output
-constexpr int NB = 16;                    // rows in flight per G wave
+#ifndef SG_FUSED_GW
+#define SG_FUSED_GW 8
+#endif
+#ifndef SG_FUSED_NB
+#define SG_FUSED_NB 16
+#endif
+#ifndef SG_FUSED_BRING
+#define SG_FUSED_BRING 3
+#endif
+#ifndef SG_FUSED_MW
+#define SG_FUSED_MW 8
+#endif
+#ifndef SG_FUSED_PREFETCH
+#define SG_FUSED_PREFETCH 0               // 1: B_r's planes pulled into L2 by LDS-DMA loads behind the level barrier (prefetch_b): measured SLOWER
+#endif
+#ifndef SG_FUSED_ADB
+#define SG_FUSED_ADB 0                    // 1: the aggregate's fragments double-buffered in registers (fits only with 4 + 4 waves)
+#endif
+constexpr int GW = SG_FUSED_GW;           // gather waves per workgroup (4 or 8); the matrix waves follow them
+constexpr int MW = SG_FUSED_MW;           // matrix waves (4: 64 output columns each, 8: 32)
+constexpr int NJ = 8 / MW;                // 32-column blocks per matrix wave
+constexpr int NB = SG_FUSED_NB;           // rows in flight per G wave
+constexpr int BRING = SG_FUSED_BRING;     // B fragment sets in flight per M wave (k steps of one 32-column block)
 constexpr int ZROW = KD * 2 + 16;         // bytes per row and plane in LDS: 528 = 132 words -> rows 4 banks apart
 constexpr int ZPLANE = TM * ZROW;
 constexpr int ZBUF = 2 * ZPLANE;          // value plane, residual plane
-constexpr int SMEM = 2 * ZBUF + 2 * TM * 4 + 2 * TM * SG_MAX_LINKS * 4;
+constexpr int SMEM = 2 * ZBUF + 2 * TM * 4 + 2 * TM * SG_MAX_LINKS * 4 + 1024;     // (+ 1 KiB nobody reads: see prefetch_b)
 
 struct Args {
   const int32_t* f_ptr;
@@ -96,6 +118,8 @@ struct Args {
   int n_dst, n_tiles, R;
   int act;
   float slope;
+  int lp;                      // levels per phase (see the kernel): 1 .. R
+  int ablate;                  // timing experiments only (SG_FUSED_ABLATE): 1 = no matrix work / B loads, 2 = every row load reads row 0
 };
 
 __device__ __forceinline__ unsigned wave_or(unsigned v) {
@@ -129,13 +153,29 @@ struct Ctx {                    // one (item = tile x level, G wave): the rows a
 };
 
 template <bool ZSAVE, bool NT>
-__global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
+__global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   float* sinv = reinterpret_cast<float*>(smem + 2 * ZBUF);       // [buffer][row] 2^-e of the row's planes
   const int t = threadIdx.x, lane = t & 63, wave = rfl(t >> 6);
   const int G = gridDim.x, b = blockIdx.x;
-  const int n_my = (a.n_tiles - b + G - 1) / G;                  // tiles b, b + G, ... (through tile_order when given)
+  // launch slots of this workgroup: stratum ti (G consecutive slots) in boustrophedon order -- b, 2G-1-b, 2G+b, ... -- so that
+  // with slots sorted by descending work no workgroup collects the heaviest tile of every stratum
+  auto slot_of = [&](int ti) __attribute__((always_inline)) { return ti * G + ((ti & 1) ? G - 1 - b : b); };
+  const int n_full = a.n_tiles / G;
+  const int n_my = n_full + ((a.n_tiles - n_full * G > 0 && slot_of(n_full) < a.n_tiles) ? 1 : 0);
   const int n_items = n_my * a.R;
+  if (n_my == 0) return;
+  // PHASES.  B_r's planes (256 KB per level, 4 MB for 16 levels) do not survive in a 4 MB L2 that the gathered rows stream
+  // through: with the levels of a tile processed back to back every (tile, level) re-fetched its planes through the fabric --
+  // 65 GB per launch at the config-5 shard next to 129 GB of rows (PMC: FETCH 174 GB, L2 hit rate 0.17), and the kernel ran at
+  // the fabric's rate for the SUM.  So the workgroup walks its tiles once per PHASE of `lp` levels: at any time every CU of
+  // the chip multiplies by the same lp levels' planes, which then live in the L2s.  The price: a tile's partial result is
+  // written at the end of a phase and read back in the next one ((phases - 1) x 2 x n x 1 KiB).  Same workgroup, fixed order:
+  // deterministic.
+  const int n_full_ph = a.R / a.lp;
+  const int per_phase = n_my * a.lp;
+  const int full_items = n_full_ph * per_phase;
+  const int n_phases = (a.R + a.lp - 1) / a.lp;
   // slot = position in the launch order (tile_order[slot] = tile, or slot itself): the plan's pointers are slot-major, the
   // tile id is only needed for output rows and comes through the scalar cache
   auto tile_of = [&](int slot) __attribute__((always_inline)) -> int {
@@ -143,14 +183,22 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
     return *((f16x3::cst_int*)(a.tile_order) + slot);
   };
 
-  if (wave < 4) {
+  if (wave < GW) {
     // ================================================= G: gather =====================================================
     const int gw = wave;
     auto load_ptrs = [&](int it, int& slot, int& r, int& pv, int& pn) __attribute__((always_inline)) {
       const int itc = min(it, n_items - 1);
-      const int ti = itc / a.R;
-      r = itc - ti * a.R;
-      slot = b + ti * G;
+      int ti;
+      if (itc < full_items) {                            // phase p: levels [p lp, (p + 1) lp) of every tile of this workgroup
+        const int p = itc / per_phase, rem = itc - p * per_phase;
+        ti = rem / a.lp;
+        r = p * a.lp + (rem - ti * a.lp);
+      } else {                                           // the last, shorter phase (R not a multiple of lp)
+        const int lr = a.R - n_full_ph * a.lp, rem = itc - full_items;
+        ti = rem / lr;
+        r = n_full_ph * a.lp + (rem - ti * lr);
+      }
+      slot = slot_of(ti);
       const long long base = (static_cast<long long>(slot) * a.R + r) * (TM + 1);
       pv = a.f_ptr[base + lane];
       pn = a.f_ptr[base + lane + 1];
@@ -163,8 +211,11 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
       c.tile = slot; c.r = r; c.it = it;
       const int p0 = __builtin_amdgcn_readlane(pv, 0), pE = __builtin_amdgcn_readlane(pn, 63);
       const long long total = pE - p0;
-      const int t1 = p0 + static_cast<int>(total / 4), t2 = p0 + static_cast<int>(total / 2), t3 = p0 + static_cast<int>(total * 3 / 4);
-      const int wj = (total > 0) ? (pv >= t1) + (pv >= t2) + (pv >= t3) : 0;
+      int wj = 0;                                        // the wave whose share of the level's edges holds the row's first edge
+      if (total > 0) {
+#pragma unroll
+        for (int q = 1; q < GW; ++q) wj += (pv >= p0 + static_cast<int>(total * q / GW)) ? 1 : 0;
+      }
       const unsigned long long mine = __ballot(wj == gw);
       const unsigned long long nonempty = __ballot(pn > pv);
       c.rows = mine & nonempty;
@@ -198,6 +249,8 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
 
     const char* xb = reinterpret_cast<const char*>(a.x);
     auto load_row = [&](f32x4& dst, int idx) __attribute__((always_inline)) {
+      if (a.ablate & 2) idx = 0;        // (timing experiment: every load hits the same row -- no control flow around the load,
+                                        //  the compiler must keep counting the outstanding loads)
       const f32x4* p = reinterpret_cast<const f32x4*>(xb + static_cast<long long>(idx) * a.ldx * 4) + lane;
       if (NT) dst = __builtin_nontemporal_load(p);
       else dst = *p;
@@ -280,7 +333,7 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
     int mI_idx, mM_idx;
     float mI_w, mM_w;
     f32x4 x[NB];
-    float w_cur[NB], w_nxt[NB];
+    float wv_cur, wv_nxt;                                // lane k: weight of edge k of the group (0 past the end of the item)
     unsigned end_cur, end_nxt;
 
     // fill: group 0 -> meta; group 1 -> meta, group 0 -> rows
@@ -291,13 +344,9 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
     load_meta(cM, giM, mM_idx, mM_w);
     {
       const int gb = cI.e_lo + giI * NB;
+      wv_cur = (gb + lane < cI.e_hi) ? mI_w : 0.f;
 #pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        const int idx = __builtin_amdgcn_readlane(mI_idx, k);
-        const float wv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mI_w), k));
-        w_cur[k] = (gb + k < cI.e_hi) ? wv : 0.f;
-        load_row(x[k], idx);
-      }
+      for (int k = 0; k < NB; ++k) load_row(x[k], __builtin_amdgcn_readlane(mI_idx, k));
       end_cur = end_mask(cI, giI);
     }
     Ctx cC = cI;
@@ -323,11 +372,13 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
         rem = cC.rows;
       }
       const int gbI = cI.e_lo + giI * NB;
+      wv_nxt = (gbI + lane < cI.e_hi) ? mI_w : 0.f;
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         // C: edge k of group giC
+        const float wk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv_cur), k));
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = __builtin_fmaf(w_cur[k], x[k][v], acc[v]);
+        for (int v = 0; v < 4; ++v) acc[v] = __builtin_fmaf(wk, x[k][v], acc[v]);
         if ((end_cur >> k) & 1u) {
           const int j = __ffsll(static_cast<long long>(rem)) - 1;
           rem &= rem - 1ull;
@@ -335,10 +386,7 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
           acc = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // I: edge k of group giI into the registers just released
-        const int idx = __builtin_amdgcn_readlane(mI_idx, k);
-        const float wv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mI_w), k));
-        w_nxt[k] = (gbI + k < cI.e_hi) ? wv : 0.f;
-        load_row(x[k], idx);
+        load_row(x[k], __builtin_amdgcn_readlane(mI_idx, k));
       }
       end_nxt = end_mask(cI, giI);
       // the consume item ends with this group: publish it
@@ -354,8 +402,7 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
       // shift the stages
       cC = cI; giC = giI;
       cI = cM; giI = giM;
-#pragma unroll
-      for (int k = 0; k < NB; ++k) w_cur[k] = w_nxt[k];
+      wv_cur = wv_nxt;
       end_cur = end_nxt;
       mI_idx = mM_idx; mI_w = mM_w;
       advance_m();
@@ -365,14 +412,14 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
   }
 
   // =================================================== M: matrix ======================================================
-  const int wn = wave - 4;                                 // output columns [64 wn, 64 wn + 64)
+  const int wn = wave - GW;                                // output columns [32 NJ wn, 32 NJ (wn + 1))
   const int l31 = lane & 31, kh = lane >> 5;
   float* rs_lds = reinterpret_cast<float*>(smem + 2 * ZBUF + 2 * TM * 4);      // [tile parity][row][r] support row sums
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
@@ -380,7 +427,7 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
   auto load_b = [&](f16x8 (&bf)[2], int r, int j, int ks) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 2; ++p)
-      bf[p] = *reinterpret_cast<const f16x8*>(bw + ((((static_cast<long long>(r) * NJB + wn * 2 + j) * KS + ks) * 2 + p) << 10));
+      bf[p] = *reinterpret_cast<const f16x8*>(bw + ((((static_cast<long long>(r) * NJB + wn * NJ + j) * KS + ks) * 2 + p) << 10));
   };
   auto read_a = [&](f16x8 (&af)[2][2], int buf, int ks) __attribute__((always_inline)) {
 #pragma unroll
@@ -390,55 +437,83 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
         af[i][p] = *reinterpret_cast<const f16x8*>(smem + buf * ZBUF + p * ZPLANE + (32 * i + l31) * ZROW + (ks * 2 + kh) * 16);
   };
   const bool has_bias = a.bias && a.rowsum;
+  // B_r's planes mostly MISS the L2 (4 MB of planes against a 4 MB L2 that the gathered rows stream through: hit rate 0.17,
+  // PMC) and come from the Infinity Cache at ~3 us; with two or three fragment sets in flight per wave the matrix waves then
+  // need as long per level as the gather (measured: matrix work alone 18 ms per launch = the gather alone).  So right behind
+  // the barrier a wave first requests ALL of its units of the level as LDS-DMA loads into a scratch KiB nobody reads -- 32
+  // in flight without a register -- and the fragment loads that follow hit the L2 (the lines are used within microseconds).
+  const unsigned scratch_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>((f16x3::lds_void*)(smem + SMEM - 1024)));
+  auto prefetch_b = [&](int r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NJ * KS * 2; ++u) {
+      const char* src = bw + ((((static_cast<long long>(r) * NJB + wn * NJ) * KS) * 2 + u) << 10);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(scratch_lds) : "memory", "m0");
+#pragma clang diagnostic pop
+    }
+  };
 
   int it = 0;
+  for (int ph = 0; ph < n_phases; ++ph) {
+  const int lv0 = ph * a.lp, nl = min(a.lp, a.R - lv0);
+  const bool first_ph = ph == 0, last_ph = ph == n_phases - 1;
   for (int ti = 0; ti < n_my; ++ti) {
-    const int tile = tile_of(b + ti * G);
+    const int tile = tile_of(slot_of(ti));
     const long long row0 = static_cast<long long>(tile) * TM;
-    if (has_bias) {       // this tile's support row sums -> LDS (each M wave a quarter; the level barriers publish them)
+    if (has_bias && last_ph) {       // this tile's support row sums -> LDS (each M wave a share; the level barriers publish them)
       float* dst = rs_lds + (ti & 1) * TM * a.R;
       const int cnt = TM * a.R;
-      for (int e = wn * 64 + lane; e < cnt; e += 256) {
+      for (int e = wn * 64 + lane; e < cnt; e += 64 * MW) {
         const long long row = row0 + e / a.R;
         dst[e] = row < a.n_dst ? a.rowsum[row0 * a.R + e] : 0.f;
       }
     }
-    for (int r = 0; r < a.R; ++r, ++it) {
-      f16x8 bF[3][2];
-      load_b(bF[0], r, 0, 0);                               // B does not depend on the gather: requested ahead of the barrier
-      load_b(bF[1], r, 0, 1);
+    for (int r = lv0; r < lv0 + nl; ++r, ++it) {
+      f16x8 bF[BRING][2];
+#pragma unroll
+      for (int p = 0; p < BRING - 1; ++p) load_b(bF[p], r, p / KS, p % KS);      // B does not depend on the gather: requested ahead of the barrier
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                         // item `it` is published
       asm volatile("" ::: "memory");
       const int buf = it & 1;
-      float sa[2][16];
+      if (__builtin_expect(a.ablate & 1, 0)) continue;
+#if SG_FUSED_PREFETCH
+      if (!(a.ablate & 4)) prefetch_b(r);
+#endif
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinv + buf * TM + 32 * i + 8 * g4 + 4 * kh);
-#pragma unroll
-          for (int v = 0; v < 4; ++v) sa[i][4 * g4 + v] = s4[v];
-        }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         f32x16 P[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int q = 0; q < 16; ++q) P[i][q] = 0.f;
+#if SG_FUSED_ADB
         f16x8 aF[2][2][2];
         read_a(aF[0], buf, 0);
+#else
+        f16x8 aF[1][2][2];         // one set: with two matrix waves per SIMD the other wave covers the LDS latency
+#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          // B fragments two k steps ahead (straight into the other column half at the end of this one)
-          const int s2 = j * KS + ks + 2;
-          if (s2 < 2 * KS) load_b(bF[s2 % 3], r, s2 / KS, s2 % KS);
+          // B fragments BRING - 1 k steps ahead (straight into the next column block at the end of this one)
+          const int s2 = j * KS + ks + BRING - 1;
+          if (s2 < NJ * KS && !(a.ablate & 16)) load_b(bF[s2 % BRING], r, s2 / KS, s2 % KS);
+#if SG_FUSED_ADB
           if (ks + 1 < KS) read_a(aF[(ks + 1) & 1], buf, ks + 1);
-          asm volatile("" ::: "memory");                      // the requests stay HERE: two (B) / one (A) k steps ahead of their use
+#else
+          if (!(a.ablate & 32)) read_a(aF[0], buf, ks);
+#endif
+          asm volatile("" ::: "memory");                      // the requests stay HERE: ahead of their use
           __builtin_amdgcn_sched_barrier(0);
-          const f16x8 (&af)[2][2] = aF[ks & 1];
-          const f16x8 (&bf)[2] = bF[(j * KS + ks) % 3];
+          const f16x8 (&af)[2][2] = aF[SG_FUSED_ADB ? (ks & 1) : 0];
+          const f16x8 (&bf)[2] = bF[(j * KS + ks) % BRING];
+          if (a.ablate & 8) {        // (timing: no matrix instructions; the operands are still consumed)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { P[i][0] += static_cast<float>(af[i][0][0] + af[i][1][0]) + static_cast<float>(bf[0][0] + bf[1][0]); }
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+          }
 #pragma unroll
           for (int i = 0; i < 2; ++i) P[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[0], P[i], 0, 0, 0);
 #pragma unroll
@@ -448,27 +523,43 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
           __builtin_amdgcn_sched_barrier(0);
         }
         // fold: acc += P * 2^-e_row * 2^-e_B
-        const float sb = a.wscale[r * NJB + wn * 2 + j];
+        const float sb = a.wscale[r * NJB + wn * NJ + j];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) acc[i][j][q] = __builtin_fmaf(P[i][q] * sa[i][q], sb, acc[i][j][q]);
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinv + buf * TM + 32 * i + 8 * g4 + 4 * kh);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[i][j][4 * g4 + v] = __builtin_fmaf(P[i][4 * g4 + v] * s4[v], sb, acc[i][j][4 * g4 + v]);
+          }
       }
     }
-    // ---- the tile's result: bias term, activation, store ----
-    if (has_bias) {
+    // ---- the tile's result: (+ the partial sums of the earlier phases) (+ bias term, activation in the last phase), store ----
+    if (!first_ph) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const long long row = row0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * kh;
+          if (row < a.n_dst) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j][q] += a.out[row * a.ldo + (wn * NJ + j) * 32 + l31];
+          }
+        }
+    }
+    if (has_bias && last_ph) {
       const float* rs = rs_lds + (ti & 1) * TM * a.R + (4 * kh) * a.R;
       for (int r = 0; r < a.R; ++r) {
-        float bv[2];
+        float bv[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bv[j] = a.bias[r * ND + wn * 64 + 32 * j + l31];
+        for (int j = 0; j < NJ; ++j) bv[j] = a.bias[r * ND + (wn * NJ + j) * 32 + l31];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             const float s = rs[(32 * i + (q & 3) + 8 * (q >> 2)) * a.R + r];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j][q] = __builtin_fmaf(s, bv[j], acc[i][j][q]);
+            for (int j = 0; j < NJ; ++j) acc[i][j][q] = __builtin_fmaf(s, bv[j], acc[i][j][q]);
           }
       }
     }
@@ -481,20 +572,21 @@ __global__ __launch_bounds__(512, 1) void agg_contract_kernel(const Args a) {
           const long long row = row0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * kh;
           if (row < a.n_dst) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              a.out[row * a.ldo + wn * 64 + 32 * j + l31] = f16x3::act_fn(acc[i][j][q], ACT, a.slope);
+            for (int j = 0; j < NJ; ++j)
+              a.out[row * a.ldo + (wn * NJ + j) * 32 + l31] = f16x3::act_fn(acc[i][j][q], ACT, a.slope);
           }
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j][q] = 0.f;
+          for (int j = 0; j < NJ; ++j) acc[i][j][q] = 0.f;
         }
     };
-    switch (a.act) {
+    switch (last_ph ? a.act : SG_ACT_NONE) {
       case SG_ACT_LEAKY: store_tile(std::integral_constant<int, SG_ACT_LEAKY>{}); break;
       case SG_ACT_RELU: store_tile(std::integral_constant<int, SG_ACT_RELU>{}); break;
       case SG_ACT_SIGMOID: store_tile(std::integral_constant<int, SG_ACT_SIGMOID>{}); break;
       case SG_ACT_TANH: store_tile(std::integral_constant<int, SG_ACT_TANH>{}); break;
       default: store_tile(std::integral_constant<int, SG_ACT_NONE>{}); break;
     }
+  }
   }
 }
 
@@ -719,6 +811,14 @@ SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, 
   a.out = out; a.ldo = ldo; a.zsave = zsave; a.ldz = ldz;
   a.n_dst = static_cast<int>(n_dst); a.n_tiles = static_cast<int>(sg_agg_fused_tiles(n_dst)); a.R = num_links;
   a.act = act; a.slope = slope;
+  static const int ablate = [] { const char* e = getenv("SG_FUSED_ABLATE"); return e ? atoi(e) : 0; }();
+  a.ablate = ablate;
+  // levels per phase: SG_FUSED_LP (tuning), default 8 -- 2 MB of planes per phase.  Config-5 shard, fused forward, ms into
+  // users / items: one phase 23.5 / 24.9, lp 8 22.0 / 24.8, lp 4 22.7 / 25.7, lp 2 26.7 / 28.7, lp 1 37.3 / 35.4
+  // (fabric reads per launch 174 / 158 / 146 GB for one phase / lp 8 / lp 4 against 133 GB without the matrix work)
+  static const int lp_env = [] { const char* e = getenv("SG_FUSED_LP"); return e ? atoi(e) : 0; }();
+  a.lp = lp_env > 0 ? lp_env : 8;
+  if (a.lp > num_links) a.lp = num_links;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
@@ -726,7 +826,7 @@ SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, 
   const unsigned grid = static_cast<unsigned>(a.n_tiles < cus ? a.n_tiles : cus);
   auto launch = [&](auto kern) {
     static_cast<void>(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, fused::SMEM));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), fused::SMEM, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (fused::GW + fused::MW)), fused::SMEM, st, a);
   };
   const long rec = fused::prof_begin(st, nnz, zsave ? 1 : 0);
   if (zsave) { if (nt_loads) launch(fused::agg_contract_kernel<true, true>); else launch(fused::agg_contract_kernel<true, false>); }

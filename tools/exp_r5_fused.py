@@ -176,9 +176,32 @@ def time_case(n_dst, n_src, nnz, R, skew=False):
     print("unfused: gather %.3f ms (%.2f TB/s) + contraction %.3f ms = %.3f ms" % (t_g, gb / t_g, t_m, t_g + t_m), flush=True)
 
 
+def bench_graph(nu=1_250_000, ni=1_000_000, ne=125_000_000, R=16):
+    """the config-5 shard of bench.py (log-normal propensities, MovieLens-like level skew): fused forward of either direction"""
+    from star_gcn_amd import functional as F
+    from star_gcn_amd.device_graph import synthetic_device_graph
+    dev = torch.device("cuda")
+    dg = synthetic_device_graph(nu, ni, ne, R, dev, seed=5)
+    gb = dg.nnz * (8 + 4 * D) / 1e9
+    for dst in (dg.U, dg.I):
+        plan = dg.plan(dst)
+        lv = (plan.c_indptr[1:] - plan.c_indptr[:-1]).view(plan.n_dst, R).sum(0).float()
+        x = torch.randn(plan.n_src, D, device=dev)
+        Ws = [torch.randn(D, D, device=dev) / 16 for _ in range(R)]
+        bs = [torch.randn(D, device=dev) for _ in range(R)]
+        t = timeit(lambda: F.multilink_aggregate(x, Ws, bs, plan, accum="sum", act="leaky", order="fused"))
+        work = (plan.c_indptr[R::R] - plan.c_indptr[:-1:R])
+        tw = torch.cat([work, work.new_zeros((-plan.n_dst) % 64)]).view(-1, 64).sum(1)
+        print("ablate %s  into %-5s: %.3f ms = %.2f TB/s; level shares %s; tile work max %d mean %.0f" % (
+            os.environ.get("SG_FUSED_ABLATE", "0"), dst, t, gb / t, " ".join("%.3f" % v for v in (lv / lv.sum()).tolist()),
+            int(tw.max()), float(tw.float().mean())), flush=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "check":
         check()
+    elif sys.argv[1] == "bench-graph":
+        bench_graph()
     else:
         a = [int(v) for v in sys.argv[2:6]] if len(sys.argv) >= 6 else [1_000_000, 1_250_000, 125_000_000, 16]
         time_case(*a)
