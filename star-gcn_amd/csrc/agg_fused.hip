@@ -84,9 +84,6 @@ constexpr int NJB = ND / 32;              // 32-column blocks of the output
 #ifndef SG_FUSED_MW
 #define SG_FUSED_MW 8
 #endif
-#ifndef SG_FUSED_PREFETCH
-#define SG_FUSED_PREFETCH 0               // 1: B_r's planes pulled into L2 by LDS-DMA loads behind the level barrier (prefetch_b): measured SLOWER
-#endif
 #ifndef SG_FUSED_ADB
 #define SG_FUSED_ADB 0                    // 1: the aggregate's fragments double-buffered in registers (fits only with 4 + 4 waves)
 #endif
@@ -98,7 +95,7 @@ constexpr int BRING = SG_FUSED_BRING;     // B fragment sets in flight per M wav
 constexpr int ZROW = KD * 2 + 16;         // bytes per row and plane in LDS: 528 = 132 words -> rows 4 banks apart
 constexpr int ZPLANE = TM * ZROW;
 constexpr int ZBUF = 2 * ZPLANE;          // value plane, residual plane
-constexpr int SMEM = 2 * ZBUF + 2 * TM * 4 + 2 * TM * SG_MAX_LINKS * 4 + 1024;     // (+ 1 KiB nobody reads: see prefetch_b)
+constexpr int SMEM = 2 * ZBUF + 2 * TM * 4 + 2 * TM * SG_MAX_LINKS * 4;
 
 struct Args {
   const int32_t* f_ptr;
@@ -118,8 +115,7 @@ struct Args {
   int n_dst, n_tiles, R;
   int act;
   float slope;
-  int lp;                      // levels per phase (see the kernel): 1 .. R
-  int ablate;                  // timing experiments only (SG_FUSED_ABLATE): 1 = no matrix work / B loads, 2 = every row load reads row 0
+  int ablate;                  // timing experiments only (SG_FUSED_ABLATE): 1 = no matrix work, 2 = every row load reads row 0
 };
 
 __device__ __forceinline__ unsigned wave_or(unsigned v) {
@@ -165,19 +161,9 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
   const int n_my = n_full + ((a.n_tiles - n_full * G > 0 && slot_of(n_full) < a.n_tiles) ? 1 : 0);
   const int n_items = n_my * a.R;
   if (n_my == 0) return;
-  // PHASES.  B_r's planes (256 KB per level, 4 MB for 16 levels) do not survive in a 4 MB L2 that the gathered rows stream
-  // through: with the levels of a tile processed back to back every (tile, level) re-fetched its planes through the fabric --
-  // 65 GB per launch at the config-5 shard next to 129 GB of rows (PMC: FETCH 174 GB, L2 hit rate 0.17), and the kernel ran at
-  // the fabric's rate for the SUM.  So the workgroup walks its tiles once per PHASE of `lp` levels: at any time every CU of
-  // the chip multiplies by the same lp levels' planes, which then live in the L2s.  The price: a tile's partial result is
-  // written at the end of a phase and read back in the next one ((phases - 1) x 2 x n x 1 KiB).  Same workgroup, fixed order:
-  // deterministic.
-  const int n_full_ph = a.R / a.lp;
-  const int per_phase = n_my * a.lp;
-  const int full_items = n_full_ph * per_phase;
-  const int n_phases = (a.R + a.lp - 1) / a.lp;
-  // slot = position in the launch order (tile_order[slot] = tile, or slot itself): the plan's pointers are slot-major, the
-  // tile id is only needed for output rows and comes through the scalar cache
+  // (Measured and removed, profiles/r5_fused_kernel.md: walking the tiles once per PHASE of a few levels so that the phase's
+  // B planes stay in the L2s -- the fabric reads fall from 174 to 146-158 GB per launch, the launch does not get faster, and
+  // the partial results written and re-read between phases make the whole step slower; LDS-DMA prefetch of the planes: slower.)
   auto tile_of = [&](int slot) __attribute__((always_inline)) -> int {
     if (!a.tile_order) return slot;
     return *((f16x3::cst_int*)(a.tile_order) + slot);
@@ -188,16 +174,8 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
     const int gw = wave;
     auto load_ptrs = [&](int it, int& slot, int& r, int& pv, int& pn) __attribute__((always_inline)) {
       const int itc = min(it, n_items - 1);
-      int ti;
-      if (itc < full_items) {                            // phase p: levels [p lp, (p + 1) lp) of every tile of this workgroup
-        const int p = itc / per_phase, rem = itc - p * per_phase;
-        ti = rem / a.lp;
-        r = p * a.lp + (rem - ti * a.lp);
-      } else {                                           // the last, shorter phase (R not a multiple of lp)
-        const int lr = a.R - n_full_ph * a.lp, rem = itc - full_items;
-        ti = rem / lr;
-        r = n_full_ph * a.lp + (rem - ti * lr);
-      }
+      const int ti = itc / a.R;
+      r = itc - ti * a.R;
       slot = slot_of(ti);
       const long long base = (static_cast<long long>(slot) * a.R + r) * (TM + 1);
       pv = a.f_ptr[base + lane];
@@ -373,21 +351,27 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       }
       const int gbI = cI.e_lo + giI * NB;
       wv_nxt = (gbI + lane < cI.e_hi) ? mI_w : 0.f;
+      // a row's edges are summed group by group (NB edges in `part`, then `part` into the row's sum): the rounding error of a
+      // 50 000-edge row grows with sqrt(edges / NB) instead of sqrt(edges) (the chunked gather of seg_gather.hip does the same)
+      f32x4 part = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         // C: edge k of group giC
         const float wk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv_cur), k));
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = __builtin_fmaf(wk, x[k][v], acc[v]);
+        for (int v = 0; v < 4; ++v) part[v] = __builtin_fmaf(wk, x[k][v], part[v]);
         if ((end_cur >> k) & 1u) {
           const int j = __ffsll(static_cast<long long>(rem)) - 1;
           rem &= rem - 1ull;
+          acc += part;
           emit(cC, j, acc);
           acc = f32x4{0.f, 0.f, 0.f, 0.f};
+          part = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // I: edge k of group giI into the registers just released
         load_row(x[k], __builtin_amdgcn_readlane(mI_idx, k));
       }
+      acc += part;
       end_nxt = end_mask(cI, giI);
       // the consume item ends with this group: publish it
       const bool item_done = (giC + 1 == cC.ng);
@@ -437,31 +421,11 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
         af[i][p] = *reinterpret_cast<const f16x8*>(smem + buf * ZBUF + p * ZPLANE + (32 * i + l31) * ZROW + (ks * 2 + kh) * 16);
   };
   const bool has_bias = a.bias && a.rowsum;
-  // B_r's planes mostly MISS the L2 (4 MB of planes against a 4 MB L2 that the gathered rows stream through: hit rate 0.17,
-  // PMC) and come from the Infinity Cache at ~3 us; with two or three fragment sets in flight per wave the matrix waves then
-  // need as long per level as the gather (measured: matrix work alone 18 ms per launch = the gather alone).  So right behind
-  // the barrier a wave first requests ALL of its units of the level as LDS-DMA loads into a scratch KiB nobody reads -- 32
-  // in flight without a register -- and the fragment loads that follow hit the L2 (the lines are used within microseconds).
-  const unsigned scratch_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>((f16x3::lds_void*)(smem + SMEM - 1024)));
-  auto prefetch_b = [&](int r) __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < NJ * KS * 2; ++u) {
-      const char* src = bw + ((((static_cast<long long>(r) * NJB + wn * NJ) * KS) * 2 + u) << 10);
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(scratch_lds) : "memory", "m0");
-#pragma clang diagnostic pop
-    }
-  };
-
   int it = 0;
-  for (int ph = 0; ph < n_phases; ++ph) {
-  const int lv0 = ph * a.lp, nl = min(a.lp, a.R - lv0);
-  const bool first_ph = ph == 0, last_ph = ph == n_phases - 1;
   for (int ti = 0; ti < n_my; ++ti) {
     const int tile = tile_of(slot_of(ti));
     const long long row0 = static_cast<long long>(tile) * TM;
-    if (has_bias && last_ph) {       // this tile's support row sums -> LDS (each M wave a share; the level barriers publish them)
+    if (has_bias) {       // this tile's support row sums -> LDS (each M wave a share; the level barriers publish them)
       float* dst = rs_lds + (ti & 1) * TM * a.R;
       const int cnt = TM * a.R;
       for (int e = wn * 64 + lane; e < cnt; e += 64 * MW) {
@@ -469,7 +433,7 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
         dst[e] = row < a.n_dst ? a.rowsum[row0 * a.R + e] : 0.f;
       }
     }
-    for (int r = lv0; r < lv0 + nl; ++r, ++it) {
+    for (int r = 0; r < a.R; ++r, ++it) {
       f16x8 bF[BRING][2];
 #pragma unroll
       for (int p = 0; p < BRING - 1; ++p) load_b(bF[p], r, p / KS, p % KS);      // B does not depend on the gather: requested ahead of the barrier
@@ -478,9 +442,6 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       asm volatile("" ::: "memory");
       const int buf = it & 1;
       if (__builtin_expect(a.ablate & 1, 0)) continue;
-#if SG_FUSED_PREFETCH
-      if (!(a.ablate & 4)) prefetch_b(r);
-#endif
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         f32x16 P[2];
@@ -498,22 +459,16 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
         for (int ks = 0; ks < KS; ++ks) {
           // B fragments BRING - 1 k steps ahead (straight into the next column block at the end of this one)
           const int s2 = j * KS + ks + BRING - 1;
-          if (s2 < NJ * KS && !(a.ablate & 16)) load_b(bF[s2 % BRING], r, s2 / KS, s2 % KS);
+          if (s2 < NJ * KS) load_b(bF[s2 % BRING], r, s2 / KS, s2 % KS);
 #if SG_FUSED_ADB
           if (ks + 1 < KS) read_a(aF[(ks + 1) & 1], buf, ks + 1);
 #else
-          if (!(a.ablate & 32)) read_a(aF[0], buf, ks);
+          read_a(aF[0], buf, ks);
 #endif
           asm volatile("" ::: "memory");                      // the requests stay HERE: ahead of their use
           __builtin_amdgcn_sched_barrier(0);
           const f16x8 (&af)[2][2] = aF[SG_FUSED_ADB ? (ks & 1) : 0];
           const f16x8 (&bf)[2] = bF[(j * KS + ks) % BRING];
-          if (a.ablate & 8) {        // (timing: no matrix instructions; the operands are still consumed)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) { P[i][0] += static_cast<float>(af[i][0][0] + af[i][1][0]) + static_cast<float>(bf[0][0] + bf[1][0]); }
-            __builtin_amdgcn_sched_barrier(0);
-            continue;
-          }
 #pragma unroll
           for (int i = 0; i < 2; ++i) P[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[0], P[i], 0, 0, 0);
 #pragma unroll
@@ -534,20 +489,8 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
           }
       }
     }
-    // ---- the tile's result: (+ the partial sums of the earlier phases) (+ bias term, activation in the last phase), store ----
-    if (!first_ph) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const long long row = row0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * kh;
-          if (row < a.n_dst) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j][q] += a.out[row * a.ldo + (wn * NJ + j) * 32 + l31];
-          }
-        }
-    }
-    if (has_bias && last_ph) {
+    // ---- the tile's result: bias term, activation, store ----
+    if (has_bias) {
       const float* rs = rs_lds + (ti & 1) * TM * a.R + (4 * kh) * a.R;
       for (int r = 0; r < a.R; ++r) {
         float bv[NJ];
@@ -579,14 +522,13 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
           for (int j = 0; j < NJ; ++j) acc[i][j][q] = 0.f;
         }
     };
-    switch (last_ph ? a.act : SG_ACT_NONE) {
+    switch (a.act) {
       case SG_ACT_LEAKY: store_tile(std::integral_constant<int, SG_ACT_LEAKY>{}); break;
       case SG_ACT_RELU: store_tile(std::integral_constant<int, SG_ACT_RELU>{}); break;
       case SG_ACT_SIGMOID: store_tile(std::integral_constant<int, SG_ACT_SIGMOID>{}); break;
       case SG_ACT_TANH: store_tile(std::integral_constant<int, SG_ACT_TANH>{}); break;
       default: store_tile(std::integral_constant<int, SG_ACT_NONE>{}); break;
     }
-  }
   }
 }
 
@@ -813,12 +755,6 @@ SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, 
   a.act = act; a.slope = slope;
   static const int ablate = [] { const char* e = getenv("SG_FUSED_ABLATE"); return e ? atoi(e) : 0; }();
   a.ablate = ablate;
-  // levels per phase: SG_FUSED_LP (tuning), default 8 -- 2 MB of planes per phase.  Config-5 shard, fused forward, ms into
-  // users / items: one phase 23.5 / 24.9, lp 8 22.0 / 24.8, lp 4 22.7 / 25.7, lp 2 26.7 / 28.7, lp 1 37.3 / 35.4
-  // (fabric reads per launch 174 / 158 / 146 GB for one phase / lp 8 / lp 4 against 133 GB without the matrix work)
-  static const int lp_env = [] { const char* e = getenv("SG_FUSED_LP"); return e ? atoi(e) : 0; }();
-  a.lp = lp_env > 0 ? lp_env : 8;
-  if (a.lp > num_links) a.lp = num_links;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
