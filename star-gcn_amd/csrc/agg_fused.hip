@@ -72,6 +72,15 @@ constexpr int KD = 256;                   // width of the gathered rows (contrac
 constexpr int ND = 256;                   // output width
 constexpr int KS = KD / 16;               // k steps per level
 constexpr int NJB = ND / 32;              // 32-column blocks of the output
+#ifndef SG_FUSED_DIRECT
+#define SG_FUSED_DIRECT 0                 // 1: the matrix instructions accumulate straight into the running result (UNITS below): no
+#endif                                    // level-local product registers, seven B fragment sets in flight instead of three.  Measured
+                                          // (profiles/r5_fused_kernel.md): the same launch time -- B's loads and the gathered rows share
+                                          // the CU's L1 miss queue, a deeper ring only moves who waits -- and 4e-7 instead of 1e-7 error:
+                                          // kept as a build option, not shipped
+#ifndef SG_FUSED_ASMLOAD
+#define SG_FUSED_ASMLOAD 1                // B fragment loads in assembly (scalar base + lane offset, counted waits)
+#endif
 #ifndef SG_FUSED_GW
 #define SG_FUSED_GW 8
 #endif
@@ -79,7 +88,7 @@ constexpr int NJB = ND / 32;              // 32-column blocks of the output
 #define SG_FUSED_NB 16
 #endif
 #ifndef SG_FUSED_BRING
-#define SG_FUSED_BRING 3
+#define SG_FUSED_BRING (SG_FUSED_DIRECT ? 7 : 3)
 #endif
 #ifndef SG_FUSED_MW
 #define SG_FUSED_MW 8
@@ -95,7 +104,7 @@ constexpr int BRING = SG_FUSED_BRING;     // B fragment sets in flight per M wav
 constexpr int ZROW = KD * 2 + 16;         // bytes per row and plane in LDS: 528 = 132 words -> rows 4 banks apart
 constexpr int ZPLANE = TM * ZROW;
 constexpr int ZBUF = 2 * ZPLANE;          // value plane, residual plane
-constexpr int SMEM = 2 * ZBUF + 2 * TM * 4 + 2 * TM * SG_MAX_LINKS * 4;
+constexpr int SMEM = 2 * ZBUF + 2 * TM * 4 + 2 * TM * SG_MAX_LINKS * 4 + 4 * TM * 4;
 
 struct Args {
   const int32_t* f_ptr;
@@ -106,6 +115,7 @@ struct Args {
   long long ldx;
   const char* wplanes;         // unit (((r NJB + jb) KS + ks) 2 + plane): lane l holds B_r[n = 32 jb + (l & 31)][k = 16 ks + 8 (l >> 5) ..+7]
   const float* wscale;         // (R NJB) 2^-e of the block
+  const int* wexp;             // (R) e of the level (SG_FUSED_DIRECT: one exponent per level)
   const float* bias;           // (R, ND) packed, or null
   const float* rowsum;         // (n_dst, R), or null
   float* out;
@@ -146,12 +156,23 @@ struct Ctx {                    // one (item = tile x level, G wave): the rows a
   unsigned long long empt;      // my empty rows
   int e_lo, e_hi, ng;           // my edges; groups of NB (at least one, possibly all padding)
   int tile, r, it;              // tile = launch slot of the tile; it = ordinal of the item in this workgroup's sequence
+  int eb;                       // exponent of the level's B planes (SG_FUSED_DIRECT)
 };
 
 template <bool ZSAVE, bool NT>
 __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   float* sinv = reinterpret_cast<float*>(smem + 2 * ZBUF);       // [buffer][row] 2^-e of the row's planes
+  // UNITS (SG_FUSED_DIRECT).  The matrix waves keep a tile's running result in units of 2^-u[row], u = e_row + e_B of the level
+  // last accumulated (e_B: ONE exponent per level of B), and the matrix instructions add a level's products straight into it --
+  // no level-local product registers, which pays for six B fragment sets in flight instead of three.  A level whose natural
+  // unit lies within 2^8 above the smallest unit the row has seen (or below it) is taken as it is and the running result is
+  // first multiplied by fac[row] = 2^(u_new - u_old) <= 2^8 (exact); a level further down -- its products are more than 2^8
+  // smaller than those of the row's largest level -- is written to the planes in the CURRENT unit instead (fewer significant
+  // bits of its own, the same absolute resolution as the terms that dominate the sum), and an all-zero row keeps the unit.
+  int* urun = reinterpret_cast<int*>(smem + 2 * ZBUF + 2 * TM * 4 + 2 * TM * SG_MAX_LINKS * 4);   // [row] unit exponent after the row's last level
+  int* umin = urun + TM;                                          // [row] smallest unit exponent so far (1 << 20: none yet)
+  float* fac = reinterpret_cast<float*>(umin + TM);               // [buffer][row] factor for the running result at this level
   const int t = threadIdx.x, lane = t & 63, wave = rfl(t >> 6);
   const int G = gridDim.x, b = blockIdx.x;
   // launch slots of this workgroup: stratum ti (G consecutive slots) in boustrophedon order -- b, 2G-1-b, 2G+b, ... -- so that
@@ -187,6 +208,7 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       asm volatile("v_mov_b32 %0, %1" : "=v"(c.pv) : "v"(pv));
       asm volatile("v_mov_b32 %0, %1" : "=v"(c.pn) : "v"(pn));
       c.tile = slot; c.r = r; c.it = it;
+      c.eb = SG_FUSED_DIRECT ? static_cast<int>(*((f16x3::cst_int*)(a.wexp) + r)) : 0;
       const int p0 = __builtin_amdgcn_readlane(pv, 0), pE = __builtin_amdgcn_readlane(pn, 63);
       const long long total = pE - p0;
       int wj = 0;                                        // the wave whose share of the level's edges holds the row's first edge
@@ -234,6 +256,28 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       else dst = *p;
     };
 
+#if SG_FUSED_DIRECT
+    // the exponent a row's planes are written with at this level, and the bookkeeping of the row's unit (see UNITS above)
+    auto unit_of = [&](const Ctx& c, int j, int e_nat, bool zero) __attribute__((always_inline)) {
+      const int eb = c.eb;
+      const bool first = c.r == 0;
+      const int u_old = first ? 0 : rfl(urun[j]);
+      const int um_old = first ? (1 << 20) : rfl(umin[j]);
+      int u;
+      if (zero) u = first ? eb : u_old;
+      else if (e_nat + eb <= um_old + 8) u = e_nat + eb;
+      else u = u_old;
+      const int e_use = min(max(u - eb, -126), 126);
+      u = e_use + eb;
+      const int d = min(max(u - u_old, -127), 8);
+      if (lane == 0) {
+        urun[j] = u;
+        umin[j] = zero ? um_old : min(um_old, u);
+        fac[(c.it & 1) * TM + j] = d <= -127 ? 0.f : __uint_as_float(static_cast<unsigned>(127 + d) << 23);
+      }
+      return e_use;
+    };
+#endif
     // a finished row: row maximum -> scale -> two f16 planes in the item's LDS buffer (+ the fp32 row to zsave)
     auto emit = [&](const Ctx& c, int j, const f32x4& acc) __attribute__((always_inline)) {
       float mx = fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
@@ -253,6 +297,9 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
         if (bits != 0u && ex != 0xff) e = 14 - (max(ex, 1) - 127);
         e = min(max(e, -126), 126);
       }
+#if SG_FUSED_DIRECT
+      e = unit_of(c, j, e, mx == 0.f);
+#endif
       const float sc = __uint_as_float(static_cast<unsigned>(127 + e) << 23);
       unsigned h1[2], h2[2];
 #pragma unroll
@@ -283,7 +330,12 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       char* zb = smem + (c.it & 1) * ZBUF + j * ZROW + lane * 8;
       *reinterpret_cast<uint2*>(zb) = make_uint2(0u, 0u);
       *reinterpret_cast<uint2*>(zb + ZPLANE) = make_uint2(0u, 0u);
+#if SG_FUSED_DIRECT
+      const int ez = unit_of(c, j, 0, true);
+      if (lane == 0) sinv[(c.it & 1) * TM + j] = __uint_as_float(static_cast<unsigned>(127 - ez) << 23);
+#else
       if (lane == 0) sinv[(c.it & 1) * TM + j] = 1.f;
+#endif
       if (ZSAVE) {
         const long long row = static_cast<long long>(tile_of(c.tile)) * TM + j;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -399,19 +451,43 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
   const int wn = wave - GW;                                // output columns [32 NJ wn, 32 NJ (wn + 1))
   const int l31 = lane & 31, kh = lane >> 5;
   float* rs_lds = reinterpret_cast<float*>(smem + 2 * ZBUF + 2 * TM * 4);      // [tile parity][row][r] support row sums
-  f32x16 acc[2][NJ];
+  f32x16 acc[NJ][2];          // [column block][row block]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+      for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
 
-  const char* bw = a.wplanes + lane * 16;
+  // B fragment loads in assembly: wave-uniform 64-bit base in scalar registers + the lane's 32-bit offset.  (Written in C++ the
+  // compiler forms one 64-bit VGPR address per unit, hoists all 32 of a level out of the loops and spills them.)  The compiler
+  // does not see these loads: wait_b<N>() is the counted wait before a fragment set's first use -- N = loads issued after it.
+  const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
   auto load_b = [&](f16x8 (&bf)[2], int r, int j, int ks) __attribute__((always_inline)) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-      bf[p] = *reinterpret_cast<const f16x8*>(bw + ((((static_cast<long long>(r) * NJB + wn * NJ + j) * KS + ks) * 2 + p) << 10));
+    const char* ub = a.wplanes + ((((static_cast<long long>(r) * NJB + wn * NJ + j) * KS + ks) * 2) << 10);
+#if SG_FUSED_ASMLOAD
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(bf[0]) : "v"(lane16), "s"(ub) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(bf[1]) : "v"(lane16), "s"(ub) : "memory");
+#else
+    bf[0] = *reinterpret_cast<const f16x8*>(ub + lane16);
+    bf[1] = *reinterpret_cast<const f16x8*>(ub + 1024 + lane16);
+#endif
+  };
+  auto wait_b = [&](f16x8 (&bf)[2], int n) __attribute__((always_inline)) {      // n is a constant after unrolling
+#if SG_FUSED_ASMLOAD
+#define SG_WAITB(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bf[0]), "+v"(bf[1]) : : "memory")
+#else
+#define SG_WAITB(N) (void)bf
+#endif
+    if (n <= 0) SG_WAITB(0);
+    else if (n == 2) SG_WAITB(2);
+    else if (n == 4) SG_WAITB(4);
+    else if (n == 6) SG_WAITB(6);
+    else if (n == 8) SG_WAITB(8);
+    else if (n == 10) SG_WAITB(10);
+    else if (n == 12) SG_WAITB(12);
+    else SG_WAITB(14);
+#undef SG_WAITB
   };
   auto read_a = [&](f16x8 (&af)[2][2], int buf, int ks) __attribute__((always_inline)) {
 #pragma unroll
@@ -444,11 +520,25 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       if (__builtin_expect(a.ablate & 1, 0)) continue;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
+#if SG_FUSED_DIRECT
+        f32x16 (&P)[2] = acc[j];                            // the running result itself, brought to the level's unit
+        {     // (also at a tile's first level: the running result is zero there and the factor finite)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const f32x4 f4 = *reinterpret_cast<const f32x4*>(fac + buf * TM + 32 * i + 8 * g4 + 4 * kh);
+#pragma unroll
+              for (int v = 0; v < 4; ++v) P[i][4 * g4 + v] *= f4[v];
+            }
+        }
+#else
         f32x16 P[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int q = 0; q < 16; ++q) P[i][q] = 0.f;
+#endif
 #if SG_FUSED_ADB
         f16x8 aF[2][2][2];
         read_a(aF[0], buf, 0);
@@ -468,7 +558,9 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
           asm volatile("" ::: "memory");                      // the requests stay HERE: ahead of their use
           __builtin_amdgcn_sched_barrier(0);
           const f16x8 (&af)[2][2] = aF[SG_FUSED_ADB ? (ks & 1) : 0];
-          const f16x8 (&bf)[2] = bF[(j * KS + ks) % BRING];
+          f16x8 (&bf)[2] = bF[(j * KS + ks) % BRING];
+          // fragment sets requested after this one: BRING - 1, fewer at the end of the level
+          wait_b(bf, 2 * min(NJ * KS - 1 - (j * KS + ks), BRING - 1));
 #pragma unroll
           for (int i = 0; i < 2; ++i) P[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[0], P[i], 0, 0, 0);
 #pragma unroll
@@ -477,6 +569,7 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
           for (int i = 0; i < 2; ++i) P[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[0], P[i], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
+#if !SG_FUSED_DIRECT
         // fold: acc += P * 2^-e_row * 2^-e_B
         const float sb = a.wscale[r * NJB + wn * NJ + j];
 #pragma unroll
@@ -485,10 +578,28 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
           for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinv + buf * TM + 32 * i + 8 * g4 + 4 * kh);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[i][j][4 * g4 + v] = __builtin_fmaf(P[i][4 * g4 + v] * s4[v], sb, acc[i][j][4 * g4 + v]);
+            for (int v = 0; v < 4; ++v) acc[j][i][4 * g4 + v] = __builtin_fmaf(P[i][4 * g4 + v] * s4[v], sb, acc[j][i][4 * g4 + v]);
+          }
+#endif
+      }
+    }
+#if SG_FUSED_DIRECT
+    {   // out of the last level's unit: 2^-e_row (its planes' scale) * 2^-e_B
+      const int buf = (it - 1) & 1;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const float sb = a.wscale[(a.R - 1) * NJB + wn * NJ + j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinv + buf * TM + 32 * i + 8 * g4 + 4 * kh);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[j][i][4 * g4 + v] = (acc[j][i][4 * g4 + v] * s4[v]) * sb;
           }
       }
     }
+#endif
     // ---- the tile's result: bias term, activation, store ----
     if (has_bias) {
       const float* rs = rs_lds + (ti & 1) * TM * a.R + (4 * kh) * a.R;
@@ -502,7 +613,7 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
           for (int q = 0; q < 16; ++q) {
             const float s = rs[(32 * i + (q & 3) + 8 * (q >> 2)) * a.R + r];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j][q] = __builtin_fmaf(s, bv[j], acc[i][j][q]);
+            for (int j = 0; j < NJ; ++j) acc[j][i][q] = __builtin_fmaf(s, bv[j], acc[j][i][q]);
           }
       }
     }
@@ -516,10 +627,10 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
           if (row < a.n_dst) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-              a.out[row * a.ldo + (wn * NJ + j) * 32 + l31] = f16x3::act_fn(acc[i][j][q], ACT, a.slope);
+              a.out[row * a.ldo + (wn * NJ + j) * 32 + l31] = f16x3::act_fn(acc[j][i][q], ACT, a.slope);
           }
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j][q] = 0.f;
+          for (int j = 0; j < NJ; ++j) acc[j][i][q] = 0.f;
         }
     };
     switch (a.act) {
@@ -539,7 +650,7 @@ struct WTable {
   const float* w[SG_MAX_LINKS];
   const float* b[SG_MAX_LINKS];
 };
-__global__ __launch_bounds__(256) void split_w_kernel(char* __restrict__ planes, float* __restrict__ wscale,
+__global__ __launch_bounds__(256) void split_w_kernel(char* __restrict__ planes, float* __restrict__ wscale, int* __restrict__ wexp,
                                                       float* __restrict__ bias_pack, const WTable tab, long long ldw, int trans) {
   __shared__ float tile[32][KD + 1];
   __shared__ float wmax[4];
@@ -562,6 +673,14 @@ __global__ __launch_bounds__(256) void split_w_kernel(char* __restrict__ planes,
       m = fmaxf(m, fabsf(v) <= 3.402823466e38f ? fabsf(v) : 0.f);
     }
   }
+#if SG_FUSED_DIRECT
+  // one exponent per LEVEL (the matrix waves accumulate across the column blocks' products in one unit per row): the maximum of
+  // the whole 256 x 256 matrix, recomputed by each of the level's eight workgroups
+  for (int e2 = t; e2 < KD * ND; e2 += 256) {
+    const float v = fabsf(W[static_cast<long long>(e2 >> 8) * ldw + (e2 & 255)]);
+    m = fmaxf(m, v <= 3.402823466e38f ? v : 0.f);
+  }
+#endif
   m = wave_max_nonneg(m);
   if ((t & 63) == 0) wmax[t >> 6] = m;
   __syncthreads();
@@ -596,6 +715,7 @@ __global__ __launch_bounds__(256) void split_w_kernel(char* __restrict__ planes,
     *reinterpret_cast<uint4*>(u + 1024) = make_uint4(h2[0], h2[1], h2[2], h2[3]);
   }
   if (t == 0) wscale[r * NJB + jb] = __uint_as_float(static_cast<unsigned>(127 - e) << 23);
+  if (t == 0 && jb == 0 && wexp) wexp[r] = e;
   if (bias_pack && t < 32) bias_pack[r * ND + 32 * jb + t] = tab.b[r] ? tab.b[r][32 * jb + t] : 0.f;
 }
 
@@ -706,7 +826,7 @@ SG_API int sg_agg_fused_refresh_hip(float* f_w, const int32_t* f_pos, const floa
 
 SG_API size_t sg_agg_fused_workspace_bytes(int32_t num_links) {
   const size_t R = static_cast<size_t>(num_links);
-  return fused::al256(R * fused::NJB * fused::KS * 2 * 1024) + fused::al256(R * fused::NJB * 4) + fused::al256(R * fused::ND * 4) + 256;
+  return fused::al256(R * fused::NJB * fused::KS * 2 * 1024) + fused::al256(R * fused::NJB * 4) + fused::al256(R * fused::ND * 4) + fused::al256(R * 4) + 256;
 }
 
 // out (n_dst, ldo) = act( sum_r (A_r x) B_r + sum_r rowsum[:, r] b_r ),  x (n_src, ldx) of width 256, out width 256.
@@ -734,6 +854,7 @@ SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, 
   char* planes = base;
   float* wscale = reinterpret_cast<float*>(base + fused::al256(R * fused::NJB * fused::KS * 2 * 1024));
   float* bias_pack = reinterpret_cast<float*>(reinterpret_cast<char*>(wscale) + fused::al256(R * fused::NJB * 4));
+  int* wexp = reinterpret_cast<int*>(reinterpret_cast<char*>(bias_pack) + fused::al256(R * fused::ND * 4));
   fused::WTable tab{};
   for (int r = 0; r < num_links; ++r) {
     if (!weights[r]) return fail(SG_ERR_INVALID, "weights[%d] is null", r);
@@ -741,14 +862,14 @@ SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, 
     tab.b[r] = biases ? biases[r] : nullptr;
   }
   const bool has_bias = biases && rowsum;
-  hipLaunchKernelGGL(fused::split_w_kernel, dim3(static_cast<unsigned>(R * fused::NJB)), dim3(256), 0, st, planes, wscale,
+  hipLaunchKernelGGL(fused::split_w_kernel, dim3(static_cast<unsigned>(R * fused::NJB)), dim3(256), 0, st, planes, wscale, wexp,
                      has_bias ? bias_pack : static_cast<float*>(nullptr), tab, static_cast<long long>(ldw), trans_w);
   if (check_launch("fused::split_w_kernel") != SG_OK) return SG_ERR_HIP;
 
   fused::Args a{};
   a.f_ptr = f_ptr; a.f_idx = f_idx; a.f_w = f_w; a.tile_order = tile_order;
   a.x = x; a.ldx = ldx;
-  a.wplanes = planes; a.wscale = wscale;
+  a.wplanes = planes; a.wscale = wscale; a.wexp = wexp;
   a.bias = has_bias ? bias_pack : nullptr; a.rowsum = has_bias ? rowsum : nullptr;
   a.out = out; a.ldo = ldo; a.zsave = zsave; a.ldz = ldz;
   a.n_dst = static_cast<int>(n_dst); a.n_tiles = static_cast<int>(sg_agg_fused_tiles(n_dst)); a.R = num_links;

@@ -6,11 +6,11 @@ set -e
 cd "$(dirname "$0")/../star-gcn_amd/csrc"
 make -j8 > /dev/null
 OBJS=$(ls *.o | grep -v agg_fused.o)
-while read name gw mw nb br adb; do
+while read name gw mw nb br adb extra; do
   [ -z "$name" ] && continue
   d=../../tools/ablate/fv_$name; mkdir -p $d
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-parameter \
-    -DSG_FUSED_GW=$gw -DSG_FUSED_MW=$mw -DSG_FUSED_NB=$nb -DSG_FUSED_BRING=$br -DSG_FUSED_ADB=$adb -c agg_fused.hip -o $d/agg_fused.o
+    -DSG_FUSED_GW=$gw -DSG_FUSED_MW=$mw -DSG_FUSED_NB=$nb -DSG_FUSED_BRING=$br -DSG_FUSED_ADB=$adb $extra -c agg_fused.hip -o $d/agg_fused.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $d/libstargcn_hip.so $OBJS $d/agg_fused.o
   echo "built $name: GW $gw MW $mw NB $nb BRING $br ADB $adb"
 done <<LIST
