@@ -170,9 +170,11 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
   // first multiplied by fac[row] = 2^(u_new - u_old) <= 2^8 (exact); a level further down -- its products are more than 2^8
   // smaller than those of the row's largest level -- is written to the planes in the CURRENT unit instead (fewer significant
   // bits of its own, the same absolute resolution as the terms that dominate the sum), and an all-zero row keeps the unit.
+#if SG_FUSED_DIRECT
   int* urun = reinterpret_cast<int*>(smem + 2 * ZBUF + 2 * TM * 4 + 2 * TM * SG_MAX_LINKS * 4);   // [row] unit exponent after the row's last level
   int* umin = urun + TM;                                          // [row] smallest unit exponent so far (1 << 20: none yet)
   float* fac = reinterpret_cast<float*>(umin + TM);               // [buffer][row] factor for the running result at this level
+#endif
   const int t = threadIdx.x, lane = t & 63, wave = rfl(t >> 6);
   const int G = gridDim.x, b = blockIdx.x;
   // launch slots of this workgroup: stratum ti (G consecutive slots) in boustrophedon order -- b, 2G-1-b, 2G+b, ... -- so that

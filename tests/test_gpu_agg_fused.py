@@ -184,3 +184,47 @@ def test_fused_order_at_ml10m_size_against_the_definition_and_the_unfused_orders
         terms = (out - const).double() * y.double()
         lhs, rhs = float(terms.sum()), float((dx.double() * x1.double()).sum())
         assert abs(lhs - rhs) <= 1e-9 * float(terms.abs().sum()), (dst, lhs, rhs, float(terms.abs().sum()))
+
+
+def test_fused_order_replays_inside_a_hip_graph():
+    """forward + backward of the fused order captured into one hipGraph (after an eager step built the plan's fused edge orders)
+    and replayed on new inputs: the same bits as the eager call -- no allocation, host read-back or stream switch hides in the
+    fused entry points."""
+    from star_gcn_amd import functional as F
+    from star_gcn_amd.plan import MultiLinkPlan
+    rng = np.random.default_rng(77)
+    n_dst, n_src, nnz, R = 500, 400, 40000, 6
+    eps, ips, sps = make_multilink(rng, n_dst, n_src, nnz, R)
+    plan = MultiLinkPlan(eps, ips, sps, n_src, "cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ws = [(torch.randn(D, D, device="cuda", generator=g) / 16).requires_grad_(True) for _ in range(R)]
+    bs = [(torch.randn(D, device="cuda", generator=g) * 0.1).requires_grad_(True) for _ in range(R)]
+    x = torch.randn(n_src, D, device="cuda", generator=g).requires_grad_(True)
+    gy = torch.randn(n_dst, D, device="cuda", generator=g)
+
+    def step():
+        for t in [x] + ws + bs:
+            t.grad = None
+        out = F.multilink_aggregate(x, ws, bs, plan, accum="sum", act="leaky", order="fused")
+        out.backward(gy)
+        return out.detach(), x.grad, ws[0].grad, bs[-1].grad
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = step()
+    with torch.no_grad():
+        x.copy_(torch.randn(n_src, D, device="cuda", generator=g))
+        gy.copy_(torch.randn(n_dst, D, device="cuda", generator=g))
+    graph.replay()
+    torch.cuda.synchronize()
+    replayed = [t.clone() for t in captured]
+    eager = step()
+    for a, b in zip(replayed, eager):
+        assert torch.equal(a, b)
