@@ -389,7 +389,11 @@ def fused_roofline(records, E_local, D, steps, rows_saved_bytes):
            "achieved": b_edge * len(recs) / total_t / 1e9, "launches_per_step": len(recs) / steps,
            "aggregations_per_step": len(recs) / steps, "avg_launch_ms": total_t / len(recs) * 1e3,
            "avg_aggregation_ms": total_t / len(recs) * 1e3, "algorithmic_bytes_per_launch": b_edge,
-           "algorithmic_bytes_per_aggregation": b_edge, "per_class": []}
+           "algorithmic_bytes_per_aggregation": b_edge, "per_class": [],
+           "note": "a launch is a whole aggregation INCLUDING its per-level contraction (rounds 1-4 timed the gather alone and ran "
+                   "the contraction as a separate GEMM that re-read a 16 GB intermediate): the fraction is of the same 8 TB/s peak "
+                   "on the same edges x (8 + 4 D) bytes, so it is lower than the gather-only 0.78 while the step is shorter; "
+                   "SG_FUSED=0 runs the unfused pair"}
     for z, name in ((0, "forward (writes only the 256-wide output)"), (1, "data gradient (also writes the fp32 aggregates)")):
         c = [t for t, _, zz in recs if zz == z]
         if c:
