@@ -125,7 +125,7 @@ struct Args {
   int n_dst, n_tiles, R;
   int act;
   float slope;
-  int ablate;                  // timing experiments only (SG_FUSED_ABLATE): 1 = no matrix work, 2 = every row load reads row 0
+  int ablate;                  // timing experiments only (SG_FUSED_ABLATE): 1 = no matrix work, 2 = every row load reads row 0, 64 = every level's B planes = level 0's
 };
 
 __device__ __forceinline__ unsigned wave_or(unsigned v) {
@@ -466,6 +466,7 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
   // does not see these loads: wait_b<N>() is the counted wait before a fragment set's first use -- N = loads issued after it.
   const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
   auto load_b = [&](f16x8 (&bf)[2], int r, int j, int ks) __attribute__((always_inline)) {
+    if (a.ablate & 64) r = 0;       // (timing: every level multiplies by level 0's planes -- 256 KB that stay in the L2s)
     const char* ub = a.wplanes + ((((static_cast<long long>(r) * NJB + wn * NJ + j) * KS + ks) * 2) << 10);
 #if SG_FUSED_ASMLOAD
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(bf[0]) : "v"(lane16), "s"(ub) : "memory");
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       __builtin_amdgcn_s_barrier();                         // item `it` is published
       asm volatile("" ::: "memory");
       const int buf = it & 1;
-      if (__builtin_expect(a.ablate & 1, 0)) continue;
+      if (__builtin_expect(a.ablate & 1, 0)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); continue; }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
 #if SG_FUSED_DIRECT
@@ -603,6 +604,10 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
     }
 #endif
     // ---- the tile's result: bias term, activation, store ----
+    // (the assembly loads above are invisible to the compiler: none may be in flight when it re-uses their registers for the
+    //  addresses below.  The last k step's wait already drained them on this path; a build whose compiler peeled the level loop
+    //  -- SG_FUSED_DIRECT with `if (r > 0)` around the rescale -- faulted here without this wait.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (has_bias) {
       const float* rs = rs_lds + (ti & 1) * TM * a.R + (4 * kh) * a.R;
       for (int r = 0; r < a.R; ++r) {
