@@ -141,6 +141,46 @@ def test_multilink_fuse_structure():
     assert np.array_equal(plan.s_indptr.numpy(), t_indptr[::R])
 
 
+def test_fused_order_routing_and_sizes_are_host_decisions(monkeypatch):
+    """sg_multilink_agg_resolve_order2 (SG_ORDER_FUSED = 3, csrc/agg_fused.hip): 'auto' fuses only 256-wide 'sum' aggregations
+    over graphs whose R-expanded matrix would travel through HBM; buffer sizes of the fused order; the plan-geometry helpers.
+    Nothing is launched."""
+    monkeypatch.delenv("SG_FUSED", raising=False)
+    lib = L.lib()
+    st = L.MultiLinkPlanStruct()
+    ref = ctypes.cast(ctypes.pointer(st), ctypes.c_void_p)
+    st.n_dst, st.n_src, st.nnz, st.num_links = 1_000_000, 1_250_000, 125_000_000, 16          # the config-5 shard
+    assert lib.sg_multilink_agg_resolve_order2(ref, 0, 256, 256, 0) == 3
+    assert lib.sg_multilink_agg_resolve_order2(ref, 0, 256, 256, 1) == 2          # 'stack': not fused, expansion on the smaller side
+    assert lib.sg_multilink_agg_resolve_order2(ref, 0, 128, 256, 0) == 2          # other widths
+    assert lib.sg_multilink_agg_resolve_order2(ref, 1, 256, 256, 0) == 1          # an explicit order is kept
+    assert lib.sg_multilink_agg_resolve_order2(ref, 3, 64, 64, 0) == 3            # ... also 'fused' (the launch then refuses)
+    st.n_dst, st.n_src, st.nnz, st.num_links = 69878, 10677, 10_000_054, 10       # MovieLens-10M: cache-resident, 167 item tiles
+    assert lib.sg_multilink_agg_resolve_order2(ref, 0, 256, 256, 0) == 1
+    st.n_dst, st.n_src, st.nnz = 200_000, 200_000, 1 << 23                        # too few edges
+    assert lib.sg_multilink_agg_resolve_order2(ref, 0, 256, 256, 0) in (1, 2)
+    assert lib.sg_multilink_agg_resolve_order2(ref, 7, 256, 256, 0) < 0
+    # sizes: nothing saved by the fused forward; its backward workspace holds dpre, dH (n_src x R x 256) and the packed gradients
+    st.n_dst, st.n_src, st.nnz, st.num_links = 1000, 3000, 50000, 4
+    st.struct_bytes = ctypes.sizeof(L.MultiLinkPlanStruct)
+    assert lib.sg_multilink_agg_workspace_bytes(ref, 256, 256, 3, 0, 1) == 0      # no level-major edge orders attached: invalid
+    for which in range(2):                 # (size queries never dereference them)
+        st.fused[which].f_ptr = st.fused[which].f_idx = st.fused[which].f_w = 4096
+    assert lib.sg_multilink_agg_saved_bytes(ref, 256, 256, 3, 0) == 0
+    wb = lib.sg_multilink_agg_workspace_bytes(ref, 256, 256, 3, 0, 1)
+    assert wb >= (1000 * 256 + 3000 * 4 * 256 + 4 * 256 * 256) * 4 and wb >= lib.sg_agg_fused_workspace_bytes(4)
+    assert lib.sg_multilink_agg_workspace_bytes(ref, 256, 256, 3, 0, 0) >= lib.sg_agg_fused_workspace_bytes(4)
+    assert lib.sg_agg_fused_workspace_bytes(16) >= 16 * 256 * 256 * 4            # two f16 planes of sixteen 256 x 256 matrices
+    assert lib.sg_agg_fused_tiles(0) == 0 and lib.sg_agg_fused_tiles(64) == 1 and lib.sg_agg_fused_tiles(65) == 2
+    assert lib.sg_agg_fused_supported(256, 256, 32) == 1 and lib.sg_agg_fused_supported(256, 256, 33) == 0
+    assert lib.sg_agg_fused_supported(256, 128, 4) == 0
+    # a fused launch without the plan's level-major edge orders is refused with a message, not run
+    for which in range(2):
+        st.fused[which].f_ptr = None
+    rc = lib.sg_multilink_agg_fwd_hip(None, None, None, None, None, ref, 256, 256, 3, 0, 0, 0.0, None, 0, None)
+    assert rc < 0 and b"fused" in lib.sg_last_error().lower()
+
+
 def test_fused_aggregator_entry_sizes_orders_and_errors():
     """sg_multilink_agg_* (the fused entry of SURVEY 8b): order resolution, buffer sizing and argument errors are
     host-side decisions -- checked here without launching anything."""
