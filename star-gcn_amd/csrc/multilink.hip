@@ -99,6 +99,50 @@ __global__ void fill_rowsum_kernel(float* __restrict__ zext, const float* __rest
   zext[row * ld + static_cast<long long>(R) * D + c] = c < R ? rowsum[row * R + c] : 0.f;
 }
 
+// db[r, u] = sum_i rowsum[i, r] * dpre[i, u]  -- the bias gradient of the fused order (= the column sums of dH_r without reading
+// the 16-20 GB of dH): pass 1, workgroup b sums rows b, b + P, ... into part[b][r][u] (one column per thread, R running sums in
+// registers, four rows in flight); pass 2 adds the P partials in order.  Bandwidth-bound on dpre (1.3 GB at the config-5 shard:
+// 0.3 ms where the 16 x 256 x n product on the exact-fp32 GEMM took 1 ms); deterministic.
+constexpr int kDbParts = 512;
+template <int RMAX>
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(float* __restrict__ part, const float* __restrict__ rowsum,
+                                                                 const float* __restrict__ dpre, long long n, int R, int U) {
+  const int u = blockIdx.y * 256 + threadIdx.x;
+  const int b = blockIdx.x, P = gridDim.x;
+  float acc[RMAX];
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) acc[r] = 0.f;
+  if (u < U) {
+    long long i = b;
+    for (; i + 3ll * P < n; i += 4ll * P) {
+      float g[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[q] = dpre[(i + static_cast<long long>(q) * P) * U + u];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* rs = rowsum + (i + static_cast<long long>(q) * P) * R;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) if (r < R) acc[r] = fmaf(rs[r], g[q], acc[r]);
+      }
+    }
+    for (; i < n; i += P) {
+      const float g = dpre[i * U + u];
+      const float* rs = rowsum + i * R;
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) if (r < R) acc[r] = fmaf(rs[r], g, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) if (r < R) part[(static_cast<long long>(b) * R + r) * U + u] = acc[r];
+  }
+}
+__global__ void bias_grad_final_kernel(float* __restrict__ db, const float* __restrict__ part, int P, int RU) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= RU) return;
+  float s = 0.f;
+  for (int b = 0; b < P; ++b) s += part[static_cast<long long>(b) * RU + i];
+  db[i] = s;
+}
+
 inline unsigned blocks_for(long long n) { return static_cast<unsigned>((n + 255) / 256); }
 inline size_t al(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
 inline size_t max2(size_t a, size_t b) { return a > b ? a : b; }
@@ -188,7 +232,7 @@ Layout make_layout(const Dims& d, bool backward) {
       L.b = take(d.n_src * d.RU * f);                                                // dH (written by the fused data gradient)
       L.c = take((d.RU * d.D + d.RU) * f);                                           // dWcat | dbcat
       sc = max2(sc, max2(sg_seg_weighted_pool_workspace_bytes(1, d.n_src * d.R, d.nnz, d.U),
-                         max2(sg_gemm_f32_workspace_bytes(d.RU, d.D, d.n_src, 1), sg_gemm_f32_workspace_bytes(d.R, d.U, d.n_dst, 1))));
+                         max2(sg_gemm_f32_workspace_bytes(d.RU, d.D, d.n_src, 1), static_cast<size_t>(kDbParts) * d.RU * f)));
     }
   } else if (d.order == SG_ORDER_TRANSFORM_FIRST) {
     L.wpack = take(d.RU * d.D * f);
@@ -441,9 +485,19 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
       SG_TRY(sg_gemm_f32_hip(dwcat, d.D, dh, d.RU, 1, x, d.D, 0, d.RU, d.D, d.n_src, nullptr, SG_ACT_NONE, 0.f, 0,
                              scratch, L.scratch_bytes, stream));
     }
-    if (want_b)
-      SG_TRY(sg_gemm_f32_hip(dbcat, d.U, plan->rowsum, d.R, 1, dpre, d.U, 0, d.R, d.U, d.n_dst, nullptr, SG_ACT_NONE, 0.f, 0,
-                             scratch, L.scratch_bytes, stream));
+    if (want_b) {
+      float* part = reinterpret_cast<float*>(scratch);
+      const int P = static_cast<int>(d.n_dst < kDbParts ? d.n_dst : kDbParts);
+      const dim3 grid(static_cast<unsigned>(P), static_cast<unsigned>((d.U + 255) / 256));
+      if (d.R <= 16)
+        hipLaunchKernelGGL(bias_grad_partial_kernel<16>, grid, dim3(256), 0, st, part, plan->rowsum, dpre,
+                           static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U));
+      else
+        hipLaunchKernelGGL(bias_grad_partial_kernel<SG_MAX_LINKS>, grid, dim3(256), 0, st, part, plan->rowsum, dpre,
+                           static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U));
+      hipLaunchKernelGGL(bias_grad_final_kernel, dim3(blocks_for(d.RU)), dim3(256), 0, st, dbcat, part, P, static_cast<int>(d.RU));
+      SG_TRY(check_launch("bias_grad kernels"));
+    }
     if (want_w || want_b) {
       hipLaunchKernelGGL(unpack_cat_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, dw, db,
                          want_w ? dwcat : static_cast<const float*>(nullptr),
