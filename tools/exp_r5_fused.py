@@ -197,11 +197,34 @@ def bench_graph(nu=1_250_000, ni=1_000_000, ne=125_000_000, R=16):
             int(tw.max()), float(tw.float().mean())), flush=True)
 
 
+def ml10m_forward():
+    """forward of either direction at the MovieLens-10M shape: fused against the unfused orders (is the tile kernel usable where
+    the gathered matrix is small?)"""
+    import star_gcn_amd.synthetic as S
+    from star_gcn_amd import functional as F
+    from star_gcn_amd.plan import MultiLinkPlan
+    graph, eu, ei, vals = S.make_graph("ml-10m")
+    for dst, src in (("user", "movie"), ("movie", "user")):
+        m = graph[dst, src]
+        eps, _, ips, sps = m.sample_neighbors(symm=True, use_multi_link=True, num_neighbors=-1)
+        plan = MultiLinkPlan(eps, ips, sps, m.shape[1], "cuda")
+        x = torch.randn(plan.n_src, D, device="cuda")
+        Ws = [torch.randn(D, D, device="cuda") / 16 for _ in range(plan.R)]
+        bs = [torch.randn(D, device="cuda") for _ in range(plan.R)]
+        with torch.no_grad():
+            for order in ("fused", "transform_first", "aggregate_first"):
+                t = timeit(lambda: F.multilink_aggregate(x, Ws, bs, plan, accum="sum", act="leaky", order=order), n=9, warm=3)
+                print("into %-5s (%d x %d, %d tiles) %-16s %.3f ms" % (dst, plan.n_dst, plan.n_src, (plan.n_dst + 63) // 64, order, t), flush=True)
+
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "check":
         check()
     elif sys.argv[1] == "bench-graph":
         bench_graph()
+    elif sys.argv[1] == "ml10m":
+        ml10m_forward()
     else:
         a = [int(v) for v in sys.argv[2:6]] if len(sys.argv) >= 6 else [1_000_000, 1_250_000, 125_000_000, 16]
         time_case(*a)
