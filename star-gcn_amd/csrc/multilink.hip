@@ -179,7 +179,11 @@ int resolve_order2(const sg_multilink_plan* p, int order, int64_t in_dim, int64_
     // walks the other side), and the fusion only pays where the R-expanded matrix would travel through HBM.  Measured: the
     // config-5 shard (1.25 M x 1 M, 125 M edges) 305 -> 272 ms per step; the MovieLens-10M shape (10 677 items = 167 tiles,
     // cache-resident sources) 9.2 -> 23 ms -- the column-sliced gather lives on L2 hits the tile kernel cannot have
-    const bool big = p->nnz >= (1ll << 24) && small_side >= (1ll << 17) && small_side * p->num_links * in_dim * 4 > (256ll << 20);
+    // (mid-size checks, same box, ms per step unfused / fused: 300 k x 250 k, 30 M edges, 16 levels 69.0 / 68.4; 150 k x 140 k,
+    //  20 M, 10 levels 39.6 / 35.7; 600 k x 500 k, 60 M, 5 levels 101.9 / 104.9 -- with few levels the expanded matrix is small
+    //  and its GEMM cheap, so the rule also asks for >= 8 levels)
+    const bool big = p->nnz >= (1ll << 24) && small_side >= (1ll << 17) && p->num_links >= 8 &&
+                     small_side * p->num_links * in_dim * 4 > (256ll << 20);
     if (mode == 1 || (mode != 0 && big)) return SG_ORDER_FUSED;
   }
   return resolve_order(p, order);

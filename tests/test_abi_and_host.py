@@ -157,7 +157,9 @@ def test_fused_order_routing_and_sizes_are_host_decisions(monkeypatch):
     assert lib.sg_multilink_agg_resolve_order2(ref, 3, 64, 64, 0) == 3            # ... also 'fused' (the launch then refuses)
     st.n_dst, st.n_src, st.nnz, st.num_links = 69878, 10677, 10_000_054, 10       # MovieLens-10M: cache-resident, 167 item tiles
     assert lib.sg_multilink_agg_resolve_order2(ref, 0, 256, 256, 0) == 1
-    st.n_dst, st.n_src, st.nnz = 200_000, 200_000, 1 << 23                        # too few edges
+    st.n_dst, st.n_src, st.nnz, st.num_links = 600_000, 500_000, 60_000_000, 5    # few levels: the expanded matrix is cheap
+    assert lib.sg_multilink_agg_resolve_order2(ref, 0, 256, 256, 0) == 1
+    st.n_dst, st.n_src, st.nnz, st.num_links = 200_000, 200_000, 1 << 23, 10      # too few edges
     assert lib.sg_multilink_agg_resolve_order2(ref, 0, 256, 256, 0) in (1, 2)
     assert lib.sg_multilink_agg_resolve_order2(ref, 7, 256, 256, 0) < 0
     # sizes: nothing saved by the fused forward; its backward workspace holds dpre, dH (n_src x R x 256) and the packed gradients
