@@ -24,6 +24,8 @@ CASES = [  # n_dst, n_src, nnz, R
     (65, 70, 50, 4),              # mostly empty (row, level) segments
     (1000, 700, 90000, 16),
     (130, 90, 3000, 1),           # one level
+    (300, 200, 20000, 32),        # SG_MAX_LINKS levels
+    (200, 150, 9000, 17),         # an odd level count
 ]
 
 
