@@ -1,7 +1,12 @@
 """Round 5: the fused aggregate -> contract kernel (csrc/agg_fused.hip) -- correctness against float64 on small graphs and
-timing at the config-5 shard shape against the unfused pair (gather into the R-expanded matrix + the 256-wide GEMM).
-  python tools/exp_r5_fused.py check
-  python tools/exp_r5_fused.py time [n_dst n_src nnz R]"""
+timing against the unfused pair (gather into the R-expanded matrix + the 256-wide GEMM).
+  python tools/exp_r5_fused.py check                        six graphs (hub row, empty segments, both weight orientations) vs float64
+  python tools/exp_r5_fused.py time [n_dst n_src nnz R]     uniform graph of the config-5 shard's size: fused / fused + saved
+                                                            aggregates / gather + GEMM
+  python tools/exp_r5_fused.py bench-graph                  fused forward of either direction on bench.py's config-5 shard graph
+                                                            (honours SG_FUSED_ABLATE, SG_FUSED_NT, SG_LIB_OVERRIDE)
+  python tools/exp_r5_fused.py ml10m                        forward of either direction at the MovieLens-10M shape, all orders
+Results: profiles/r5_fused_kernel.md."""
 import ctypes
 import os
 import sys

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (Ran on the development build that still had level phases -- SG_FUSED_LP no longer exists in csrc/agg_fused.hip.)
 # PMC of the fused kernel under its tuning switches on the config-5 shard graph (tools/exp_r5_fused.py bench-graph):
 # FETCH_SIZE and TCC_HIT_sum / TCC_MISS_sum per launch for: default, SG_FUSED_NT=1, SG_FUSED_LP=8, SG_FUSED_ABLATE=1 (no matrix work)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
