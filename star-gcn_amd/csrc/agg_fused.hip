@@ -6,31 +6,35 @@
 // h_r = FullyConnected(x) (written, n_src x U) and seg_weighted_pool(h_r) and adds the R results; the unfused path of
 // this library (multilink.hip) does one gather into an R-expanded matrix (n x R*D floats: 16 GB at the config-5 shard)
 // and one GEMM that reads it back.  Here a workgroup owns a TILE of 64 destination rows; for every level r the
-// aggregate Z_r (64 x 256 fp32) exists only as two f16 planes in LDS, is multiplied by B_r (256 x 256, L2-resident
-// planes) on the matrix cores, and only `out` (and, for the backward's weight gradient, optionally Z itself) is written.
+// aggregate Z_r (64 x 256 fp32) exists only as two f16 planes in LDS, is multiplied by B_r (256 x 256, f16 planes read
+// through L2) on the matrix cores, and only `out` (and, for the backward's weight gradient, optionally Z itself) is written.
 //
-// Work split inside the workgroup (8 waves, ONE workgroup per CU, persistent over its tiles):
-//   waves 0-3  "G"  gather.  Each owns a contiguous run of the tile's rows at the current level (the level's edges split
-//              four ways by count), streams their source rows -- 1 KiB per row, one float4 per lane, NB = 16 rows in flight per
-//              wave across row, level and tile boundaries -- accumulates in fp32, and when a row is complete scales it by a
-//              power of two (row maximum -> [2^14, 2^15)), splits it into an f16 value + f16 residual and writes both to the
-//              level's LDS buffer.
-//   waves 4-7  "M"  matrix.  Each owns 64 of the 256 output columns for all 64 rows: after the barrier that publishes level
-//              r's planes it runs 16 k-steps x 12 v_mfma_f32_32x32x16_f16 (value x value, value x residual, residual x value:
-//              fp32 accuracy, gemm_f16x3.hip) into a level-local product P, with B_r's fragments loaded straight from L2 into
-//              registers (fragment-major planes, one 1 KiB unit per wave load), then folds P * 2^-(e_row + e_B) into the
-//              running result.  After the last level: bias term, activation, store.
+// Work split inside the workgroup (16 waves, ONE workgroup per CU, persistent over its tiles; profiles/r5_fused_kernel.md):
+//   waves 0-7   "G"  gather.  Each owns a contiguous run of the tile's rows at the current level (the level's edges split
+//               eight ways by count, at row boundaries), streams their source rows -- 1 KiB per row, one float4 per lane, NB = 16
+//               rows in flight per wave across row, level and tile boundaries: a three-stage stream (plan entries of group
+//               s + 2, row loads of group s + 1, FMAs of group s) -- accumulates in fp32 group by group, and when a row is
+//               complete scales it by a power of two (row maximum -> [2^14, 2^15)), splits it into an f16 value + f16
+//               residual and writes both to the level's LDS buffer (+ the fp32 row to `zsave`).
+//   waves 8-15  "M"  matrix.  Each owns 32 of the 256 output columns for all 64 rows: after the barrier that publishes level
+//               r's planes it runs 16 k-steps x 6 v_mfma_f32_32x32x16_f16 (value x value, value x residual, residual x value:
+//               fp32 accuracy, gemm_f16x3.hip) into a level-local product P, with B_r's fragments loaded straight from L2 into
+//               registers (fragment-major planes, one 1 KiB unit per wave load; in assembly: scalar base + lane offset,
+//               counted waits), then folds P * 2^-(e_row + e_B) into the running result.  After the last level: bias term
+//               from the tile's rowsum rows, activation, store.
 //   One s_barrier per (tile, level): G has finished level q+1 in buffer (q+1)&1, M has finished reading level q-1 from it.
 //   The G waves never wait for memory at a barrier: loads stay in flight across it (only LDS traffic is drained).
-// The matrix work (3 x 2 x 64 x 256 x 256 flops per tile and level = 15 % of the launch at the config-5 shard) rides
-// under the HBM time of the gather (measured: profiles/r5_fused_agg.txt).
+// What binds (measured): the gather side alone runs at 6.4-7.1 TB/s algorithmic on the config-5 shard graph; the matrix
+// INSTRUCTIONS cost 0.5 ms of a 23.7 ms launch, the B planes' loads 2.5-3.9 ms -- they share the CU's L1 miss queue with the
+// gathered rows, and 4 MB of planes do not survive in a 4 MB L2 that the rows stream through (hit rate 0.17).
 //
-// Plan ("f-plan"): the edges of a tile reordered level-major -- segment (tile t, level r, row j) at f_ptr[(t R + r) 64 + j]
-// -- so that a level's edges of a tile are one contiguous run.  Built on the device from the plan's (row, level)-major CSR
-// (a tile's edges are the same contiguous range in both orders: the permutation is local to the tile).
+// Plan ("f-plan"): the edges of a tile reordered level-major inside the tile's own edge range -- 65 absolute edge offsets per
+// (launch slot, level) at f_ptr[(slot R + r) 65 ..] -- so that a level's edges of a tile are one contiguous run.  Launch slots
+// are the tiles sorted by descending edge count, dealt to the workgroups boustrophedon.  Built on the device (plan_kernel).
 //
 // Accuracy: Z_r rows carry one scale per (row, level) (256 elements), B_r one per (level, 32 output columns); error model
-// as gemm_f16x3.hip (block-relative 3 x 2^-22 per product term); the aggregation itself is plain fp32 FMA in edge order.
+// as gemm_f16x3.hip (block-relative 3 x 2^-22 per product term); the aggregation itself is plain fp32 FMA, edges of a row
+// summed in groups of 16.
 #include "gemm_x3_shared.hpp"
 
 #include <mutex>
