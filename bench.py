@@ -394,7 +394,9 @@ def fused_roofline(records, E_local, D, steps, rows_saved_bytes):
                    "the contraction as a separate GEMM that re-read a 16 GB intermediate): the fraction is of the same 8 TB/s peak "
                    "on the same edges x (8 + 4 D) bytes, so it is lower than the gather-only 0.78 while the step is shorter; "
                    "SG_FUSED=0 runs the unfused pair"}
-    for z, name in ((0, "forward (writes only the 256-wide output)"), (1, "data gradient (also writes the fp32 aggregates)")):
+    for z, name in ((0, "launches that write only their 256-wide output"),
+                    (1, "launches that also write the fp32 aggregates (the forward where the destination side is the smaller one, "
+                        "else the data gradient)")):
         c = [t for t, _, zz in recs if zz == z]
         if c:
             extra = rows_saved_bytes if z else 0

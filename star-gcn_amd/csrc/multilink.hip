@@ -150,6 +150,7 @@ inline size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 struct Dims {
   int64_t n_dst, n_src, nnz, D, U, ld, outw, RU;
   int R, order, stack;
+  bool saves_z;       // fused order: the forward writes the aggregates (see fused_saves_z)
 };
 
 int resolve_order(const sg_multilink_plan* p, int order) {
@@ -168,6 +169,13 @@ int fused_nt() {       // SG_FUSED_NT=1: gathered rows read non-temporally (meas
 bool has_fused(const sg_multilink_plan* p, int which) {
   return p->struct_bytes >= static_cast<int32_t>(offsetof(sg_multilink_plan, fused) + sizeof(p->fused)) &&
          p->fused[which].f_ptr && p->fused[which].f_idx && p->fused[which].f_w;
+}
+// Fused order: which R-expanded matrix feeds the weight gradient.  dW_r = dH_r^T x (dH = [A_r^T dpre]_r, n_src rows, written by
+// the data-gradient launch) = dpre^T Z_r (Z = [A_r x]_r, n_dst rows, written by the FORWARD launch): the one on the smaller node
+// side is 20 % smaller at the config-5 shard (16.4 against 20.5 GB) and so is its GEMM (K = 1 M against 1.25 M).
+bool fused_saves_z(const sg_multilink_plan* p) {
+  static const int mode = [] { const char* e = getenv("SG_FUSED_SAVEZ"); return e ? atoi(e) : -1; }();    // 0 / 1: never / always (A-B)
+  return mode < 0 ? p->n_dst < p->n_src : mode != 0;
 }
 // the order for these widths; AUTO prefers the fused kernel where the R-expanded matrix would cost HBM time
 int resolve_order2(const sg_multilink_plan* p, int order, int64_t in_dim, int64_t upl, int accum) {
@@ -208,6 +216,7 @@ int make_dims(Dims* d, const sg_multilink_plan* p, int64_t in_dim, int64_t upl, 
   }
   d->stack = accum == SG_ACCUM_STACK;
   d->RU = d->R * upl;
+  d->saves_z = d->order == SG_ORDER_FUSED && fused_saves_z(p);
   d->outw = d->stack ? d->RU : upl;
   const int64_t used = d->R * in_dim + d->R;
   // row pitch of the R-expanded matrices (Zext / dZ): every level block of a row is gathered / scattered as one burst of
@@ -233,10 +242,12 @@ Layout make_layout(const Dims& d, bool backward) {
     sc = sg_agg_fused_workspace_bytes(d.R);
     if (backward) {
       L.a = take(d.n_dst * d.outw * f);                                              // dpre
-      L.b = take(d.n_src * d.RU * f);                                                // dH (written by the fused data gradient)
-      L.c = take((d.RU * d.D + d.RU) * f);                                           // dWcat | dbcat
-      sc = max2(sc, max2(sg_seg_weighted_pool_workspace_bytes(1, d.n_src * d.R, d.nnz, d.U),
-                         max2(sg_gemm_f32_workspace_bytes(d.RU, d.D, d.n_src, 1), static_cast<size_t>(kDbParts) * d.RU * f)));
+      if (!d.saves_z) L.b = take(d.n_src * d.RU * f);                                // dH (written by the fused data gradient)
+      L.c = take((d.RU * d.D + d.RU) * f);                                           // dWcat | dbcat   (or dWext (U, R D) | dbcat)
+      sc = max2(sc, max2(d.saves_z ? 0 : sg_seg_weighted_pool_workspace_bytes(1, d.n_src * d.R, d.nnz, d.U),
+                         max2(d.saves_z ? sg_gemm_f32_workspace_bytes(d.U, d.R * d.D, d.n_dst, 1)
+                                        : sg_gemm_f32_workspace_bytes(d.RU, d.D, d.n_src, 1),
+                              static_cast<size_t>(kDbParts) * d.RU * f)));
     }
   } else if (d.order == SG_ORDER_TRANSFORM_FIRST) {
     L.wpack = take(d.RU * d.D * f);
@@ -365,7 +376,8 @@ SG_API size_t sg_multilink_agg_saved_bytes(const sg_multilink_plan* plan, int64_
                                            int order, int accum) {
   Dims d;
   if (make_dims(&d, plan, in_dim, units_per_level, order, accum) != SG_OK) return 0;
-  return d.order == SG_ORDER_AGGREGATE_FIRST ? static_cast<size_t>(d.n_dst) * d.ld * sizeof(float) : 0;   // (fused: nothing)
+  if (d.saves_z) return static_cast<size_t>(d.n_dst) * d.R * d.D * sizeof(float);       // fused, destination side smaller: Z
+  return d.order == SG_ORDER_AGGREGATE_FIRST ? static_cast<size_t>(d.n_dst) * d.ld * sizeof(float) : 0;
 }
 
 SG_API size_t sg_multilink_agg_workspace_bytes(const sg_multilink_plan* plan, int64_t in_dim, int64_t units_per_level,
@@ -397,8 +409,10 @@ SG_API int sg_multilink_agg_fwd_hip(float* out, void* saved, const float* x, con
     if (d.n_src == 0) return fail(SG_ERR_INVALID, "fused aggregation with edges but no source rows");
     if (biases && !plan->rowsum) return fail(SG_ERR_INVALID, "the fused order needs plan->rowsum for the bias term");
     const sg_fused_plan& fp = plan->fused[0];
-    return sg_agg_fused_hip(out, d.U, nullptr, 0, x, d.D, weights, d.D, 0, biases, plan->rowsum, fp.f_ptr, fp.f_idx, fp.f_w,
-                            fp.tile_order, d.n_dst, d.R, d.nnz, d.D, d.U, act, slope, fused_nt(), scratch, L.scratch_bytes, stream);
+    if (d.saves_z && !saved) return fail(SG_ERR_INVALID, "the fused order needs the `saved` buffer here (sg_multilink_agg_saved_bytes)");
+    return sg_agg_fused_hip(out, d.U, d.saves_z ? static_cast<float*>(saved) : nullptr, d.R * d.D, x, d.D, weights, d.D, 0, biases,
+                            plan->rowsum, fp.f_ptr, fp.f_idx, fp.f_w, fp.tile_order, d.n_dst, d.R, d.nnz, d.D, d.U, act, slope,
+                            fused_nt(), scratch, L.scratch_bytes, stream);
   }
 
   if (d.order == SG_ORDER_TRANSFORM_FIRST) {
@@ -475,6 +489,47 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
     float* dbcat = dwcat + d.RU * d.D;
     if (d.n_src == 0 || d.n_dst == 0) return fail(SG_ERR_INVALID, "fused aggregation with edges but no rows");
     if (want_b && !plan->rowsum) return fail(SG_ERR_INVALID, "the fused order needs plan->rowsum for the bias gradient");
+    if (d.saves_z) {      // the forward kept Z = [A_r x]_r: dWext (U, R D) = dpre^T Z; the data gradient writes nothing but dx
+      if (want_w && !saved) return fail(SG_ERR_INVALID, "fused backward needs the `saved` buffer of the forward");
+      if (dx) {
+        const sg_fused_plan& fp = plan->fused[1];
+        SG_TRY(sg_agg_fused_hip(dx, d.D, nullptr, 0, dpre, d.U, weights, d.D, 1, nullptr, nullptr, fp.f_ptr, fp.f_idx, fp.f_w,
+                                fp.tile_order, d.n_src, d.R, d.nnz, d.U, d.D, SG_ACT_NONE, 0.f, fused_nt(), scratch,
+                                L.scratch_bytes, stream));
+      }
+      float* dwext = dwcat;
+      if (want_w)
+        SG_TRY(sg_gemm_f32_hip(dwext, d.R * d.D, dpre, d.U, 1, static_cast<const float*>(saved), d.R * d.D, 0, d.U, d.R * d.D,
+                               d.n_dst, nullptr, SG_ACT_NONE, 0.f, 0, scratch, L.scratch_bytes, stream));
+      if (want_b) {
+        float* part = reinterpret_cast<float*>(scratch);
+        const int P = static_cast<int>(d.n_dst < kDbParts ? d.n_dst : kDbParts);
+        const dim3 grid(static_cast<unsigned>(P), static_cast<unsigned>((d.U + 255) / 256));
+        if (d.R <= 16)
+          hipLaunchKernelGGL(bias_grad_partial_kernel<16>, grid, dim3(256), 0, st, part, plan->rowsum, dpre,
+                             static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U));
+        else
+          hipLaunchKernelGGL(bias_grad_partial_kernel<SG_MAX_LINKS>, grid, dim3(256), 0, st, part, plan->rowsum, dpre,
+                             static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U));
+        hipLaunchKernelGGL(bias_grad_final_kernel, dim3(blocks_for(d.RU)), dim3(256), 0, st, dbcat, part, P, static_cast<int>(d.RU));
+        SG_TRY(check_launch("bias_grad kernels"));
+      }
+      if (want_w) {
+        MutPtrTable nodb;
+        for (int r = 0; r < SG_MAX_LINKS; ++r) nodb.p[r] = nullptr;
+        hipLaunchKernelGGL(unpack_ext_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, dw, nodb, dwext, d.R,
+                           static_cast<int>(d.U), static_cast<int>(d.D), static_cast<int>(d.R * d.D), 0);
+        SG_TRY(check_launch("unpack_ext_kernel"));
+      }
+      if (want_b) {
+        MutPtrTable nodw;
+        for (int r = 0; r < SG_MAX_LINKS; ++r) nodw.p[r] = nullptr;
+        hipLaunchKernelGGL(unpack_cat_kernel, dim3(blocks_for(d.RU)), dim3(256), 0, st, nodw, db, static_cast<const float*>(nullptr),
+                           dbcat, d.R, static_cast<int>(d.U), static_cast<int>(d.D));
+        SG_TRY(check_launch("unpack_cat_kernel"));
+      }
+      return SG_OK;
+    }
     if (dx) {
       const sg_fused_plan& fp = plan->fused[1];
       SG_TRY(sg_agg_fused_hip(dx, d.D, want_w ? dh : nullptr, d.RU, dpre, d.U, weights, d.D, 1, nullptr, nullptr, fp.f_ptr,

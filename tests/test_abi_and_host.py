@@ -168,9 +168,15 @@ def test_fused_order_routing_and_sizes_are_host_decisions(monkeypatch):
     assert lib.sg_multilink_agg_workspace_bytes(ref, 256, 256, 3, 0, 1) == 0      # no level-major edge orders attached: invalid
     for which in range(2):                 # (size queries never dereference them)
         st.fused[which].f_ptr = st.fused[which].f_idx = st.fused[which].f_w = 4096
+    # destination side smaller: the forward keeps Z = [A_r x]_r (n_dst x R x 256) for dW = dpre^T Z, the backward writes no dH
+    assert lib.sg_multilink_agg_saved_bytes(ref, 256, 256, 3, 0) == 1000 * 4 * 256 * 4
+    wb = lib.sg_multilink_agg_workspace_bytes(ref, 256, 256, 3, 0, 1)
+    assert (1000 * 256 + 4 * 256 * 256) * 4 <= wb < (1000 * 256 + 3000 * 4 * 256) * 4 and wb >= lib.sg_agg_fused_workspace_bytes(4)
+    # source side smaller: nothing saved by the forward, the data-gradient launch writes dH (n_src x R x 256) into the workspace
+    st.n_dst, st.n_src = 3000, 1000
     assert lib.sg_multilink_agg_saved_bytes(ref, 256, 256, 3, 0) == 0
     wb = lib.sg_multilink_agg_workspace_bytes(ref, 256, 256, 3, 0, 1)
-    assert wb >= (1000 * 256 + 3000 * 4 * 256 + 4 * 256 * 256) * 4 and wb >= lib.sg_agg_fused_workspace_bytes(4)
+    assert wb >= (3000 * 256 + 1000 * 4 * 256 + 4 * 256 * 256) * 4
     assert lib.sg_multilink_agg_workspace_bytes(ref, 256, 256, 3, 0, 0) >= lib.sg_agg_fused_workspace_bytes(4)
     assert lib.sg_agg_fused_workspace_bytes(16) >= 16 * 256 * 256 * 4            # two f16 planes of sixteen 256 x 256 matrices
     assert lib.sg_agg_fused_tiles(0) == 0 and lib.sg_agg_fused_tiles(64) == 1 and lib.sg_agg_fused_tiles(65) == 2
