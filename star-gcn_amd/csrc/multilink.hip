@@ -100,39 +100,56 @@ __global__ void fill_rowsum_kernel(float* __restrict__ zext, const float* __rest
 }
 
 // db[r, u] = sum_i rowsum[i, r] * dpre[i, u]  -- the bias gradient of the fused order (= the column sums of dH_r without reading
-// the 16-20 GB of dH): pass 1, workgroup b sums rows b, b + P, ... into part[b][r][u] (one column per thread, R running sums in
-// registers, four rows in flight); pass 2 adds the P partials in order.  Bandwidth-bound on dpre (1.3 GB at the config-5 shard:
-// 0.3 ms where the 16 x 256 x n product on the exact-fp32 GEMM took 1 ms); deterministic.
+// the 16-20 GB of dH).  Pass 1: workgroup b (1024 threads = 4 row groups x 256 columns) owns a contiguous block of rows; 64 rows
+// of rowsum at a time go through LDS (read back as broadcasts), every thread keeps R running sums for its column over its
+// group's rows, the four groups are added through LDS and part[b][r][u] is written.  Pass 2 adds the P partials in order.
+// Bandwidth-bound on dpre (1.3 GB at the config-5 shard); deterministic.
 constexpr int kDbParts = 512;
 template <int RMAX>
-__global__ __launch_bounds__(256) void bias_grad_partial_kernel(float* __restrict__ part, const float* __restrict__ rowsum,
-                                                                 const float* __restrict__ dpre, long long n, int R, int U) {
-  const int u = blockIdx.y * 256 + threadIdx.x;
+__global__ __launch_bounds__(1024) void bias_grad_partial_kernel(float* __restrict__ part, const float* __restrict__ rowsum,
+                                                                  const float* __restrict__ dpre, long long n, int R, int U) {
+  __shared__ float s_rs[64 * RMAX];
+  __shared__ float s_red[3][256];
+  const int t = threadIdx.x, grp = t >> 8, col = t & 255;
+  const int u = blockIdx.y * 256 + col;
   const int b = blockIdx.x, P = gridDim.x;
+  const long long chunk = (n + P - 1) / P;
+  const long long r_lo = b * chunk, r_hi = (r_lo + chunk < n) ? r_lo + chunk : n;
   float acc[RMAX];
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) acc[r] = 0.f;
-  if (u < U) {
-    long long i = b;
-    for (; i + 3ll * P < n; i += 4ll * P) {
-      float g[4];
+  for (long long base = r_lo; base < r_hi; base += 64) {
+    const int rows = static_cast<int>((r_hi - base < 64) ? r_hi - base : 64);
+    __syncthreads();
+    for (int e = t; e < rows * R; e += 1024) s_rs[(e / R) * RMAX + (e % R)] = rowsum[base * R + e];
+    __syncthreads();
+    if (u < U) {
+      for (int j = grp; j < rows; j += 16) {          // rows j, j + 4, j + 8, j + 12 of the batch in flight
+        float g[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) g[q] = dpre[(i + static_cast<long long>(q) * P) * U + u];
+        for (int q = 0; q < 4; ++q) g[q] = (j + 4 * q < rows) ? dpre[(base + j + 4 * q) * U + u] : 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float* rs = rowsum + (i + static_cast<long long>(q) * P) * R;
+        for (int q = 0; q < 4; ++q) {
+          const float* rs = s_rs + ((j + 4 * q < rows) ? (j + 4 * q) : 0) * RMAX;
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) if (r < R) acc[r] = fmaf(rs[r], g[q], acc[r]);
+          for (int r = 0; r < RMAX; ++r) acc[r] = fmaf(rs[r], g[q], acc[r]);
+        }
       }
     }
-    for (; i < n; i += P) {
-      const float g = dpre[i * U + u];
-      const float* rs = rowsum + i * R;
+  }
+  // the four row groups, in order
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) if (r < R) acc[r] = fmaf(rs[r], g, acc[r]);
+  for (int r = 0; r < RMAX; ++r) {
+    if (r < R) {          // (uniform)
+      __syncthreads();
+      if (grp > 0) s_red[grp - 1][col] = acc[r];
+      __syncthreads();
+      if (grp == 0 && u < U) {
+        float v = acc[r];
+        v += s_red[0][col]; v += s_red[1][col]; v += s_red[2][col];
+        part[(static_cast<long long>(b) * R + r) * U + u] = v;
+      }
     }
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) if (r < R) part[(static_cast<long long>(b) * R + r) * U + u] = acc[r];
   }
 }
 __global__ void bias_grad_final_kernel(float* __restrict__ db, const float* __restrict__ part, int P, int RU) {
@@ -506,12 +523,12 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
         const int P = static_cast<int>(d.n_dst < kDbParts ? d.n_dst : kDbParts);
         const dim3 grid(static_cast<unsigned>(P), static_cast<unsigned>((d.U + 255) / 256));
         if (d.R <= 16)
-          hipLaunchKernelGGL(bias_grad_partial_kernel<16>, grid, dim3(256), 0, st, part, plan->rowsum, dpre,
+          hipLaunchKernelGGL(bias_grad_partial_kernel<16>, grid, dim3(1024), 0, st, part, plan->rowsum, dpre,
                              static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U));
         else
-          hipLaunchKernelGGL(bias_grad_partial_kernel<SG_MAX_LINKS>, grid, dim3(256), 0, st, part, plan->rowsum, dpre,
+          hipLaunchKernelGGL(bias_grad_partial_kernel<SG_MAX_LINKS>, grid, dim3(1024), 0, st, part, plan->rowsum, dpre,
                              static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U));
-        hipLaunchKernelGGL(bias_grad_final_kernel, dim3(blocks_for(d.RU)), dim3(256), 0, st, dbcat, part, P, static_cast<int>(d.RU));
+        hipLaunchKernelGGL(bias_grad_final_kernel, dim3(static_cast<unsigned>((d.RU + 63) / 64)), dim3(64), 0, st, dbcat, part, P, static_cast<int>(d.RU));
         SG_TRY(check_launch("bias_grad kernels"));
       }
       if (want_w) {
@@ -549,12 +566,12 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
       const int P = static_cast<int>(d.n_dst < kDbParts ? d.n_dst : kDbParts);
       const dim3 grid(static_cast<unsigned>(P), static_cast<unsigned>((d.U + 255) / 256));
       if (d.R <= 16)
-        hipLaunchKernelGGL(bias_grad_partial_kernel<16>, grid, dim3(256), 0, st, part, plan->rowsum, dpre,
+        hipLaunchKernelGGL(bias_grad_partial_kernel<16>, grid, dim3(1024), 0, st, part, plan->rowsum, dpre,
                            static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U));
       else
-        hipLaunchKernelGGL(bias_grad_partial_kernel<SG_MAX_LINKS>, grid, dim3(256), 0, st, part, plan->rowsum, dpre,
+        hipLaunchKernelGGL(bias_grad_partial_kernel<SG_MAX_LINKS>, grid, dim3(1024), 0, st, part, plan->rowsum, dpre,
                            static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U));
-      hipLaunchKernelGGL(bias_grad_final_kernel, dim3(blocks_for(d.RU)), dim3(256), 0, st, dbcat, part, P, static_cast<int>(d.RU));
+      hipLaunchKernelGGL(bias_grad_final_kernel, dim3(static_cast<unsigned>((d.RU + 63) / 64)), dim3(64), 0, st, dbcat, part, P, static_cast<int>(d.RU));
       SG_TRY(check_launch("bias_grad kernels"));
     }
     if (want_w || want_b) {
