@@ -296,7 +296,8 @@ def graph_replay(step, dev, steps):
         for _ in range(2):
             step()
     torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
+    import star_gcn_amd.dist as sgdist
+    sgdist.quiesce_for_capture(dev)     # the RCCL watchdog must have retired the warm-up collectives before capture begins
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         loss = step()

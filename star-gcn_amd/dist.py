@@ -83,6 +83,21 @@ def comm_stream(device):
     return s
 
 
+def quiesce_for_capture(device=None, settle_s=0.5):
+    """Call right before a step with RCCL collectives is captured into a hipGraph.  torch's RCCL watchdog thread polls the
+    completion events of the collectives enqueued so far (eagerly: warm-up steps) about every 100 ms and retires them; HIP
+    answers hipEventQuery with hipErrorCapturedEvent when the event's stream has MEANWHILE entered capture, which the
+    watchdog turns into a process abort.  A capture that begins inside that window therefore dies about once in ten runs.
+    Drain the device, then give the watchdog time to retire everything that has finished (SG_CAPTURE_SETTLE_S overrides the wait).  No-op without RCCL."""
+    if device is not None:
+        torch.cuda.synchronize(device)
+    elif torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if _active() and dist.get_backend() == "nccl":
+        import time
+        time.sleep(float(os.environ.get("SG_CAPTURE_SETTLE_S", settle_s)))
+
+
 def _wait_on(cur, done):
     """make stream `cur` wait for event `done`; with statistics on, bracket the wait with two events on `cur` whose
     distance is the time `cur` sat blocked (0 when the collective had already finished)"""
