@@ -376,6 +376,13 @@ def gather_roofline(timeline, E_local, D, steps):
             "_classes": {k: (n, tt / n, ne / n) for k, (n, tt, ne) in classes.items()}}
 
 
+def fused_saved_rows(nu, ni):
+    """Rows of the R-expanded matrix a fused launch saves for the weight gradient (multilink.hip, fused_saves_z): by default
+    always the smaller node side's (the forward saves Z where it aggregates INTO the smaller side, the data gradient saves dH
+    where its transposed launch does); with SG_FUSED_SAVEZ=0/1 forced, one launch of each size -> the mean."""
+    return min(nu, ni) if os.environ.get("SG_FUSED_SAVEZ") not in ("0", "1") else (nu + ni) / 2
+
+
 def fused_roofline(records, E_local, D, steps, rows_saved_bytes):
     """HIP-event times of the fused aggregate -> contract launches (csrc/agg_fused.hip) -> algorithmic rate.  One launch is
     one whole aggregation (every edge visited once: idx + support + one fp32 row = 8 + 4 D bytes) AND its
@@ -519,7 +526,7 @@ def hbm_leg(args, dev):
            "graph_gen_s": round(t_gen, 2), "plan_build_s": round(t_plan, 2),
            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
            "smallest_gathered_matrix_mb": src_small // 2 ** 20}
-    froof = fused_roofline(getattr(timed_steps, "last_fused", []), E, D, args.hbm_steps, max(nu, ni) * R * D * 4)
+    froof = fused_roofline(getattr(timed_steps, "last_fused", []), E, D, args.hbm_steps, fused_saved_rows(nu, ni) * R * D * 4)
     if froof:       # the step ran the fused order (the default at this size): that kernel is the dominant one
         rec = profile_record("hbm-config5-shard-fused:%d" % D, "agg_fused.hip")
         live = rec and not rec.get("stale")
@@ -637,7 +644,7 @@ def run_config5(args, dev, dist_on, world, rank, backend):
     if roof:
         roof.update(bound="hbm", peak=HBM_PEAK / 1e9, frac=roof["achieved"] * 1e9 / HBM_PEAK, traffic=None)
         roof.pop("_classes", None)
-    froof = fused_roofline(getattr(timed_steps, "last_fused", []), E_local, D, args.steps, max(nu, ni) * R * D * 4)
+    froof = fused_roofline(getattr(timed_steps, "last_fused", []), E_local, D, args.steps, fused_saved_rows(nu, ni) * R * D * 4)
     if froof:      # rank 0's fused aggregate -> contract launches (the default order at this size)
         froof.update(bound="hbm", peak=HBM_PEAK / 1e9, frac=froof["achieved"] * 1e9 / HBM_PEAK, traffic=None)
         if roof:
