@@ -10,20 +10,26 @@
 // through L2) on the matrix cores, and only `out` (and, for the backward's weight gradient, optionally Z itself) is written.
 //
 // Work split inside the workgroup (16 waves, ONE workgroup per CU, persistent over its tiles; profiles/r5_fused_kernel.md):
-//   waves 0-7   "G"  gather.  Each owns a contiguous run of the tile's rows at the current level (the level's edges split
-//               eight ways by count, at row boundaries), streams their source rows -- 1 KiB per row, one float4 per lane, NB = 16
-//               rows in flight per wave across row, level and tile boundaries: a three-stage stream (plan entries of group
-//               s + 2, row loads of group s + 1, FMAs of group s) -- accumulates in fp32 group by group, and when a row is
-//               complete scales it by a power of two (row maximum -> [2^14, 2^15)), splits it into an f16 value + f16
-//               residual and writes both to the level's LDS buffer (+ the fp32 row to `zsave`).
+//   waves 0-7   "G"  gather.  Each owns one EIGHTH of the tile's edges at the current level, cut at any edge (a hub row is
+//               summed in pieces by several waves; with cuts at row boundaries the busiest wave of a (tile, level) had 1.45 x
+//               / 2.2 x its even share on the config-5 shard graph, into users / into items), streams their source rows --
+//               1 KiB per row, one float4 per lane, NB = 16 rows in flight per wave across row, level and tile boundaries: a
+//               three-stage stream (plan entries of group s + 2, row loads of group s + 1, FMAs of group s) -- accumulates in
+//               fp32 group by group, and when a row is complete scales it by a power of two (row maximum -> [2^14, 2^15)),
+//               splits it into an f16 value + f16 residual and writes both to the level's LDS buffer (+ the fp32 row to
+//               `zsave`).  A row cut between waves: every wave but the one in whose share the row ends leaves its piece as an
+//               fp32 partial row in LDS (one slot per wave: at most one row runs on past a share's end), and the last one adds
+//               them to its own piece between the item's two barriers.
 //   waves 8-15  "M"  matrix.  Each owns 32 of the 256 output columns for all 64 rows: after the barrier that publishes level
 //               r's planes it runs 16 k-steps x 6 v_mfma_f32_32x32x16_f16 (value x value, value x residual, residual x value:
 //               fp32 accuracy, gemm_f16x3.hip) into a level-local product P, with B_r's fragments loaded straight from L2 into
 //               registers (fragment-major planes, one 1 KiB unit per wave load; in assembly: scalar base + lane offset,
 //               counted waits), then folds P * 2^-(e_row + e_B) into the running result.  After the last level: bias term
 //               from the tile's rowsum rows, activation, store.
-//   One s_barrier per (tile, level): G has finished level q+1 in buffer (q+1)&1, M has finished reading level q-1 from it.
-//   The G waves never wait for memory at a barrier: loads stay in flight across it (only LDS traffic is drained).
+//   Two s_barriers per (tile, level), back to back for the M waves: at the first every piece of level q+1 is in LDS (buffer
+//   (q+1)&1 or a partial slot) and M has finished reading level q-1 from that buffer; between the two the cut rows are put
+//   together; the second publishes the level.  The G waves never wait for memory at a barrier: loads stay in flight across
+//   it (only LDS traffic is drained).
 // What binds (measured): the gather side alone runs at 6.4-7.1 TB/s algorithmic on the config-5 shard graph; the matrix
 // INSTRUCTIONS cost 0.5 ms of a 23.7 ms launch, the B planes' loads 2.5-3.9 ms -- they share the CU's L1 miss queue with the
 // gathered rows, and 4 MB of planes do not survive in a 4 MB L2 that the rows stream through (hit rate 0.17).
@@ -97,6 +103,9 @@ constexpr int NJB = ND / 32;              // 32-column blocks of the output
 #ifndef SG_FUSED_MW
 #define SG_FUSED_MW 8
 #endif
+#ifndef SG_FUSED_EVEN
+#define SG_FUSED_EVEN 1                   // 0: a level's edges go to the gather waves at ROW boundaries (the first version: a hub row is one wave's)
+#endif
 #ifndef SG_FUSED_ADB
 #define SG_FUSED_ADB 0                    // 1: the aggregate's fragments double-buffered in registers (fits only with 4 + 4 waves)
 #endif
@@ -108,7 +117,11 @@ constexpr int BRING = SG_FUSED_BRING;     // B fragment sets in flight per M wav
 constexpr int ZROW = KD * 2 + 16;         // bytes per row and plane in LDS: 528 = 132 words -> rows 4 banks apart
 constexpr int ZPLANE = TM * ZROW;
 constexpr int ZBUF = 2 * ZPLANE;          // value plane, residual plane
-constexpr int SMEM = 2 * ZBUF + 2 * TM * 4 + 2 * TM * SG_MAX_LINKS * 4 + 4 * TM * 4;
+constexpr int SMEM_BASE = 2 * ZBUF + 2 * TM * 4 + 2 * TM * SG_MAX_LINKS * 4 + 4 * TM * 4;
+constexpr int SMEM = SMEM_BASE + (SG_FUSED_EVEN == 1 ? GW * 1024 : 0);       // + one fp32 partial row per gather wave
+#if SG_FUSED_EVEN == 1 && SG_FUSED_DIRECT
+#error "SG_FUSED_EVEN is not written for SG_FUSED_DIRECT"
+#endif
 
 struct Args {
   const int32_t* f_ptr;
@@ -161,6 +174,7 @@ struct Ctx {                    // one (item = tile x level, G wave): the rows a
   int e_lo, e_hi, ng;           // my edges; groups of NB (at least one, possibly all padding)
   int tile, r, it;              // tile = launch slot of the tile; it = ordinal of the item in this workgroup's sequence
   int eb;                       // exponent of the level's B planes (SG_FUSED_DIRECT)
+  int split;                    // SG_FUSED_EVEN: tail row | head row << 8 | first wave of the head row << 16 (row 64 = none)
 };
 
 template <bool ZSAVE, bool NT>
@@ -213,7 +227,7 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       // real copies (not aliases of the F registers): the next item's pointers are loaded into those while this context lives
       asm volatile("v_mov_b32 %0, %1" : "=v"(c.pv) : "v"(pv));
       asm volatile("v_mov_b32 %0, %1" : "=v"(c.pn) : "v"(pn));
-      c.tile = slot; c.r = r; c.it = it;
+      c.tile = slot; c.r = r; c.it = it; c.split = 64 | (64 << 8);
       c.eb = SG_FUSED_DIRECT ? static_cast<int>(*((f16x3::cst_int*)(a.wexp) + r)) : 0;
       const int p0 = __builtin_amdgcn_readlane(pv, 0), pE = __builtin_amdgcn_readlane(pn, 63);
       const long long total = pE - p0;
@@ -222,6 +236,26 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
 #pragma unroll
         for (int q = 1; q < GW; ++q) wj += (pv >= p0 + static_cast<int>(total * q / GW)) ? 1 : 0;
       }
+#if SG_FUSED_EVEN == 1
+      // the level's edges cut into GW equal shares at ANY edge: a row that straddles a cut is summed in pieces.  A piece whose row
+      // goes on into the next share ("tail": my last row) is left as an fp32 partial row in LDS; the wave in whose share the row ENDS
+      // ("head": its first row) adds the partials of the waves before it between the item's two barriers and emits the row.
+      const int c_lo = p0 + static_cast<int>(total * gw / GW), c_hi = p0 + static_cast<int>(total * (gw + 1) / GW);
+      // (Measured, profiles/r5_fused_kernel.md section 6: leaving rows of <= 4 / 16 / 64 edges whole changes nothing or loses.)
+      const int pe = min(pn, c_hi), ps = max(pv, c_lo);
+      const bool have = pe > ps;
+      const unsigned long long nonempty = __ballot(pn > pv);
+      c.rows = __ballot(have);
+      c.empt = __ballot(wj == gw) & ~nonempty;
+      const unsigned long long tailm = __ballot(have && pn > c_hi);
+      const unsigned long long headm = __ballot(have && pv < c_lo && pn <= c_hi);
+      const int tj = tailm ? __ffsll(static_cast<long long>(tailm)) - 1 : 64;
+      const int hj = headm ? __ffsll(static_cast<long long>(headm)) - 1 : 64;
+      const int hu = headm ? __builtin_amdgcn_readlane(wj, hj & 63) : 0;
+      c.split = tj | (hj << 8) | (hu << 16);
+      asm volatile("v_mov_b32 %0, %1" : "=v"(c.pn) : "v"(pe));
+      c.e_lo = c_lo; c.e_hi = c_hi;
+#else
       const unsigned long long mine = __ballot(wj == gw);
       const unsigned long long nonempty = __ballot(pn > pv);
       c.rows = mine & nonempty;
@@ -234,7 +268,8 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       } else {
         c.e_lo = 0; c.e_hi = 0;
       }
-      if (it >= n_items) { c.rows = 0ull; c.empt = 0ull; c.e_hi = c.e_lo; }      // past the end of the stream: padding only
+#endif
+      if (it >= n_items) { c.rows = 0ull; c.empt = 0ull; c.e_hi = c.e_lo; c.split = 64 | (64 << 8); }      // past the end of the stream: padding only
       c.ng = max(1, (c.e_hi - c.e_lo + NB - 1) / NB);
       return c;
     };
@@ -392,6 +427,7 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
     advance_m();
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 hacc = {0.f, 0.f, 0.f, 0.f};                   // SG_FUSED_EVEN: my piece of the head row
     unsigned long long rem = cC.rows;                    // my rows of the consume item that are still open
 
     for (;;) {
@@ -422,7 +458,13 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
           const int j = __ffsll(static_cast<long long>(rem)) - 1;
           rem &= rem - 1ull;
           acc += part;
+#if SG_FUSED_EVEN == 1
+          if (j == (cC.split & 0xff)) *reinterpret_cast<f32x4*>(smem + SMEM_BASE + gw * 1024 + lane * 16) = acc;
+          else if (j == ((cC.split >> 8) & 0xff)) hacc = acc;
+          else emit(cC, j, acc);
+#else
           emit(cC, j, acc);
+#endif
           acc = f32x4{0.f, 0.f, 0.f, 0.f};
           part = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -439,6 +481,20 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#if SG_FUSED_EVEN == 1
+        {     // every piece of the item is in LDS: the rows that END in my share but began in an earlier one
+          const int hj = (cC.split >> 8) & 0xff;
+          if (hj < 64) {
+            f32x4 sum = hacc;
+            for (int v = (cC.split >> 16) & 0xff; v < gw; ++v)
+              sum += *reinterpret_cast<const f32x4*>(smem + SMEM_BASE + v * 1024 + lane * 16);
+            emit(cC, hj, sum);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+#endif
       }
       if (last) break;
       // shift the stages
@@ -522,6 +578,9 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       for (int p = 0; p < BRING - 1; ++p) load_b(bF[p], r, p / KS, p % KS);      // B does not depend on the gather: requested ahead of the barrier
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                         // item `it` is published
+#if SG_FUSED_EVEN == 1
+      __builtin_amdgcn_s_barrier();                         // ... after the rows cut between gather waves are put together
+#endif
       asm volatile("" ::: "memory");
       const int buf = it & 1;
       if (__builtin_expect(a.ablate & 1, 0)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); continue; }

@@ -223,6 +223,48 @@ def ml10m_forward():
 
 
 
+def imbalance(nu=1_250_000, ni=1_000_000, ne=125_000_000, R=16, G=256, GW=8):
+    """How evenly does the fused kernel's work split?  Per (tile, level) the edges go to the 8 gather waves at ROW boundaries (a
+    row belongs to the wave whose share holds its first edge): a hub row is one wave's.  Prints, per direction of the config-5
+    shard graph: sum over items of the busiest wave's edges against edges / 8 (1.0 = even), and the same per workgroup after
+    the descending-work boustrophedon dealing (the launch ends with the slowest workgroup)."""
+    from star_gcn_amd.device_graph import synthetic_device_graph
+    dev = torch.device("cuda")
+    dg = synthetic_device_graph(nu, ni, ne, R, dev, seed=5)
+    for dst in (dg.U, dg.I):
+        plan = dg.plan(dst)
+        cnt = (plan.c_indptr[1:] - plan.c_indptr[:-1]).view(plan.n_dst, R).long()
+        pad = (-plan.n_dst) % 64
+        cnt = torch.cat([cnt, cnt.new_zeros(pad, R)]).view(-1, 64, R).permute(0, 2, 1).contiguous()      # (T, R, 64)
+        T = cnt.shape[0]
+        total = cnt.sum(2)                                                                              # (T, R)
+        pre = cnt.cumsum(2) - cnt
+        wj = torch.zeros_like(cnt)
+        for q in range(1, GW):
+            wj += (pre >= (total * q // GW).unsqueeze(2)).long()
+        wj = torch.where(total.unsqueeze(2) > 0, wj, torch.zeros_like(wj))
+        loads = torch.zeros(T, R, GW, dtype=torch.long, device=dev).scatter_add_(2, wj, cnt)
+        busiest = loads.max(2).values                                                                   # (T, R)
+        even = (total + GW - 1) // GW
+        tile_edges = total.sum(1)
+        order = torch.argsort(tile_edges, descending=True)
+        slot = torch.arange(T, device=dev)
+        ti, pos = slot // G, slot % G
+        wg = torch.where(ti % 2 == 1, G - 1 - pos, pos)
+        wg_of_tile = torch.empty(T, dtype=torch.long, device=dev)
+        wg_of_tile[order] = wg
+        per_wg_busy = torch.zeros(G, dtype=torch.long, device=dev).scatter_add_(0, wg_of_tile, busiest.sum(1))
+        per_wg_even = torch.zeros(G, dtype=torch.long, device=dev).scatter_add_(0, wg_of_tile, even.sum(1))
+        per_wg_edges = torch.zeros(G, dtype=torch.long, device=dev).scatter_add_(0, wg_of_tile, tile_edges)
+        big = (cnt.max(2).values > even * 2).float().mean()
+        print("into %-5s: %d tiles; busiest-wave edges / (edges / 8) over all items %.3f; per workgroup: edges max/mean %.3f, "
+              "busiest-wave sum max / even mean %.3f (mean / even mean %.3f); items whose largest row exceeds 2 x its even share: %.3f; "
+              "largest (row, level) %d edges" % (
+                  dst, T, float(busiest.sum()) / float(even.sum()), float(per_wg_edges.max()) / float(per_wg_edges.float().mean()),
+                  float(per_wg_busy.max()) / float(per_wg_even.float().mean()), float(per_wg_busy.float().mean()) / float(per_wg_even.float().mean()),
+                  float(big), int(cnt.max())), flush=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "check":
         check()
@@ -230,6 +272,8 @@ if __name__ == "__main__":
         bench_graph()
     elif sys.argv[1] == "ml10m":
         ml10m_forward()
+    elif sys.argv[1] == "imbalance":
+        imbalance()
     else:
         a = [int(v) for v in sys.argv[2:6]] if len(sys.argv) >= 6 else [1_000_000, 1_250_000, 125_000_000, 16]
         time_case(*a)
