@@ -9,19 +9,20 @@
 // aggregate Z_r (64 x 256 fp32) exists only as two f16 planes in LDS, is multiplied by B_r (256 x 256, f16 planes read
 // through L2) on the matrix cores, and only `out` (and, for the backward's weight gradient, optionally Z itself) is written.
 //
-// Work split inside the workgroup (16 waves, ONE workgroup per CU, persistent over its tiles; profiles/r5_fused_kernel.md):
+// Work split inside the workgroup (12 waves = 3 per SIMD, 168 registers each; ONE workgroup per CU, persistent over its tiles;
+// profiles/r5_fused_kernel.md -- 8 + 8 waves with 16 rows in flight per gather wave, the first version, is 1.4 % slower):
 //   waves 0-7   "G"  gather.  Each owns one EIGHTH of the tile's edges at the current level, cut at any edge (a hub row is
 //               summed in pieces by several waves; with cuts at row boundaries the busiest wave of a (tile, level) had 1.45 x
 //               / 2.2 x its even share on the config-5 shard graph, into users / into items), streams their source rows --
-//               1 KiB per row, one float4 per lane, NB = 16 rows in flight per wave across row, level and tile boundaries: a
+//               1 KiB per row, one float4 per lane, NB = 32 rows in flight per wave across row, level and tile boundaries: a
 //               three-stage stream (plan entries of group s + 2, row loads of group s + 1, FMAs of group s) -- accumulates in
 //               fp32 group by group, and when a row is complete scales it by a power of two (row maximum -> [2^14, 2^15)),
 //               splits it into an f16 value + f16 residual and writes both to the level's LDS buffer (+ the fp32 row to
 //               `zsave`).  A row cut between waves: every wave but the one in whose share the row ends leaves its piece as an
 //               fp32 partial row in LDS (one slot per wave: at most one row runs on past a share's end), and the last one adds
 //               them to its own piece between the item's two barriers.
-//   waves 8-15  "M"  matrix.  Each owns 32 of the 256 output columns for all 64 rows: after the barrier that publishes level
-//               r's planes it runs 16 k-steps x 6 v_mfma_f32_32x32x16_f16 (value x value, value x residual, residual x value:
+//   waves 8-11  "M"  matrix.  Each owns 64 of the 256 output columns (two 32-column blocks, one after the other) for all 64
+//               rows: after the barrier that publishes level r's planes it runs, per block, 16 k-steps x 6 v_mfma_f32_32x32x16_f16 (value x value, value x residual, residual x value:
 //               fp32 accuracy, gemm_f16x3.hip) into a level-local product P, with B_r's fragments loaded straight from L2 into
 //               registers (fragment-major planes, one 1 KiB unit per wave load; in assembly: scalar base + lane offset,
 //               counted waits), then folds P * 2^-(e_row + e_B) into the running result.  After the last level: bias term
@@ -40,7 +41,7 @@
 //
 // Accuracy: Z_r rows carry one scale per (row, level) (256 elements), B_r one per (level, 32 output columns); error model
 // as gemm_f16x3.hip (block-relative 3 x 2^-22 per product term); the aggregation itself is plain fp32 FMA, edges of a row
-// summed in groups of 16.
+// summed in groups of NB = 32.
 #include "gemm_x3_shared.hpp"
 
 #include <mutex>
@@ -95,13 +96,13 @@ constexpr int NJB = ND / 32;              // 32-column blocks of the output
 #define SG_FUSED_GW 8
 #endif
 #ifndef SG_FUSED_NB
-#define SG_FUSED_NB 16
+#define SG_FUSED_NB 32
 #endif
 #ifndef SG_FUSED_BRING
 #define SG_FUSED_BRING (SG_FUSED_DIRECT ? 7 : 3)
 #endif
 #ifndef SG_FUSED_MW
-#define SG_FUSED_MW 8
+#define SG_FUSED_MW 4
 #endif
 #ifndef SG_FUSED_EVEN
 #define SG_FUSED_EVEN 1                   // 0: a level's edges go to the gather waves at ROW boundaries (the first version: a hub row is one wave's)

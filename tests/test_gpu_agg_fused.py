@@ -32,11 +32,40 @@ CASES = [  # n_dst, n_src, nnz, R
 @pytest.mark.parametrize("n_dst,n_src,nnz,R", CASES)
 @pytest.mark.parametrize("act", ["leaky", None])
 def test_fused_order_matches_reference_order(n_dst, n_src, nnz, R, act):
-    from star_gcn_amd import functional as F
-    from star_gcn_amd.plan import MultiLinkPlan
     rng = np.random.default_rng(n_dst + nnz + R)
     eps, ips, sps = make_multilink(rng, n_dst, n_src, nnz, R)
-    g = torch.Generator().manual_seed(R + nnz)
+    _check_against_reference_order(eps, ips, sps, n_dst, n_src, R, act, seed=R + nnz)
+
+
+def test_fused_order_rows_cut_between_gather_waves():
+    """A level's edges of a tile go to the eight gather waves in equal shares cut at ANY edge: a row that IS its level (one
+    piece in every wave), a long row in the middle of short ones, a long last row, a level with a single edge (seven empty
+    shares), an empty level, rows of exactly one share -- against the reference order, forward and all gradients."""
+    n_dst, n_src, R = 100, 300, 6
+    cnt = np.zeros((R, n_dst), np.int64)
+    cnt[0, 5] = 5000                                   # the whole level is one row
+    cnt[1, :64] = 1; cnt[1, 0] = 3; cnt[1, 1] = 900    # a long row after a short one
+    cnt[2, :64] = 2; cnt[2, 63] = 2000                 # a long LAST row of the tile
+    cnt[3, 70] = 1                                     # one edge in the second tile, none in the first
+    cnt[4, :64] = 16; cnt[4, 64:] = np.arange(36) % 2 * 40   # every share exactly two rows / alternating empty and 40-edge rows
+    rng = np.random.default_rng(7)                     # (level 5 stays empty)
+    eps, ips, sps = [], [], []
+    for r in range(R):
+        ip = np.concatenate([[0], np.cumsum(cnt[r])]).astype(np.int32)
+        n = int(ip[-1])
+        e = rng.integers(0, n_src, n).astype(np.int32)
+        sp = rng.uniform(0.05, 1.0, n).astype(np.float32)
+        if n == 0:
+            e, sp = np.zeros(1, np.int32), np.zeros(1, np.float32)      # reference graph.py:221-222 empty_as_zero
+        eps.append(e); ips.append(ip); sps.append(sp)
+    for act in ("leaky", None):
+        _check_against_reference_order(eps, ips, sps, n_dst, n_src, R, act, seed=3)
+
+
+def _check_against_reference_order(eps, ips, sps, n_dst, n_src, R, act, seed):
+    from star_gcn_amd import functional as F
+    from star_gcn_amd.plan import MultiLinkPlan
+    g = torch.Generator().manual_seed(seed)
     x = torch.randn(n_src, D, generator=g) * 0.1 * torch.exp(torch.randn(n_src, 1, generator=g))    # rows of very different scale
     ws = [torch.randn(D, D, generator=g) * (3.0 / D) ** 0.5 for _ in range(R)]
     bs = [torch.randn(D, generator=g) * 0.1 for _ in range(R)]
