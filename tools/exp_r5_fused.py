@@ -256,6 +256,15 @@ def imbalance(nu=1_250_000, ni=1_000_000, ne=125_000_000, R=16, G=256, GW=8):
         per_wg_busy = torch.zeros(G, dtype=torch.long, device=dev).scatter_add_(0, wg_of_tile, busiest.sum(1))
         per_wg_even = torch.zeros(G, dtype=torch.long, device=dev).scatter_add_(0, wg_of_tile, even.sum(1))
         per_wg_edges = torch.zeros(G, dtype=torch.long, device=dev).scatter_add_(0, wg_of_tile, tile_edges)
+        # the same tiles dealt stratum by stratum (G tiles of similar size) to the workgroups in ascending order of their load so far
+        te = tile_edges[order].cpu()
+        load = torch.zeros(G, dtype=torch.long)
+        for s0 in range(0, T, G):
+            chunk = te[s0:s0 + G]
+            wgs = torch.argsort(load)[:chunk.numel()]
+            load[wgs] += chunk
+        print("      stratum-greedy dealing: per-workgroup edges max/mean %.4f (boustrophedon: %.4f)" % (
+            float(load.max()) / float(load.float().mean()), float(per_wg_edges.max()) / float(per_wg_edges.float().mean())), flush=True)
         big = (cnt.max(2).values > even * 2).float().mean()
         print("into %-5s: %d tiles; busiest-wave edges / (edges / 8) over all items %.3f; per workgroup: edges max/mean %.3f, "
               "busiest-wave sum max / even mean %.3f (mean / even mean %.3f); items whose largest row exceeds 2 x its even share: %.3f; "
