@@ -373,9 +373,10 @@ typedef struct sg_multilink_plan {      /* all pointers are DEVICE pointers; see
 } sg_multilink_plan;
 int sg_multilink_agg_resolve_order(const sg_multilink_plan* plan, int order);
 /* The order sg_multilink_agg_{fwd,bwd}_hip run for these sizes.  SG_ORDER_AUTO resolves to SG_ORDER_FUSED when the fused
- * kernel handles the widths ('sum', in_dim = units_per_level = 256), the graph is large enough for the R-expanded matrix to
- * cost HBM time (nnz >= 2^24, >= 2^17 nodes on the smaller side, >= 8 levels, its expanded matrix beyond the 256 MB Infinity Cache; SG_FUSED=0 / 1
- * in the environment forces never / whenever supported), and otherwise to the rule of sg_multilink_agg_resolve_order.
+ * kernel handles the widths ('sum', in_dim = units_per_level = 256) and the measured rule says it is the faster one (>= 2 levels,
+ * >= 2^14 nodes on the smaller side, the larger side at most twice the smaller, the smaller side's R-expanded matrix beyond
+ * 192 MB: multilink.hip, profiles/r5_fused_kernel.md section 7; SG_FUSED=0 / 1 in the environment forces never / whenever
+ * supported), and otherwise to the rule of sg_multilink_agg_resolve_order.
  * The caller then attaches plan->fused (both entries) before the launch. */
 int sg_multilink_agg_resolve_order2(const sg_multilink_plan* plan, int order, int64_t in_dim, int64_t units_per_level,
                                     int accum);

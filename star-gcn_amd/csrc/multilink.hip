@@ -200,15 +200,20 @@ int resolve_order2(const sg_multilink_plan* p, int order, int64_t in_dim, int64_
   if (accum == SG_ACCUM_SUM && p->nnz > 0 && p->n_dst > 0 && p->n_src > 0 && sg_agg_fused_supported(in_dim, upl, p->num_links)) {
     const int mode = fused_mode();
     const int64_t small_side = p->n_src < p->n_dst ? p->n_src : p->n_dst;
-    // 64-row tiles over 256 persistent workgroups need a few thousand tiles on BOTH node sides to balance (the data gradient
-    // walks the other side), and the fusion only pays where the R-expanded matrix would travel through HBM.  Measured: the
-    // config-5 shard (1.25 M x 1 M, 125 M edges) 305 -> 272 ms per step; the MovieLens-10M shape (10 677 items = 167 tiles,
-    // cache-resident sources) 9.2 -> 23 ms -- the column-sliced gather lives on L2 hits the tile kernel cannot have
-    // (mid-size checks, same box, ms per step unfused / fused: 300 k x 250 k, 30 M edges, 16 levels 69.0 / 68.4; 150 k x 140 k,
-    //  20 M, 10 levels 39.6 / 35.7; 600 k x 500 k, 60 M, 5 levels 101.9 / 104.9 -- with few levels the expanded matrix is small
-    //  and its GEMM cheap, so the rule also asks for >= 8 levels)
-    const bool big = p->nnz >= (1ll << 24) && small_side >= (1ll << 17) && p->num_links >= 8 &&
-                     small_side * p->num_links * in_dim * 4 > (256ll << 20);
+    const int64_t big_side = p->n_src < p->n_dst ? p->n_dst : p->n_src;
+    // Measured per direction, forward + backward, on bench.py's synthetic graphs from 17 k x 16.5 k nodes / 1.5 M edges to the
+    // config-5 shard, 2 .. 32 levels (tools/exp_r5_fused.py dir-ab, tools/mid_size_fused_ab.sh; profiles/r5_fused_kernel.md
+    // section 7), fused time / time of the better unfused order:
+    //   * node sides within a factor of two and the smaller side's R-expanded matrix beyond ~200 MB (it does not stay in the
+    //     L2s / the Infinity Cache next to its sources): 0.65 .. 0.97 -- 30 k x 25 k, 10 levels 0.68; 60 k x 50 k, 16 levels 0.65;
+    //     120 k x 100 k 0.67; 300 k x 250 k with TWO levels 0.95; the shard 0.78 / 0.83; down to 258 tiles (17 k x 16.5 k) 0.86 .. 0.95;
+    //   * lopsided graphs: the unfused orders put the R-expanded matrix and its GEMM on the SMALL side, the fused kernel contracts
+    //     on whichever side is the destination: ties at 2.5 .. 4 : 1 (100 k x 40 k 0.97, 400 k x 100 k 0.97 / 1.02, 1 M x 300 k 0.98),
+    //     losses beyond (200 k x 33 k 1.02, 156 k x 1 M -- one rank's block of eight -- 1.30, 500 k x 20 k 1.5, the MovieLens-10M
+    //     shape 70 k x 10.7 k 1.5: 167 item tiles on 256 CUs, sources that live in the L2s);
+    //   * smaller expanded matrices (70 k x 35 k, 5 levels: 171 MB) tie.
+    const bool big = small_side >= (1ll << 14) && p->num_links >= 2 && big_side <= 2 * small_side &&
+                     small_side * p->num_links * in_dim * 4 > (192ll << 20);
     if (mode == 1 || (mode != 0 && big)) return SG_ORDER_FUSED;
   }
   return resolve_order(p, order);

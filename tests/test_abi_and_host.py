@@ -157,10 +157,17 @@ def test_fused_order_routing_and_sizes_are_host_decisions(monkeypatch):
     assert lib.sg_multilink_agg_resolve_order2(ref, 3, 64, 64, 0) == 3            # ... also 'fused' (the launch then refuses)
     st.n_dst, st.n_src, st.nnz, st.num_links = 69878, 10677, 10_000_054, 10       # MovieLens-10M: cache-resident, 167 item tiles
     assert lib.sg_multilink_agg_resolve_order2(ref, 0, 256, 256, 0) == 1
-    st.n_dst, st.n_src, st.nnz, st.num_links = 600_000, 500_000, 60_000_000, 5    # few levels: the expanded matrix is cheap
-    assert lib.sg_multilink_agg_resolve_order2(ref, 0, 256, 256, 0) == 1
-    st.n_dst, st.n_src, st.nnz, st.num_links = 200_000, 200_000, 1 << 23, 10      # too few edges
-    assert lib.sg_multilink_agg_resolve_order2(ref, 0, 256, 256, 0) in (1, 2)
+    # measured rule (multilink.hip, profiles/r5_fused_kernel.md section 7): node sides within a factor of two, >= 2^14 nodes on
+    # the smaller one, its R-expanded matrix beyond 192 MB
+    for shape, want in (((600_000, 500_000, 60_000_000, 5), 3), ((30_000, 25_000, 3_000_000, 10), 3), ((17_000, 16_500, 1_500_000, 16), 3),
+                        ((300_000, 250_000, 30_000_000, 2), 3),
+                        ((70_000, 35_000, 5_000_000, 5), 1),           # 171 MB: stays in the caches
+                        ((156_250, 1_000_000, 15_600_000, 16), 2),     # one rank's user block of eight: lopsided
+                        ((500_000, 20_000, 20_000_000, 16), 1), ((100_000, 40_000, 10_000_000, 10), 1),
+                        ((300_000, 250_000, 30_000_000, 1), 1),        # one level: nothing is expanded
+                        ((16_000, 16_000, 4_000_000, 32), 1)):         # fewer than 2^14 nodes: fewer tiles than CUs
+        st.n_dst, st.n_src, st.nnz, st.num_links = shape
+        assert lib.sg_multilink_agg_resolve_order2(ref, 0, 256, 256, 0) == want, shape
     assert lib.sg_multilink_agg_resolve_order2(ref, 7, 256, 256, 0) < 0
     # sizes: nothing saved by the fused forward; its backward workspace holds dpre, dH (n_src x R x 256) and the packed gradients
     st.n_dst, st.n_src, st.nnz, st.num_links = 1000, 3000, 50000, 4

@@ -274,6 +274,39 @@ def imbalance(nu=1_250_000, ni=1_000_000, ne=125_000_000, R=16, G=256, GW=8):
                   float(big), int(cnt.max())), flush=True)
 
 
+def dir_ab(shapes):
+    """fused against the better unfused order, PER DIRECTION, forward + backward through autograd, on bench.py's synthetic graph
+    (log-normal propensities) at the given (users, items, ratings, levels) shapes: the data behind the routing rule of
+    sg_multilink_agg_resolve_order2"""
+    from star_gcn_amd import functional as F
+    from star_gcn_amd.device_graph import synthetic_device_graph
+    dev = torch.device("cuda")
+    for nu, ni, ne, R in shapes:
+        dg = synthetic_device_graph(nu, ni, ne, R, dev, seed=5)
+        for dst in (dg.U, dg.I):
+            plan = dg.plan(dst)
+            x = torch.randn(plan.n_src, D, device=dev, requires_grad=True)
+            Ws = [(torch.randn(D, D, device=dev) / 16).requires_grad_(True) for _ in range(R)]
+            bs = [torch.randn(D, device=dev).requires_grad_(True) for _ in range(R)]
+            gy = torch.randn(plan.n_dst, D, device=dev)
+            res = {}
+            for order in ("fused", "transform_first", "aggregate_first"):
+                def step():
+                    out = F.multilink_aggregate(x, Ws, bs, plan, accum="sum", act="leaky", order=order)
+                    out.backward(gy)
+                res[order] = timeit(step, n=5, warm=2)
+            work = (plan.c_indptr[R::R] - plan.c_indptr[:-1:R])
+            tw = torch.cat([work, work.new_zeros((-plan.n_dst) % 64)]).view(-1, 64).sum(1)
+            unf = min(res["transform_first"], res["aggregate_first"])
+            print("%9d x %9d %10d R %2d into %-5s: tiles %6d (%.2f per CU) n_dst/n_src %.2f expanded dst %5.0f MB src %5.0f MB  fused %8.3f  "
+                  "unfused %8.3f (tf %.3f af %.3f)  fused/unfused %.2f  tile max/mean %.1f" % (
+                      nu, ni, dg.nnz, R, dst, tw.numel(), tw.numel() / 256, plan.n_dst / plan.n_src, plan.n_dst * R * D * 4 / 2**20,
+                      plan.n_src * R * D * 4 / 2**20, res["fused"], unf, res["transform_first"], res["aggregate_first"], res["fused"] / unf,
+                      float(tw.max()) / float(tw.float().mean())), flush=True)
+        del dg, plan
+        torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "check":
         check()
@@ -283,6 +316,8 @@ if __name__ == "__main__":
         ml10m_forward()
     elif sys.argv[1] == "imbalance":
         imbalance()
+    elif sys.argv[1] == "dir-ab":
+        dir_ab([tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]])
     else:
         a = [int(v) for v in sys.argv[2:6]] if len(sys.argv) >= 6 else [1_000_000, 1_250_000, 125_000_000, 16]
         time_case(*a)
