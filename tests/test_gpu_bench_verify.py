@@ -80,3 +80,24 @@ def test_config5_shard_bench_network_against_float64_definition():
     _release()
     assert torch.cuda.memory_reserved(dev) < 8 << 30       # nothing of the 140 GB stays behind for the tests that follow
     assert os.sched_getaffinity(0) == affinity
+
+
+def test_mid_size_graph_where_auto_fuses_against_float64_definition():
+    """60 k users x 50 k items, 6 M ratings, 16 levels: far from the shard's size, but inside the measured rule of
+    sg_multilink_agg_resolve_order2 (node sides within a factor of two, expanded matrix beyond the caches), so `auto` runs every
+    aggregation of the network in the fused aggregate -> contract kernel; same float64 check as the two timed workloads."""
+    import bench
+    from star_gcn_amd import ops
+    dev = torch.device("cuda", 0)
+    c = bench.hbm_case("60000,50000,6000000,16", 256, "auto", dev)
+    ops.fused_profile(True)
+    c.step()
+    torch.cuda.synchronize()
+    ops.fused_profile(False)
+    recs = ops.fused_profile_read()
+    assert len(recs) == 8 and all(n == c.E for _, n, _ in recs), recs          # 2 layers x 2 node types x (forward + data gradient)
+    v = bench.verify_leg(c.net, c.step, (c.dg.ind_ptr, c.dg.end_points, c.dg.level, c.ni, c.R, None), c.y, 1.0 / c.E)
+    v.update(n_user=c.nu, n_item=c.ni)
+    _check(v)
+    del c
+    _release()
