@@ -144,7 +144,7 @@ def test_bench_under_torch_distributed_run():
     assert abs(one["config"]["loss"] - two["config"]["loss"]) <= 1e-5 * max(1.0, abs(one["config"]["loss"]))
 
 
-def _config5_union_worker(rank, world, port, shape, dim, result_path):
+def _config5_union_worker(rank, world, port, shape, dim, result_path, calibrate=False):
     """Rank r: the config-5 construction of bench.run_config5 (own user block, item degrees summed over the ranks, partitioned
     network).  Rank 0 then rebuilds the SAME problem as one graph -- the blocks stacked -- without any partition and compares."""
     import numpy as np
@@ -185,10 +185,18 @@ def _config5_union_worker(rank, world, port, shape, dim, result_path):
             return loss
         step()
         M.deterministic_init(net, 1234, {bench.U: (0, rows, rows), bench.I: (0, ni, ni)})
+        if calibrate:       # O(1) activations and scores (bench.prepare_net): gradients that are not sums of cancelling 1e-10s
+            M.calibrate_output_scale(net, lambda: net.run(plan), reduce=SD.all_reduce_sum if part is not None else None,
+                                     run_scores=lambda: net.run(plan)[0][0])
         return net, step()
 
     y = ((vals - mean) / std).contiguous()
+    from star_gcn_amd import ops
+    ops.fused_profile(True)
     net, loss = loss_and_grads(dgp, y, SD.NodePartition([bench.U], [bench.I]), nu)
+    torch.cuda.synchronize()
+    ops.fused_profile(False)
+    fused_launches = len(ops.fused_profile_read())      # launches of the fused aggregate -> contract kernel in the partitioned steps
     SD.allreduce_grads(net.local_region_parameters())
     total = SD.all_reduce_sum(loss.detach().view(1))[0]
     if rank == 0:
@@ -210,15 +218,19 @@ def _config5_union_worker(rank, world, port, shape, dim, result_path):
         rstep()
         M.deterministic_init(ref, 1234, {bench.I: (0, ni, ni)})
         ukey = "embed_layers._layers.%d.weight" % ref.embed_layers._key2idx[bench.U]
-        with torch.no_grad():       # every rank holds the same user table (run_config5): the union table stacks it
-            dict(ref.named_parameters())[ukey].copy_(dict(net.named_parameters())[ukey].repeat(world, 1))
+        with torch.no_grad():       # the partitioned network's parameters; every rank holds the same user table (run_config5):
+            for k, p in ref.named_parameters():                                          # the union table stacks it
+                src = dict(net.named_parameters())[k]
+                p.copy_(src.repeat(world, 1) if k == ukey else src)
         rl = rstep()
         errs = dict()
         for k, p in net.named_parameters():
             g = dict(ref.named_parameters())[k].grad
             g = g[:nu] if k == ukey else g
-            errs[k] = (float((p.grad - g).abs().max()), float(g.abs().max()))
-        torch.save({"loss": float(total), "ref_loss": float(rl), "errs": errs}, result_path)
+            d = (p.grad - g).abs()
+            rows_off = float((d.view(d.shape[0], -1).max(1).values > 1e-5 * g.abs().max()).float().mean())
+            errs[k] = (float(d.max()), float(g.abs().max()), float(d.double().norm()), float(g.double().norm()), rows_off)
+        torch.save({"loss": float(total), "ref_loss": float(rl), "errs": errs, "fused_launches": fused_launches}, result_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -237,8 +249,39 @@ def test_config5_blocks_equal_the_union_graph(tmp_path):
     mp.spawn(_config5_union_worker, args=(2, port, (2500, 1800, 50000, 4), 64, res), nprocs=2, join=True)
     r = torch.load(res)
     assert abs(r["loss"] - r["ref_loss"]) <= 1e-5 * max(1.0, abs(r["ref_loss"])), r
-    worst = max(e / max(sc, 1e-30) for e, sc in r["errs"].values())
+    worst = max(v[0] / max(v[1], 1e-30) for v in r["errs"].values())
     assert worst <= 2e-4, {k: v for k, v in r["errs"].items() if v[0] > 2e-4 * v[1]}
+
+
+def test_config5_blocks_equal_the_union_graph_where_auto_fuses(tmp_path):
+    """The same at dim 256 with blocks of 20 000 users x 33 000 items, 2 M ratings, 16 levels per rank: inside the measured rule
+    of sg_multilink_agg_resolve_order2, so every aggregation of the PARTITIONED network runs in the fused aggregate -> contract
+    kernel (item-side partial sums leave it without activation, are all-reduced, then activated) -- and must still equal the
+    unpartitioned network over the union graph."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = str(tmp_path / "r.pt")
+    mp.spawn(_config5_union_worker, args=(2, port, (20000, 33000, 2000000, 16), 256, res, True), nprocs=2, join=True)
+    r = torch.load(res)
+    assert r["fused_launches"] >= 16, r["fused_launches"]       # two steps x (2 layers x 2 node types x forward + data gradient)
+    assert abs(r["loss"] - r["ref_loss"]) <= 1e-6 * max(1.0, abs(r["ref_loss"])), r
+    # Gradients: the two runs add the item-side sums in different orders, and at this size a few pre-activations sit within
+    # fp32 rounding of LeakyReLU's kink (bench.py's float64 check adopts the network's sign there); tensors whose gradient is a
+    # sum of cancelling terms (first-block aggregator weights: 1e-6 against 1e0 for the rating projections) show that as
+    # 1e-4 .. 1e-3 of their own scale -- with the unfused orders just as with the fused one (tools/dbg_union.py).  So: the
+    # tensors that carry the gradient agree to fp32, every tensor agrees roughly, and the whole gradient agrees in norm.
+    errs = r["errs"]
+    top = max(v[1] for v in errs.values())
+    for k, v in errs.items():       # v = (max |diff|, max |g|, ||diff||, ||g||, share of rows with a diff > 1e-5 max |g|)
+        assert v[0] <= 5e-3 * v[1], (k, v)
+        if v[1] >= 1e-2 * top:      # ... to fp32, except in the one or two rows a flipped derivative reaches directly
+            assert v[0] <= 2e-5 * v[1] or v[4] <= 0.02, (k, v)
+    assert sum(v[2] ** 2 for v in errs.values()) ** 0.5 <= 2e-5 * sum(v[3] ** 2 for v in errs.values()) ** 0.5
 
 
 def test_bench_step_replays_as_one_hipgraph():
