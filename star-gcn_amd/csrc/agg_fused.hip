@@ -175,7 +175,7 @@ struct Ctx {                    // one (item = tile x level, G wave): the rows a
   int e_lo, e_hi, ng;           // my edges; groups of NB (at least one, possibly all padding)
   int tile, r, it;              // tile = launch slot of the tile; it = ordinal of the item in this workgroup's sequence
   int eb;                       // exponent of the level's B planes (SG_FUSED_DIRECT)
-  int split;                    // SG_FUSED_EVEN: tail row | head row << 8 | first wave of the head row << 16 (row 64 = none)
+  int split;                    // SG_FUSED_EVEN: tail row | head row << 8 | first wave of the head row << 16 (row 64 = none) | empty share << 24
 };
 
 template <bool ZSAVE, bool NT>
@@ -253,7 +253,9 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       const int tj = tailm ? __ffsll(static_cast<long long>(tailm)) - 1 : 64;
       const int hj = headm ? __ffsll(static_cast<long long>(headm)) - 1 : 64;
       const int hu = headm ? __builtin_amdgcn_readlane(wj, hj & 63) : 0;
-      c.split = tj | (hj << 8) | (hu << 16);
+      // (with fewer than GW edges some shares are empty; one that lies inside a cut row must still hand a partial row -- zeros -- to
+      //  the wave that puts the row together: bit 24)
+      c.split = tj | (hj << 8) | (hu << 16) | ((total > 0 && c_lo == c_hi) ? (1 << 24) : 0);
       asm volatile("v_mov_b32 %0, %1" : "=v"(c.pn) : "v"(pe));
       c.e_lo = c_lo; c.e_hi = c_hi;
 #else
@@ -443,6 +445,9 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
           emit_zero(cC, j);
         }
         rem = cC.rows;
+#if SG_FUSED_EVEN == 1
+        if ((cC.split >> 24) & 1) *reinterpret_cast<f32x4*>(smem + SMEM_BASE + gw * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
       }
       const int gbI = cI.e_lo + giI * NB;
       wv_nxt = (gbI + lane < cI.e_hi) ? mI_w : 0.f;

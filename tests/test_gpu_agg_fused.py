@@ -175,6 +175,64 @@ def test_fused_kernel_raw_c_abi_rows_of_other_pitch_and_saved_aggregates():
     assert rc < 0 and b"workspace" in lib.sg_last_error()
 
 
+def test_fused_kernel_on_heavy_tailed_random_graphs():
+    """80 random shapes (1 .. 700 rows, 1 .. 32 levels, 1 .. 150 000 edges) with Zipf row AND level popularity: rows that are
+    a level's whole share of a tile, levels with fewer edges than gather waves (empty shares inside a cut row), empty tiles,
+    one-row graphs -- forward with saved aggregates, both weight orientations, bias on, against float64.  (Found a bug the
+    hand-made cases missed: a two-edge row in a three-edge level.)"""
+    from star_gcn_amd import _lib as L
+    from star_gcn_amd import ops
+    lib = L.lib()
+    dev = torch.device("cuda")
+    rng = torch.Generator(device="cpu").manual_seed(20240)
+    for case in range(80):
+        n_dst = int(torch.randint(1, 701, (1,), generator=rng))
+        n_src = int(torch.randint(1, 3001, (1,), generator=rng))
+        R = int(torch.randint(1, 33, (1,), generator=rng))
+        nnz = int(10 ** (float(torch.rand(1, generator=rng)) * 5.17)) + 1
+        a_row = 0.5 + 2.0 * float(torch.rand(1, generator=rng))
+        a_lvl = 2.5 * float(torch.rand(1, generator=rng))
+        g = torch.Generator(device=dev).manual_seed(case)
+        pr = (torch.arange(1, n_dst + 1, device=dev, dtype=torch.float64) ** -a_row)[torch.randperm(n_dst, device=dev, generator=g)]
+        pl = (torch.arange(1, R + 1, device=dev, dtype=torch.float64) ** -a_lvl)[torch.randperm(R, device=dev, generator=g)]
+        key, _ = torch.sort(torch.multinomial(pr, nnz, replacement=True, generator=g) * R +
+                            torch.multinomial(pl, nnz, replacement=True, generator=g))
+        indptr = torch.zeros(n_dst * R + 1, dtype=torch.int32, device=dev)
+        indptr[1:] = torch.cumsum(torch.bincount(key, minlength=n_dst * R), 0).to(torch.int32)
+        idx = torch.randint(0, n_src, (nnz,), device=dev, generator=g, dtype=torch.int32)
+        w = torch.rand(nnz, device=dev, generator=g) + 0.1
+        x = torch.randn(n_src, D, device=dev, generator=g) * torch.exp(torch.randn(n_src, 1, device=dev, generator=g))
+        Ws = [torch.randn(D, D, device=dev, generator=g) / 16 for _ in range(R)]
+        bs = [torch.randn(D, device=dev, generator=g) for _ in range(R)]
+        trans = case & 1
+        tiles = (n_dst + 63) // 64
+        order = torch.randperm(tiles, device=dev, generator=g).to(torch.int32) if case & 4 else None
+        f_ptr = torch.empty(tiles * R * 65, dtype=torch.int32, device=dev)
+        f_idx, f_w = torch.empty_like(idx), torch.empty_like(w)
+        L.check(lib.sg_agg_fused_plan_build_hip(L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), None, L.ptr(order), L.ptr(indptr), L.ptr(idx),
+                                                L.ptr(w), n_dst, R, nnz, L.stream_ptr()), "plan")
+        seg = torch.repeat_interleave(torch.arange(n_dst * R, device=dev), (indptr[1:] - indptr[:-1]).long())
+        Z = torch.zeros(n_dst * R, D, dtype=torch.float64, device=dev).index_add_(0, seg, x.double()[idx.long()] * w.double()[:, None])
+        Z = Z.view(n_dst, R, D)
+        rs = torch.zeros(n_dst * R, dtype=torch.float64, device=dev).index_add_(0, seg, w.double()).view(n_dst, R)
+        ref = torch.zeros(n_dst, D, dtype=torch.float64, device=dev)
+        mag = torch.zeros_like(ref)
+        for r in range(R):
+            B = Ws[r].double() if trans else Ws[r].double().t()
+            ref += Z[:, r] @ B + rs[:, r:r + 1] * bs[r].double()[None]
+            mag += Z[:, r].abs() @ B.abs() + (rs[:, r:r + 1] * bs[r].double()[None]).abs()
+        out = torch.empty(n_dst, D, device=dev)
+        zs = torch.full((n_dst, R * D), -7.0, device=dev)
+        ws, wsn = L.workspace(lib.sg_agg_fused_workspace_bytes(R), dev)
+        L.check(lib.sg_agg_fused_hip(L.ptr(out), D, L.ptr(zs), R * D, L.ptr(x), D, ops._ptr_array(Ws), D, trans, ops._ptr_array(bs),
+                                     L.ptr(rs.float().contiguous()), L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), L.ptr(order), n_dst, R,
+                                     nnz, D, D, 0, 0.0, 0, L.ptr(ws), wsn, L.stream_ptr()), "fused")
+        err = float(((out.double() - ref).abs() / mag.clamp_min(1e-30)).max())
+        zerr = float((zs.double().view(n_dst, R, D) - Z).abs().max() / Z.abs().max().clamp_min(1e-300))
+        what = (case, n_dst, R, nnz, int((indptr[1:] - indptr[:-1]).max()))
+        assert err < 2e-6 and zerr < 2e-6, (what, err, zerr)          # |err| / sum |a||b|: fp32 products at f16x3 accuracy
+
+
 def test_fused_order_at_ml10m_size_against_the_definition_and_the_unfused_orders():
     """BASELINE config 4 size (69878 x 10677, 10 M ratings, 10 levels, dim 256), both directions of the bipartite graph
     (heavy item rows up to 35 k ratings): >= 64 sampled output rows and gradient rows against the float64 definition,

@@ -307,6 +307,50 @@ def dir_ab(shapes):
         torch.cuda.empty_cache()
 
 
+def fuzz(n_cases=60):
+    """random shapes (1 .. 700 rows, 1 .. 32 levels, 1 .. 150 000 edges) with heavy-tailed (Zipf) row and level popularity -- rows
+    that are a level's whole share, levels with a handful of edges, empty tiles -- forward with saved aggregates, either operand
+    orientation, against float64; exercises the equal-share cuts of the gather waves"""
+    dev = torch.device("cuda")
+    rng = torch.Generator(device="cpu").manual_seed(20240)
+    worst, worst_z = 0.0, 0.0
+    for case in range(n_cases):
+        n_dst = int(torch.randint(1, 701, (1,), generator=rng))
+        n_src = int(torch.randint(1, 3001, (1,), generator=rng))
+        R = int(torch.randint(1, 33, (1,), generator=rng))
+        nnz = int(10 ** (float(torch.rand(1, generator=rng)) * 5.17)) + 1
+        a_row = 0.5 + 2.0 * float(torch.rand(1, generator=rng))
+        a_lvl = 2.5 * float(torch.rand(1, generator=rng))
+        g = torch.Generator(device=dev).manual_seed(case)
+        pr = (torch.arange(1, n_dst + 1, device=dev, dtype=torch.float64) ** -a_row)[torch.randperm(n_dst, device=dev, generator=g)]
+        pl = (torch.arange(1, R + 1, device=dev, dtype=torch.float64) ** -a_lvl)[torch.randperm(R, device=dev, generator=g)]
+        dst = torch.multinomial(pr, nnz, replacement=True, generator=g)
+        lvl = torch.multinomial(pl, nnz, replacement=True, generator=g)
+        key, _ = torch.sort(dst * R + lvl)
+        indptr = torch.zeros(n_dst * R + 1, dtype=torch.int32, device=dev)
+        indptr[1:] = torch.cumsum(torch.bincount(key, minlength=n_dst * R), 0).to(torch.int32)
+        idx = torch.randint(0, n_src, (nnz,), device=dev, generator=g, dtype=torch.int32)
+        w = torch.rand(nnz, device=dev, generator=g) + 0.1
+        x = torch.randn(n_src, D, device=dev, generator=g) * torch.exp(torch.randn(n_src, 1, device=dev, generator=g))
+        Ws = [torch.randn(D, D, device=dev, generator=g) / 16 for _ in range(R)]
+        bs = [torch.randn(D, device=dev, generator=g) for _ in range(R)]
+        trans, act = case & 1, ("leaky" if case & 2 else None)
+        tiles = (n_dst + 63) // 64
+        order = torch.randperm(tiles, device=dev, generator=g).to(torch.int32) if case & 4 else None
+        plan = build_plan(indptr, idx, w, n_dst, R, order)
+        ref, mag, Z, rs = reference(x, Ws, bs, indptr, idx, w, n_dst, R, act, trans)
+        zsave = torch.full((n_dst, R * D), -7.0, device=dev)
+        out = fused(x, Ws, bs, rs.float().contiguous(), plan, order, n_dst, R, nnz, act, trans, zsave)
+        torch.cuda.synchronize()
+        err = ((out.double() - ref).abs() / mag.clamp_min(1e-30)).max().item()
+        zerr = ((zsave.double().view(n_dst, R, D) - Z).abs().max() / Z.abs().max().clamp_min(1e-300)).item()
+        big = int((indptr[1:] - indptr[:-1]).max())
+        worst, worst_z = max(worst, err), max(worst_z, zerr)
+        print("case %2d: %3d rows %2d levels %6d edges (largest (row, level) %6d) trans %d: out %.2e  saved aggregates %.2e%s" % (
+            case, n_dst, R, nnz, big, trans, err, zerr, "   <-- FAIL" if not (err < 2e-6 and zerr < 2e-6) else ""), flush=True)
+    print("WORST out %.3g aggregates %.3g (%s)" % (worst, worst_z, "ok" if worst < 2e-6 and worst_z < 2e-6 else "FAIL"))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "check":
         check()
@@ -316,6 +360,8 @@ if __name__ == "__main__":
         ml10m_forward()
     elif sys.argv[1] == "imbalance":
         imbalance()
+    elif sys.argv[1] == "fuzz":
+        fuzz(int(sys.argv[2]) if len(sys.argv) > 2 else 60)
     elif sys.argv[1] == "dir-ab":
         dir_ab([tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]])
     else:
