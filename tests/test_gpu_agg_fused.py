@@ -233,6 +233,52 @@ def test_fused_kernel_on_heavy_tailed_random_graphs():
         assert err < 2e-6 and zerr < 2e-6, (what, err, zerr)          # |err| / sum |a||b|: fp32 products at f16x3 accuracy
 
 
+def test_fused_order_through_autograd_on_heavy_tailed_random_graphs():
+    """40 random graphs with Zipf destination, source and level popularity through the whole aggregator (forward, data gradient
+    over the transposed plan, weight gradient from the saved aggregates -- either side smaller --, bias gradient): the fused order
+    against the transform-first order of the same library, and the outputs against float64."""
+    from star_gcn_amd import functional as F
+    from star_gcn_amd.plan import MultiLinkPlan
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        n_dst, n_src = int(rng.integers(1, 500)), int(rng.integers(1, 500))
+        R = int(rng.integers(1, 33))
+        nnz = int(10 ** rng.uniform(0, 4.6)) + 1
+        zipf = lambda n, a: (np.arange(1, n + 1) ** -a)[rng.permutation(n)]
+        pd, ps, pl = zipf(n_dst, rng.uniform(0.3, 2.5)), zipf(n_src, rng.uniform(0.0, 1.5)), zipf(R, rng.uniform(0.0, 2.5))
+        dst = rng.choice(n_dst, nnz, p=pd / pd.sum())
+        src = rng.choice(n_src, nnz, p=ps / ps.sum()).astype(np.int32)
+        lev = rng.choice(R, nnz, p=pl / pl.sum())
+        sup = rng.uniform(0.05, 1.0, nnz).astype(np.float32)
+        eps, ips, sps = [], [], []
+        for r in range(R):
+            sel = np.flatnonzero(lev == r)
+            sel = sel[np.argsort(dst[sel], kind="stable")]
+            ips.append(np.concatenate([[0], np.cumsum(np.bincount(dst[sel], minlength=n_dst))]).astype(np.int32))
+            e, sp = src[sel], sup[sel]
+            if e.size == 0:
+                e, sp = np.zeros(1, np.int32), np.zeros(1, np.float32)      # reference graph.py:221-222 empty_as_zero
+            eps.append(e); sps.append(sp)
+        plan = MultiLinkPlan(eps, ips, sps, n_src, "cuda")
+        g = torch.Generator().manual_seed(case)
+        x = torch.randn(n_src, D, generator=g) * torch.exp(torch.randn(n_src, 1, generator=g))
+        ws = [torch.randn(D, D, generator=g) * (3.0 / D) ** 0.5 for _ in range(R)]
+        bs = [torch.randn(D, generator=g) * 0.1 for _ in range(R)]
+        gy = torch.randn(n_dst, D, generator=g).cuda()
+        res = {}
+        for order in ("fused", "transform_first"):
+            xd = x.cuda().requires_grad_(True)
+            wd = [w.cuda().requires_grad_(True) for w in ws]
+            bd = [b.cuda().requires_grad_(True) for b in bs]
+            out = F.multilink_aggregate(xd, wd, bd, plan, accum="sum", act="leaky", slope=0.1, order=order)
+            out.backward(gy)
+            res[order] = (out.detach(), xd.grad, torch.stack([w.grad for w in wd]), torch.stack([b.grad for b in bd]))
+        for name, a, b in zip(("out", "dx", "dW", "db"), res["fused"], res["transform_first"]):
+            rel_close(a, b.double(), 2e-5, "case %d (%d x %d, %d levels, %d edges) %s" % (case, n_dst, n_src, R, nnz, name))
+        ref = OM.multilink_aggregator(x.double(), [w.double() for w in ws], [b.double() for b in bs], eps, ips, sps, accum="sum", act="leaky")
+        rel_close(res["fused"][0], ref, 1e-5, "case %d out vs float64" % case)
+
+
 def test_fused_order_at_ml10m_size_against_the_definition_and_the_unfused_orders():
     """BASELINE config 4 size (69878 x 10677, 10 M ratings, 10 levels, dim 256), both directions of the bipartite graph
     (heavy item rows up to 35 k ratings): >= 64 sampled output rows and gradient rows against the float64 definition,
