@@ -274,10 +274,10 @@ class MultiLinkPlan(object):
         cannot be built now (stream capture)."""
         if getattr(self, "_fused", None) is not None and not rebuild:
             return True
-        if torch.cuda.is_current_stream_capturing():
-            return False
-        lib = L.lib()
         old = getattr(self, "_fused", None)
+        if old is None and torch.cuda.is_current_stream_capturing():
+            return False        # the first build allocates and sorts; a rebuild (below) is one kernel launch per view into the same
+        lib = L.lib()           # buffers and MUST run inside a captured iteration: the weights it copies were just rewritten
         built = []
         for which, (ip, idx, w, rows) in enumerate(((self.c_indptr, self.c_idx, self.c_w, self.n_dst),
                                                     (self.t_indptr, self.t_idx, self.t_w, self.n_src))):

@@ -363,3 +363,35 @@ def test_fused_order_replays_inside_a_hip_graph():
     eager = step()
     for a, b in zip(replayed, eager):
         assert torch.equal(a, b)
+    # the resident training iteration: the plan's weights are rewritten (edge masking) and refreshed INSIDE the captured region --
+    # the fused kernel reads its own level-major copy of them, which the refresh must rebuild during capture, not skip
+    cw0, tw0 = plan.c_w.clone(), plan.t_w.clone()
+    fac = torch.ones(1, device="cuda")
+
+    def masked_step():
+        plan.c_w.copy_(cw0 * fac)
+        plan.t_w.copy_(tw0 * fac)
+        plan.refresh_rowsum()
+        return step()
+
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        masked_step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2):
+        captured2 = masked_step()
+    fac.fill_(0.25)
+    graph2.replay()
+    torch.cuda.synchronize()
+    replayed2 = [t.clone() for t in captured2]
+    assert not torch.equal(replayed2[0], replayed[0])
+    sps4 = [sp * np.float32(0.25) for sp in sps]
+    plan4 = MultiLinkPlan(eps, ips, sps4, n_src, "cuda")
+    for t in [x] + ws + bs:
+        t.grad = None
+    out4 = F.multilink_aggregate(x, ws, bs, plan4, accum="sum", act="leaky", order="fused")
+    out4.backward(gy)
+    for a, b in zip(replayed2, (out4.detach(), x.grad, ws[0].grad, bs[-1].grad)):
+        assert torch.equal(a, b)
