@@ -270,13 +270,18 @@ def test_fused_order_through_autograd_on_heavy_tailed_random_graphs():
             xd = x.cuda().requires_grad_(True)
             wd = [w.cuda().requires_grad_(True) for w in ws]
             bd = [b.cuda().requires_grad_(True) for b in bs]
-            out = F.multilink_aggregate(xd, wd, bd, plan, accum="sum", act="leaky", slope=0.1, order=order)
+            # (no activation under the gradients: two summation orders may put a pre-activation on either side of LeakyReLU's kink,
+            #  and on a 10 000-edge hub row one flipped derivative is 1e-5 of the gradient -- tools/dbg_case2.py)
+            out = F.multilink_aggregate(xd, wd, bd, plan, accum="sum", act=None, order=order)
             out.backward(gy)
             res[order] = (out.detach(), xd.grad, torch.stack([w.grad for w in wd]), torch.stack([b.grad for b in bd]))
         for name, a, b in zip(("out", "dx", "dW", "db"), res["fused"], res["transform_first"]):
             rel_close(a, b.double(), 2e-5, "case %d (%d x %d, %d levels, %d edges) %s" % (case, n_dst, n_src, R, nnz, name))
         ref = OM.multilink_aggregator(x.double(), [w.double() for w in ws], [b.double() for b in bs], eps, ips, sps, accum="sum", act="leaky")
-        rel_close(res["fused"][0], ref, 1e-5, "case %d out vs float64" % case)
+        with torch.no_grad():
+            out = F.multilink_aggregate(x.cuda(), [w.cuda() for w in ws], [b.cuda() for b in bs], plan, accum="sum", act="leaky",
+                                        slope=0.1, order="fused")
+        rel_close(out, ref, 1e-5, "case %d out (leaky) vs float64" % case)
 
 
 def test_fused_order_at_ml10m_size_against_the_definition_and_the_unfused_orders():
