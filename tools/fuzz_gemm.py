@@ -28,11 +28,24 @@ def main(n_cases, tol=1e-6):
         if case % 3 == 0:       # rows of very different scale (hub rows)
             A = A * torch.exp(2.5 * torch.randn(ash[0], 1, device=dev, generator=g))
             A = torch.cat([A, A.new_zeros(ash[0], pad_a)], 1)[:, :ash[1]] if pad_a else A
-        C = ops.gemm(A, B, trans_a=ta, trans_b=tb)
+        use_bias, acc_into, act = bool(rng.integers(0, 2)), bool(rng.integers(0, 3) == 0), [None, "leaky", "relu", "tanh", "sigmoid"][int(rng.integers(0, 5))]
+        pad_c = int(rng.choice([0, 0, 4, 64]))
+        bias = torch.randn(N, device=dev, generator=g) if use_bias else None
+        Cbuf = torch.randn(M, N + pad_c, device=dev, generator=g)
+        C0 = Cbuf[:, :N].clone()
+        C = ops.gemm(A, B, trans_a=ta, trans_b=tb, bias=bias, act=None if acc_into else act, out=Cbuf[:, :N], accumulate=acc_into)
+        assert pad_c == 0 or bool((Cbuf[:, N:] == Cbuf[:, N:]).all())
         a64 = (A.double().t() if ta else A.double())
         b64 = (B.double().t() if tb else B.double())
         ref = a64 @ b64
-        mag = a64.abs() @ b64.abs()
+        mag = a64.abs() @ b64.abs() + 1.0
+        if use_bias:
+            ref = ref + bias.double()[None]
+        if acc_into:
+            ref = ref + C0.double()
+        elif act is not None:
+            # activations are 1-Lipschitz (leaky / relu) or flatter: the pre-activation error bounds the output error
+            ref = {"leaky": lambda t: torch.where(t > 0, t, 0.1 * t), "relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act](ref)
         err = float(((C.double() - ref).abs() / mag.clamp_min(1e-300)).max())
         # rows of very different scale inside one 32-row scale block: the error model is block-relative (gemm_f16x3.hip), so a row
         # 100 x below its block's largest loses that factor against its OWN sum |a||b|
