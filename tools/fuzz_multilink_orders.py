@@ -18,11 +18,17 @@ def main(n_cases):
     rng = np.random.default_rng(4242)
     bad = 0
     for case in range(n_cases):
-        n_dst, n_src = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
-        R = int(rng.integers(1, 17))
-        nnz = int(10 ** rng.uniform(0, 5.3)) + 1
-        D = int(rng.choice([8, 64, 75, 250, 256, 100]))
-        U = int(rng.choice([8, 64, 75, 250, 256, 33]))
+        if os.environ.get("FUZZ_BIG") == "1":     # source matrices of 24 .. 256 MB: the gathers run as two source-range phases, XCD-sliced
+            n_dst, n_src = int(rng.integers(2000, 30000)), int(rng.integers(2000, 30000))
+            R = int(rng.integers(4, 17))
+            nnz = int(10 ** rng.uniform(4.5, 6.4)) + 1
+            D = U = 256 if rng.random() < 0.7 else 64
+        else:
+            n_dst, n_src = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
+            R = int(rng.integers(1, 17))
+            nnz = int(10 ** rng.uniform(0, 5.3)) + 1
+            D = int(rng.choice([8, 64, 75, 250, 256, 100]))
+            U = int(rng.choice([8, 64, 75, 250, 256, 33]))
         accum = "stack" if rng.random() < 0.3 else "sum"
         zipf = lambda n, a: (np.arange(1, n + 1) ** -a)[rng.permutation(n)]
         pd, ps, pl = zipf(n_dst, rng.uniform(0.3, 2.5)), zipf(n_src, rng.uniform(0.0, 1.5)), zipf(R, rng.uniform(0.0, 2.5))
