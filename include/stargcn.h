@@ -430,9 +430,10 @@ size_t sg_agg_fused_workspace_bytes(int32_t num_links);
 int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, const float* x, int64_t ldx,
                      const float* const* weights, int64_t ldw, int trans_w, const float* const* biases,
                      const float* rowsum, const int32_t* f_ptr, const int32_t* f_idx, const float* f_w,
-                     const int32_t* tile_order, int64_t n_dst, int32_t num_links, int64_t nnz, int64_t in_dim,
-                     int64_t out_dim, int act, float slope, int nt_loads, void* workspace, size_t workspace_bytes,
-                     void* stream);
+                     const int32_t* tile_order, int64_t n_dst, int64_t n_src, int32_t num_links, int64_t nnz,
+                     int64_t in_dim, int64_t out_dim, int act, float slope, int nt_loads, void* workspace,
+                     size_t workspace_bytes, void* stream);      /* n_src: rows of x, or 0 = unknown (rows are then addressed
+                                                                  * with 64-bit pointers instead of 32-bit buffer offsets) */
 /* measurement aid for bench.py, as sg_gather_profile_*: HIP events around every fused launch on its own stream.  read():
  * (elapsed ms, edges, 1 when the launch also wrote the aggregates) per launch, in launch order; clears the records. */
 int sg_agg_fused_profile_enable(int on);

@@ -141,7 +141,7 @@ _SIGS = {
     "sg_agg_fused_plan_build_hip": (_INT, [_P] * 8 + [_I64, _c.c_int32, _I64, _P]),
     "sg_agg_fused_refresh_hip": (_INT, [_P, _P, _P, _I64, _P]),
     "sg_agg_fused_workspace_bytes": (_SZ, [_c.c_int32]),
-    "sg_agg_fused_hip": (_INT, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _INT, _P, _P, _P, _P, _P, _P, _I64, _c.c_int32,
+    "sg_agg_fused_hip": (_INT, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _INT, _P, _P, _P, _P, _P, _P, _I64, _I64, _c.c_int32,
                                 _I64, _I64, _I64, _INT, _F32, _INT, _P, _SZ, _P]),
     "sg_agg_fused_profile_enable": (_INT, [_INT]),
     "sg_agg_fused_profile_read": (_I64, [_P, _P, _P, _I64]),

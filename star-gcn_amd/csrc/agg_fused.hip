@@ -107,6 +107,9 @@ constexpr int NJB = ND / 32;              // 32-column blocks of the output
 #ifndef SG_FUSED_EVEN
 #define SG_FUSED_EVEN 1                   // 0: a level's edges go to the gather waves at ROW boundaries (the first version: a hub row is one wave's)
 #endif
+#ifndef SG_FUSED_ROWPOLICY
+#define SG_FUSED_ROWPOLICY 1              // cache-policy immediate of the rows' buffer loads: 1 sc0 (ships), 0 none, 16 sc1, 2 nt
+#endif
 #ifndef SG_FUSED_ADB
 #define SG_FUSED_ADB 0                    // 1: the aggregate's fragments double-buffered in registers (fits only with 4 + 4 waves)
 #endif
@@ -178,7 +181,7 @@ struct Ctx {                    // one (item = tile x level, G wave): the rows a
   int split;                    // SG_FUSED_EVEN: tail row | head row << 8 | first wave of the head row << 16 (row 64 = none) | empty share << 24
 };
 
-template <bool ZSAVE, bool NT>
+template <bool ZSAVE, bool NT, bool BUF>
 __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   float* sinv = reinterpret_cast<float*>(smem + 2 * ZBUF);       // [buffer][row] 2^-e of the row's planes
@@ -292,12 +295,22 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
     };
 
     const char* xb = reinterpret_cast<const char*>(a.x);
+    // BUF: the gathered matrix ends below 4 GB from its first byte -- rows through a buffer resource (wave-uniform base, ONE 32-bit
+    // offset per lane instead of a 64-bit address: fewer address instructions on the issue-bound gather waves) with sc0 (no L1
+    // allocation for rows nobody re-reads).  Measured, profiles/r5_fused_kernel.md section 8: 21.2 -> 20.5 ms into users; nt 23-25.
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, BUF ? 0xffffffff : 0, 0x00020000);
     auto load_row = [&](f32x4& dst, int idx) __attribute__((always_inline)) {
       if (a.ablate & 2) idx = 0;        // (timing experiment: every load hits the same row -- no control flow around the load,
                                         //  the compiler must keep counting the outstanding loads)
-      const f32x4* p = reinterpret_cast<const f32x4*>(xb + static_cast<long long>(idx) * a.ldx * 4) + lane;
-      if (NT) dst = __builtin_nontemporal_load(p);
-      else dst = *p;
+      if (BUF) {
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        const unsigned voff = static_cast<unsigned>(idx) * static_cast<unsigned>(a.ldx * 4) + static_cast<unsigned>(lane) * 16u;
+        dst = __builtin_bit_cast(f32x4, static_cast<u32x4_t>(__builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, SG_FUSED_ROWPOLICY)));
+      } else {
+        const f32x4* p = reinterpret_cast<const f32x4*>(xb + static_cast<long long>(idx) * a.ldx * 4) + lane;
+        if (NT) dst = __builtin_nontemporal_load(p);
+        else dst = *p;
+      }
     };
 
 #if SG_FUSED_DIRECT
@@ -909,12 +922,13 @@ SG_API size_t sg_agg_fused_workspace_bytes(int32_t num_links) {
 // weights[r]: trans_w = 0 -> (256 out, 256 in) row-major with leading dimension ldw (B_r = W_r^T); trans_w = 1 -> (256 in, 256 out)
 // (B_r = W_r).  biases (host array of R device pointers) and rowsum may be null (no bias term).  zsave (n_dst, ldz) receives the
 // fp32 aggregates [r * 256 + k] when not null.  f_*: the level-major plan of sg_agg_fused_plan_build_hip; tile_order may be null.
+// n_src: rows of x (every index of the plan is below it), or 0 when unknown.
 SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, const float* x, int64_t ldx,
                             const float* const* weights, int64_t ldw, int trans_w, const float* const* biases,
                             const float* rowsum, const int32_t* f_ptr, const int32_t* f_idx, const float* f_w,
-                            const int32_t* tile_order, int64_t n_dst, int32_t num_links, int64_t nnz, int64_t in_dim,
-                            int64_t out_dim, int act, float slope, int nt_loads, void* workspace, size_t workspace_bytes,
-                            void* stream) {
+                            const int32_t* tile_order, int64_t n_dst, int64_t n_src, int32_t num_links, int64_t nnz,
+                            int64_t in_dim, int64_t out_dim, int act, float slope, int nt_loads, void* workspace,
+                            size_t workspace_bytes, void* stream) {
   if (!sg_agg_fused_supported(in_dim, out_dim, num_links))
     return fail(SG_ERR_UNSUPPORTED, "fused aggregation handles in_dim = out_dim = 256 (got %lld, %lld)", (long long)in_dim, (long long)out_dim);
   if (n_dst == 0) return SG_OK;
@@ -962,8 +976,17 @@ SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (fused::GW + fused::MW)), fused::SMEM, st, a);
   };
   const long rec = fused::prof_begin(st, nnz, zsave ? 1 : 0);
-  if (zsave) { if (nt_loads) launch(fused::agg_contract_kernel<true, true>); else launch(fused::agg_contract_kernel<true, false>); }
-  else { if (nt_loads) launch(fused::agg_contract_kernel<false, true>); else launch(fused::agg_contract_kernel<false, false>); }
+  // rows of x through 32-bit buffer offsets when every row ends below 4 GB (n_src = 0: extent unknown, 64-bit addresses)
+  const bool buf = !nt_loads && n_src > 0 && (n_src - 1) * ldx * 4 + fused::KD * 4 <= 0xffffffffll;
+  if (zsave) {
+    if (nt_loads) launch(fused::agg_contract_kernel<true, true, false>);
+    else if (buf) launch(fused::agg_contract_kernel<true, false, true>);
+    else launch(fused::agg_contract_kernel<true, false, false>);
+  } else {
+    if (nt_loads) launch(fused::agg_contract_kernel<false, true, false>);
+    else if (buf) launch(fused::agg_contract_kernel<false, false, true>);
+    else launch(fused::agg_contract_kernel<false, false, false>);
+  }
   fused::prof_end(rec, st);
   return check_launch("fused::agg_contract_kernel");
 }

@@ -433,7 +433,7 @@ SG_API int sg_multilink_agg_fwd_hip(float* out, void* saved, const float* x, con
     const sg_fused_plan& fp = plan->fused[0];
     if (d.saves_z && !saved) return fail(SG_ERR_INVALID, "the fused order needs the `saved` buffer here (sg_multilink_agg_saved_bytes)");
     return sg_agg_fused_hip(out, d.U, d.saves_z ? static_cast<float*>(saved) : nullptr, d.R * d.D, x, d.D, weights, d.D, 0, biases,
-                            plan->rowsum, fp.f_ptr, fp.f_idx, fp.f_w, fp.tile_order, d.n_dst, d.R, d.nnz, d.D, d.U, act, slope,
+                            plan->rowsum, fp.f_ptr, fp.f_idx, fp.f_w, fp.tile_order, d.n_dst, d.n_src, d.R, d.nnz, d.D, d.U, act, slope,
                             fused_nt(), scratch, L.scratch_bytes, stream);
   }
 
@@ -516,7 +516,7 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
       if (dx) {
         const sg_fused_plan& fp = plan->fused[1];
         SG_TRY(sg_agg_fused_hip(dx, d.D, nullptr, 0, dpre, d.U, weights, d.D, 1, nullptr, nullptr, fp.f_ptr, fp.f_idx, fp.f_w,
-                                fp.tile_order, d.n_src, d.R, d.nnz, d.U, d.D, SG_ACT_NONE, 0.f, fused_nt(), scratch,
+                                fp.tile_order, d.n_src, d.n_dst, d.R, d.nnz, d.U, d.D, SG_ACT_NONE, 0.f, fused_nt(), scratch,
                                 L.scratch_bytes, stream));
       }
       float* dwext = dwcat;
@@ -555,7 +555,7 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
     if (dx) {
       const sg_fused_plan& fp = plan->fused[1];
       SG_TRY(sg_agg_fused_hip(dx, d.D, want_w ? dh : nullptr, d.RU, dpre, d.U, weights, d.D, 1, nullptr, nullptr, fp.f_ptr,
-                              fp.f_idx, fp.f_w, fp.tile_order, d.n_src, d.R, d.nnz, d.U, d.D, SG_ACT_NONE, 0.f, fused_nt(),
+                              fp.f_idx, fp.f_w, fp.tile_order, d.n_src, d.n_dst, d.R, d.nnz, d.U, d.D, SG_ACT_NONE, 0.f, fused_nt(),
                               scratch, L.scratch_bytes, stream));
     } else if (want_w) {
       SG_TRY(gather_view(plan, SG_VIEW_T_IDX_T, dh, d.R, d.RU, dpre, 1, d.U, plan->t_w, plan->t_idx, plan->t_indptr,

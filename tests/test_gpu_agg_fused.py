@@ -148,8 +148,8 @@ def test_fused_kernel_raw_c_abi_rows_of_other_pitch_and_saved_aggregates():
         zs = torch.full((n_dst, R * D + 128), -7.0, device=dev)
         ws, wsn = L.workspace(lib.sg_agg_fused_workspace_bytes(R), dev)
         L.check(lib.sg_agg_fused_hip(L.ptr(out), out.shape[1], L.ptr(zs), zs.shape[1], L.ptr(x), xbig.shape[1], ops._ptr_array(Ws), D,
-                                     1, None, None, L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), L.ptr(order), n_dst, R, nnz, D, D, 0,
-                                     0.0, 0, L.ptr(ws), wsn, L.stream_ptr()), "fused")
+                                     1, None, None, L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), L.ptr(order), n_dst, n_src if wts is w else 0, R, nnz,
+                                     D, D, 0, 0.0, 0, L.ptr(ws), wsn, L.stream_ptr()), "fused")      # second run: row extent unknown
         seg = torch.repeat_interleave(torch.arange(n_dst * R, device=dev), (indptr[1:] - indptr[:-1]).long())
         Z = torch.zeros(n_dst * R, D, dtype=torch.float64, device=dev)
         Z.index_add_(0, seg, x.double()[idx.long()] * wts.double()[:, None])
@@ -167,10 +167,10 @@ def test_fused_kernel_raw_c_abi_rows_of_other_pitch_and_saved_aggregates():
     ws, wsn = L.workspace(lib.sg_agg_fused_workspace_bytes(R), dev)
     out = torch.empty(n_dst, D, device=dev)
     rc = lib.sg_agg_fused_hip(L.ptr(out), D, None, 0, L.ptr(x), xbig.shape[1], ops._ptr_array(Ws), D, 0, None, None, L.ptr(f_ptr),
-                              L.ptr(f_idx), L.ptr(f_w), None, n_dst, R, nnz, 128, D, 0, 0.0, 0, L.ptr(ws), wsn, L.stream_ptr())
+                              L.ptr(f_idx), L.ptr(f_w), None, n_dst, n_src, R, nnz, 128, D, 0, 0.0, 0, L.ptr(ws), wsn, L.stream_ptr())
     assert rc == -2 and b"256" in lib.sg_last_error()          # SG_ERR_UNSUPPORTED
     rc = lib.sg_agg_fused_hip(L.ptr(out), D, None, 0, L.ptr(x), xbig.shape[1], ops._ptr_array(Ws), D, 0, None, None, L.ptr(f_ptr),
-                              L.ptr(f_idx), L.ptr(f_w), None, n_dst, R, nnz, D, D, 0, 0.0, 0, L.ptr(ws), ctypes.c_size_t(16),
+                              L.ptr(f_idx), L.ptr(f_w), None, n_dst, n_src, R, nnz, D, D, 0, 0.0, 0, L.ptr(ws), ctypes.c_size_t(16),
                               L.stream_ptr())
     assert rc < 0 and b"workspace" in lib.sg_last_error()
 
@@ -225,8 +225,8 @@ def test_fused_kernel_on_heavy_tailed_random_graphs():
         zs = torch.full((n_dst, R * D), -7.0, device=dev)
         ws, wsn = L.workspace(lib.sg_agg_fused_workspace_bytes(R), dev)
         L.check(lib.sg_agg_fused_hip(L.ptr(out), D, L.ptr(zs), R * D, L.ptr(x), D, ops._ptr_array(Ws), D, trans, ops._ptr_array(bs),
-                                     L.ptr(rs.float().contiguous()), L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), L.ptr(order), n_dst, R,
-                                     nnz, D, D, 0, 0.0, 0, L.ptr(ws), wsn, L.stream_ptr()), "fused")
+                                     L.ptr(rs.float().contiguous()), L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), L.ptr(order), n_dst,
+                                     n_src if case % 3 else 0, R, nnz, D, D, 0, 0.0, 0, L.ptr(ws), wsn, L.stream_ptr()), "fused")
         err = float(((out.double() - ref).abs() / mag.clamp_min(1e-30)).max())
         zerr = float((zs.double().view(n_dst, R, D) - Z).abs().max() / Z.abs().max().clamp_min(1e-300))
         what = (case, n_dst, R, nnz, int((indptr[1:] - indptr[:-1]).max()))

@@ -59,7 +59,7 @@ def fused(x, Ws, bs, rowsum, plan, order, n_dst, R, nnz, act, trans, zsave=None,
     wp = ops._ptr_array(Ws)
     bp = ops._ptr_array(bs) if bs is not None else None
     L.check(lib.sg_agg_fused_hip(L.ptr(out), D, L.ptr(zsave), zsave.shape[1] if zsave is not None else 0, L.ptr(x), x.shape[1],
-                                 wp, D, trans, bp, L.ptr(rowsum), L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), L.ptr(order), n_dst, R,
+                                 wp, D, trans, bp, L.ptr(rowsum), L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), L.ptr(order), n_dst, x.shape[0], R,
                                  nnz, D, D, ops._act_id(act), 0.1, nt, L.ptr(ws), wsn, L.stream_ptr()), "sg_agg_fused_hip")
     return out
 
