@@ -164,6 +164,26 @@ __device__ __forceinline__ unsigned wave_or(unsigned v) {
   return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
 }
 
+// maximum of a NON-NEGATIVE float over the wave, on the bit patterns (they order like the values; a NaN pattern would sort above
+// infinity, but the callers' fmaxf has dropped NaNs already): unsigned max takes the DPP operand directly -- six instructions,
+// where fmaxf on a DPP move costs a move, the max and a canonicalising max per step.  One per emitted row: 20 M per launch.
+__device__ __forceinline__ float wave_max_bits(float f) {
+  unsigned v = __float_as_uint(f);
+  auto step = [&](auto ctrl, auto row_mask) __attribute__((always_inline)) {
+    const unsigned y = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), decltype(ctrl)::value,
+                                                                         decltype(row_mask)::value, 0xf, true));
+    v = v > y ? v : y;
+  };
+  using std::integral_constant;
+  step(integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});     // quad_perm [1,0,3,2]
+  step(integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});     // quad_perm [2,3,0,1]
+  step(integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});    // row_half_mirror
+  step(integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});    // row_mirror
+  step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});    // row_bcast:15
+  step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});    // row_bcast:31
+  return __uint_as_float(static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63)));
+}
+
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
@@ -338,14 +358,14 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
     // a finished row: row maximum -> scale -> two f16 planes in the item's LDS buffer (+ the fp32 row to zsave)
     auto emit = [&](const Ctx& c, int j, const f32x4& acc) __attribute__((always_inline)) {
       float mx = fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
-      mx = wave_max_nonneg(mx);
+      mx = wave_max_bits(mx);
       bool nonfinite = false;
       if (__builtin_expect(!(mx <= 3.402823466e38f), 0)) {
         nonfinite = true;
         float mf = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const float v = fabsf(acc[i]); mf = fmaxf(mf, v <= 3.402823466e38f ? v : 0.f); }
-        mx = wave_max_nonneg(mf);
+        mx = wave_max_bits(mf);
       }
       int e = 0;
       {
