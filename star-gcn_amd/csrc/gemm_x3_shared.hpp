@@ -41,11 +41,15 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // ends up with the maximum) instead of six dependent ds_bpermute round trips through the LDS pipe (~100+ cycles each
 // under load, and each `s_waitcnt lgkmcnt(0)` also waits for every other LDS operation of the wave).  fmaxf drops NaNs,
 // as the shuffle form did.
-__device__ __forceinline__ float wave_max_nonneg(float v) {
+__device__ __forceinline__ float wave_max_nonneg(float f) {
+  // on the BIT PATTERNS: non-negative floats order like unsigned integers (+inf above every finite value; the callers' fmaxf
+  // chains have dropped NaNs), and v_max_u32 takes the DPP operand directly -- one instruction per step, where fmaxf on a DPP
+  // move costs the move, the max and a canonicalising max
+  unsigned v = __float_as_uint(f);
   auto step = [&](auto ctrl, auto row_mask) __attribute__((always_inline)) {
-    const int y = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), decltype(ctrl)::value,
-                                              decltype(row_mask)::value, 0xf, false);
-    v = fmaxf(v, __int_as_float(y));
+    const unsigned y = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), decltype(ctrl)::value,
+                                                                         decltype(row_mask)::value, 0xf, true));
+    v = v > y ? v : y;
   };
   using std::integral_constant;
   step(integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});     // quad_perm [1,0,3,2]
@@ -54,7 +58,7 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
   step(integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});    // row_mirror: every lane holds its row's maximum
   step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});    // row_bcast:15 into rows 1 and 3
   step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});    // row_bcast:31 into rows 2 and 3
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return __uint_as_float(static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63)));
 }
 
 
