@@ -404,7 +404,7 @@ int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* const* db
  * (8b) aggregate -> contract in ONE kernel (csrc/agg_fused.hip): the aggregation of (8) without its R-expanded
  *     intermediate.  Reference: the same MultiLinkGCNAggregator.hybrid_forward (aggregators.py:141-160: R FullyConnected
  *     outputs written and re-read by R seg_weighted_pool ops).
- *        out (n_dst, ldo) = act( sum_r (A_r x) B_r + sum_r rowsum[:, r] b_r )        x (n_src, ldx), 256 wide; out 256 wide
+ *        out (n_dst, ldo) = act( sum_r (A_r x) B_r + sum_r rowsum[:, r] b_r )        x (n_src, ldx), <= 256 wide; out <= 256 wide
  *     A workgroup owns 64 destination rows; per level the aggregate lives as two f16 planes in LDS and is multiplied by
  *     B_r on the matrix cores (three f16 MFMAs per product, error model of sg_gemm_backend 3 with one scale per
  *     (row, level) of the aggregate and per (level, 32 output columns) of B_r) while the next level is gathered.
@@ -434,6 +434,23 @@ int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, const f
                      int64_t in_dim, int64_t out_dim, int act, float slope, int nt_loads, void* workspace,
                      size_t workspace_bytes, void* stream);      /* n_src: rows of x, or 0 = unknown (rows are then addressed
                                                                   * with 64-bit pointers instead of 32-bit buffer offsets) */
+/* The general form (round 6): rows of 4 .. 256 floats (multiple of 4) x 1 .. 256 output columns per level -- the reference's own
+ * widths (EMBED.UNITS 32 / 64 -> GCN.AGG.UNITS 250, experiments/cfg, the yml files) -- and both accumulations of
+ * MultiLinkGCNAggregator (aggregators.py:79-81, 151-159):
+ *     accum = SG_ACCUM_STACK: out (n_dst, ldo >= R * out_dim), column block r = act( (A_r x) B_r + rowsum[:, r] b_r )
+ *     x_level_stride: level r gathers its rows from x + r * x_level_stride floats (multiple of 4): the data gradient of 'stack',
+ *                     where level r reads column block r of the output gradient (accum = SG_ACCUM_SUM there: dx sums the levels)
+ *     in_dim: floats per gathered row that exist in memory; k_valid <= in_dim: the contraction length present in the weights
+ *             (rows padded to a multiple of 4 by the caller: the padding must be finite, the planes beyond k_valid are zero)
+ *     zsave (n_dst, ldz): level r's fp32 aggregate at [r * in_dim, (r + 1) * in_dim).
+ * The kernel is built for 256 x 256 tiles: narrower rows leave gather lanes idle and narrower outputs multiply zero-padded
+ * planes -- supported and exact, not tuned; SG_ORDER_AUTO routes only 256 -> 256 'sum' here. */
+int sg_agg_fused2_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, const float* x, int64_t ldx, int64_t x_level_stride,
+                      const float* const* weights, int64_t ldw, int trans_w, int64_t k_valid, const float* const* biases,
+                      const float* rowsum, const int32_t* f_ptr, const int32_t* f_idx, const float* f_w,
+                      const int32_t* tile_order, int64_t n_dst, int64_t n_src, int32_t num_links, int64_t nnz,
+                      int64_t in_dim, int64_t out_dim, int accum, int act, float slope, int nt_loads, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* measurement aid for bench.py, as sg_gather_profile_*: HIP events around every fused launch on its own stream.  read():
  * (elapsed ms, edges, 1 when the launch also wrote the aggregates) per launch, in launch order; clears the records. */
 int sg_agg_fused_profile_enable(int on);

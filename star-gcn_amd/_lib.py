@@ -143,6 +143,10 @@ _SIGS = {
     "sg_agg_fused_workspace_bytes": (_SZ, [_c.c_int32]),
     "sg_agg_fused_hip": (_INT, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _INT, _P, _P, _P, _P, _P, _P, _I64, _I64, _c.c_int32,
                                 _I64, _I64, _I64, _INT, _F32, _INT, _P, _SZ, _P]),
+    # out ldo zsave ldz x ldx x_level_stride weights ldw trans_w k_valid biases rowsum f_ptr f_idx f_w tile_order n_dst n_src R nnz
+    # in_dim out_dim accum act slope nt_loads workspace bytes stream
+    "sg_agg_fused2_hip": (_INT, [_P, _I64, _P, _I64, _P, _I64, _I64, _P, _I64, _INT, _I64, _P, _P, _P, _P, _P, _P, _I64, _I64,
+                                 _c.c_int32, _I64, _I64, _I64, _INT, _INT, _F32, _INT, _P, _SZ, _P]),
     "sg_agg_fused_profile_enable": (_INT, [_INT]),
     "sg_agg_fused_profile_read": (_I64, [_P, _P, _P, _I64]),
 }

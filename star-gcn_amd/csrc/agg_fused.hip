@@ -144,6 +144,11 @@ struct Args {
   float* zsave;                // (n_dst, ldz) fp32 aggregates [r KD + k], or null
   long long ldz;
   int n_dst, n_tiles, R;
+  int in_dim;                  // floats per gathered row that exist in memory (multiple of 4, <= KD); the lanes beyond read nothing
+  int out_dim;                 // output columns written per level (<= ND); B's planes are zero beyond
+  int stack;                   // 1: accum 'stack' -- every level's product (+ its own bias term, activation) goes to its own column block
+                               //    [r * out_dim, (r + 1) * out_dim) of `out`; 0: the levels are summed (accum 'sum')
+  long long x_lstride;         // level r gathers from x + r * x_lstride (the data gradient of 'stack': level r reads its own column block)
   int act;
   float slope;
   int ablate;                  // timing experiments only (SG_FUSED_ABLATE): 1 = no matrix work, 2 = every row load reads row 0, 64 = every level's B planes = level 0's
@@ -201,7 +206,10 @@ struct Ctx {                    // one (item = tile x level, G wave): the rows a
   int split;                    // SG_FUSED_EVEN: tail row | head row << 8 | first wave of the head row << 16 (row 64 = none) | empty share << 24
 };
 
-template <bool ZSAVE, bool NT, bool BUF>
+// GEN = false: the shape the kernel is built and tuned for -- 256-float rows, 256 output columns, accum 'sum' (in_dim, out_dim,
+// stack, x_lstride of Args are not read; the code is the round-5 kernel instruction for instruction).  GEN = true: any supported
+// widths, 'stack', level-strided rows (correct and deterministic, not tuned: the compiler spills in this instantiation).
+template <bool ZSAVE, bool NT, bool BUF, bool GEN>
 __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   float* sinv = reinterpret_cast<float*>(smem + 2 * ZBUF);       // [buffer][row] 2^-e of the row's planes
@@ -319,19 +327,26 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
     // offset per lane instead of a 64-bit address: fewer address instructions on the issue-bound gather waves) with sc0 (no L1
     // allocation for rows nobody re-reads).  Measured, profiles/r5_fused_kernel.md section 8: 21.2 -> 20.5 ms into users; nt 23-25.
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, BUF ? 0xffffffff : 0, 0x00020000);
-    auto load_row = [&](f32x4& dst, int idx) __attribute__((always_inline)) {
+    // Rows narrower than KD (in_dim < 256): the lanes past the row's end re-read its last float4 (a valid address, no branch around
+    // the load) and their sums are zeroed when the row is emitted.  `roff`: byte offset of the level's column block (x_lstride).
+    const bool lane_live = GEN ? lane * 4 < a.in_dim : true;
+    const unsigned lane_off = static_cast<unsigned>(GEN ? min(lane, (a.in_dim >> 2) - 1) : lane) * 16u;
+    const int zdim = GEN ? a.in_dim : KD;             // width of a level's block in zsave
+    auto load_row = [&](f32x4& dst, int idx, unsigned roff) __attribute__((always_inline)) {
       if (a.ablate & 2) idx = 0;        // (timing experiment: every load hits the same row -- no control flow around the load,
                                         //  the compiler must keep counting the outstanding loads)
+      if (!GEN) roff = 0u;
       if (BUF) {
         typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-        const unsigned voff = static_cast<unsigned>(idx) * static_cast<unsigned>(a.ldx * 4) + static_cast<unsigned>(lane) * 16u;
+        const unsigned voff = static_cast<unsigned>(idx) * static_cast<unsigned>(a.ldx * 4) + lane_off + roff;
         dst = __builtin_bit_cast(f32x4, static_cast<u32x4_t>(__builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, SG_FUSED_ROWPOLICY)));
       } else {
-        const f32x4* p = reinterpret_cast<const f32x4*>(xb + static_cast<long long>(idx) * a.ldx * 4) + lane;
+        const f32x4* p = reinterpret_cast<const f32x4*>(xb + static_cast<long long>(idx) * a.ldx * 4 + roff + lane_off);
         if (NT) dst = __builtin_nontemporal_load(p);
         else dst = *p;
       }
     };
+    const unsigned lstride4 = GEN ? static_cast<unsigned>(a.x_lstride * 4) : 0u;
 
 #if SG_FUSED_DIRECT
     // the exponent a row's planes are written with at this level, and the bookkeeping of the row's unit (see UNITS above)
@@ -356,7 +371,9 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
     };
 #endif
     // a finished row: row maximum -> scale -> two f16 planes in the item's LDS buffer (+ the fp32 row to zsave)
-    auto emit = [&](const Ctx& c, int j, const f32x4& acc) __attribute__((always_inline)) {
+    auto emit = [&](const Ctx& c, int j, const f32x4& acc_in) __attribute__((always_inline)) {
+      f32x4 acc = acc_in;
+      if (GEN && !lane_live) acc = f32x4{0.f, 0.f, 0.f, 0.f};
       float mx = fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
       mx = wave_max_bits(mx);
       bool nonfinite = false;
@@ -399,8 +416,8 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       if (lane == 0) sinv[(c.it & 1) * TM + j] = __uint_as_float(static_cast<unsigned>(127 - e) << 23);
       if (ZSAVE) {
         const long long row = static_cast<long long>(tile_of(c.tile)) * TM + j;
-        if (row < a.n_dst)
-          __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.zsave + row * a.ldz + static_cast<long long>(c.r) * KD) + lane);
+        if (row < a.n_dst && lane_live)
+          __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.zsave + row * a.ldz + static_cast<long long>(c.r) * zdim) + lane);
       }
     };
     auto emit_zero = [&](const Ctx& c, int j) __attribute__((always_inline)) {
@@ -416,8 +433,8 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       if (ZSAVE) {
         const long long row = static_cast<long long>(tile_of(c.tile)) * TM + j;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        if (row < a.n_dst)
-          __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(a.zsave + row * a.ldz + static_cast<long long>(c.r) * KD) + lane);
+        if (row < a.n_dst && lane_live)
+          __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(a.zsave + row * a.ldz + static_cast<long long>(c.r) * zdim) + lane);
       }
     };
 
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
       const int gb = cI.e_lo + giI * NB;
       wv_cur = (gb + lane < cI.e_hi) ? mI_w : 0.f;
 #pragma unroll
-      for (int k = 0; k < NB; ++k) load_row(x[k], __builtin_amdgcn_readlane(mI_idx, k));
+      for (int k = 0; k < NB; ++k) load_row(x[k], __builtin_amdgcn_readlane(mI_idx, k), static_cast<unsigned>(cI.r) * lstride4);
       end_cur = end_mask(cI, giI);
     }
     Ctx cC = cI;
@@ -483,6 +500,7 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
 #endif
       }
       const int gbI = cI.e_lo + giI * NB;
+      const unsigned roffI = static_cast<unsigned>(cI.r) * lstride4;
       wv_nxt = (gbI + lane < cI.e_hi) ? mI_w : 0.f;
       // a row's edges are summed group by group (NB edges in `part`, then `part` into the row's sum): the rounding error of a
       // 50 000-edge row grows with sqrt(edges / NB) instead of sqrt(edges) (the chunked gather of seg_gather.hip does the same)
@@ -508,7 +526,7 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
           part = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // I: edge k of group giI into the registers just released
-        load_row(x[k], __builtin_amdgcn_readlane(mI_idx, k));
+        load_row(x[k], __builtin_amdgcn_readlane(mI_idx, k), roffI);
       }
       acc += part;
       end_nxt = end_mask(cI, giI);
@@ -599,6 +617,73 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
         af[i][p] = *reinterpret_cast<const f16x8*>(smem + buf * ZBUF + p * ZPLANE + (32 * i + l31) * ZROW + (ks * 2 + kh) * 16);
   };
   const bool has_bias = a.bias && a.rowsum;
+  // ---- a finished result: the tile's (accum 'sum': after the last level) or the level's ('stack': after every level) ----
+  auto finish = [&](int r, int it, int ti, long long row0) __attribute__((always_inline)) {
+#if SG_FUSED_DIRECT
+      {   // out of the last level's unit: 2^-e_row (its planes' scale) * 2^-e_B.  (SG_FUSED_DIRECT is written for 'sum' only.)
+        const int buf = it & 1;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float sb = a.wscale[(a.R - 1) * NJB + wn * NJ + j];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinv + buf * TM + 32 * i + 8 * g4 + 4 * kh);
+#pragma unroll
+              for (int v = 0; v < 4; ++v) acc[j][i][4 * g4 + v] = (acc[j][i][4 * g4 + v] * s4[v]) * sb;
+            }
+        }
+      }
+#endif
+      // bias term, activation, store.
+      // (the assembly loads above are invisible to the compiler: none may be in flight when it re-uses their registers for the
+      //  addresses below.  The last k step's wait already drained them on this path; a build whose compiler peeled the level loop
+      //  -- SG_FUSED_DIRECT with `if (r > 0)` around the rescale -- faulted here without this wait.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (has_bias) {
+        const float* rs = rs_lds + (ti & 1) * TM * a.R + (4 * kh) * a.R;
+        for (int rb = (GEN && a.stack) ? r : 0; rb <= r; ++rb) {        // 'sum': every level's bias rides on its support row sums; 'stack': this level's
+          float bv[NJ];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) bv[j] = a.bias[rb * ND + (wn * NJ + j) * 32 + l31];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const float sv = rs[(32 * i + (q & 3) + 8 * (q >> 2)) * a.R + rb];
+#pragma unroll
+              for (int j = 0; j < NJ; ++j) acc[j][i][q] = __builtin_fmaf(sv, bv[j], acc[j][i][q]);
+            }
+        }
+      }
+      const long long coff = (GEN && a.stack) ? static_cast<long long>(r) * a.out_dim : 0;
+      auto store_tile = [&](auto actc) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const long long row = row0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * kh;
+            if (row < a.n_dst) {
+#pragma unroll
+              for (int j = 0; j < NJ; ++j) {
+                const int col = (wn * NJ + j) * 32 + l31;
+                if (!GEN || col < a.out_dim) a.out[row * a.ldo + coff + col] = f16x3::act_fn(acc[j][i][q], ACT, a.slope);
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j][i][q] = 0.f;
+          }
+      };
+      switch (a.act) {
+        case SG_ACT_LEAKY: store_tile(std::integral_constant<int, SG_ACT_LEAKY>{}); break;
+        case SG_ACT_RELU: store_tile(std::integral_constant<int, SG_ACT_RELU>{}); break;
+        case SG_ACT_SIGMOID: store_tile(std::integral_constant<int, SG_ACT_SIGMOID>{}); break;
+        case SG_ACT_TANH: store_tile(std::integral_constant<int, SG_ACT_TANH>{}); break;
+        default: store_tile(std::integral_constant<int, SG_ACT_NONE>{}); break;
+      }
+  };
   int it = 0;
   for (int ti = 0; ti < n_my; ++ti) {
     const int tile = tile_of(slot_of(ti));
@@ -687,68 +772,9 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
           }
 #endif
       }
+      if (GEN && (a.stack || r + 1 == a.R)) finish(r, it, ti, row0);
     }
-#if SG_FUSED_DIRECT
-    {   // out of the last level's unit: 2^-e_row (its planes' scale) * 2^-e_B
-      const int buf = (it - 1) & 1;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const float sb = a.wscale[(a.R - 1) * NJB + wn * NJ + j];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinv + buf * TM + 32 * i + 8 * g4 + 4 * kh);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[j][i][4 * g4 + v] = (acc[j][i][4 * g4 + v] * s4[v]) * sb;
-          }
-      }
-    }
-#endif
-    // ---- the tile's result: bias term, activation, store ----
-    // (the assembly loads above are invisible to the compiler: none may be in flight when it re-uses their registers for the
-    //  addresses below.  The last k step's wait already drained them on this path; a build whose compiler peeled the level loop
-    //  -- SG_FUSED_DIRECT with `if (r > 0)` around the rescale -- faulted here without this wait.)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (has_bias) {
-      const float* rs = rs_lds + (ti & 1) * TM * a.R + (4 * kh) * a.R;
-      for (int r = 0; r < a.R; ++r) {
-        float bv[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bv[j] = a.bias[r * ND + (wn * NJ + j) * 32 + l31];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const float s = rs[(32 * i + (q & 3) + 8 * (q >> 2)) * a.R + r];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j][i][q] = __builtin_fmaf(s, bv[j], acc[j][i][q]);
-          }
-      }
-    }
-    auto store_tile = [&](auto actc) __attribute__((always_inline)) {
-      constexpr int ACT = decltype(actc)::value;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const long long row = row0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * kh;
-          if (row < a.n_dst) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-              a.out[row * a.ldo + (wn * NJ + j) * 32 + l31] = f16x3::act_fn(acc[j][i][q], ACT, a.slope);
-          }
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[j][i][q] = 0.f;
-        }
-    };
-    switch (a.act) {
-      case SG_ACT_LEAKY: store_tile(std::integral_constant<int, SG_ACT_LEAKY>{}); break;
-      case SG_ACT_RELU: store_tile(std::integral_constant<int, SG_ACT_RELU>{}); break;
-      case SG_ACT_SIGMOID: store_tile(std::integral_constant<int, SG_ACT_SIGMOID>{}); break;
-      case SG_ACT_TANH: store_tile(std::integral_constant<int, SG_ACT_TANH>{}); break;
-      default: store_tile(std::integral_constant<int, SG_ACT_NONE>{}); break;
-    }
+    if (!GEN) finish(a.R - 1, it - 1, ti, row0);
   }
 }
 
@@ -759,8 +785,10 @@ struct WTable {
   const float* w[SG_MAX_LINKS];
   const float* b[SG_MAX_LINKS];
 };
+// kdim / ndim: the contraction length and the output width that exist (<= KD / ND); the planes are zero beyond them.
 __global__ __launch_bounds__(256) void split_w_kernel(char* __restrict__ planes, float* __restrict__ wscale, int* __restrict__ wexp,
-                                                      float* __restrict__ bias_pack, const WTable tab, long long ldw, int trans) {
+                                                      float* __restrict__ bias_pack, const WTable tab, long long ldw, int trans,
+                                                      int kdim, int ndim) {
   __shared__ float tile[32][KD + 1];
   __shared__ float wmax[4];
   const int r = blockIdx.x / NJB, jb = blockIdx.x - r * NJB;
@@ -770,14 +798,14 @@ __global__ __launch_bounds__(256) void split_w_kernel(char* __restrict__ planes,
   if (!trans) {
     for (int e = t; e < 32 * KD; e += 256) {
       const int n = e / KD, k = e - n * KD;
-      const float v = W[static_cast<long long>(32 * jb + n) * ldw + k];
+      const float v = (32 * jb + n < ndim && k < kdim) ? W[static_cast<long long>(32 * jb + n) * ldw + k] : 0.f;
       tile[n][k] = v;
       m = fmaxf(m, fabsf(v) <= 3.402823466e38f ? fabsf(v) : 0.f);
     }
   } else {
     for (int e = t; e < 32 * KD; e += 256) {
       const int k = e / 32, n = e - k * 32;
-      const float v = W[static_cast<long long>(k) * ldw + 32 * jb + n];
+      const float v = (32 * jb + n < ndim && k < kdim) ? W[static_cast<long long>(k) * ldw + 32 * jb + n] : 0.f;
       tile[n][k] = v;
       m = fmaxf(m, fabsf(v) <= 3.402823466e38f ? fabsf(v) : 0.f);
     }
@@ -785,7 +813,7 @@ __global__ __launch_bounds__(256) void split_w_kernel(char* __restrict__ planes,
 #if SG_FUSED_DIRECT
   // one exponent per LEVEL (the matrix waves accumulate across the column blocks' products in one unit per row): the maximum of
   // the whole 256 x 256 matrix, recomputed by each of the level's eight workgroups
-  for (int e2 = t; e2 < KD * ND; e2 += 256) {
+  for (int e2 = t; e2 < KD * ND; e2 += 256) {      // (SG_FUSED_DIRECT is written for full 256 x 256 levels)
     const float v = fabsf(W[static_cast<long long>(e2 >> 8) * ldw + (e2 & 255)]);
     m = fmaxf(m, v <= 3.402823466e38f ? v : 0.f);
   }
@@ -825,7 +853,7 @@ __global__ __launch_bounds__(256) void split_w_kernel(char* __restrict__ planes,
   }
   if (t == 0) wscale[r * NJB + jb] = __uint_as_float(static_cast<unsigned>(127 - e) << 23);
   if (t == 0 && jb == 0 && wexp) wexp[r] = e;
-  if (bias_pack && t < 32) bias_pack[r * ND + 32 * jb + t] = tab.b[r] ? tab.b[r][32 * jb + t] : 0.f;
+  if (bias_pack && t < 32) bias_pack[r * ND + 32 * jb + t] = (tab.b[r] && 32 * jb + t < ndim) ? tab.b[r][32 * jb + t] : 0.f;
 }
 
 // ---- f-plan: one workgroup per launch slot (tile = tile_order[slot], or the slot itself).  The tile's edges keep their
@@ -905,8 +933,12 @@ using namespace sg;
 
 SG_API int64_t sg_agg_fused_tiles(int64_t n_dst) { return (n_dst + fused::TM - 1) / fused::TM; }
 
+// Widths the kernel handles: gathered rows of 4 .. 256 floats in steps of 4 (16-byte lanes), 1 .. 256 output columns per level.
+// It is BUILT for 256 x 256 (KD, ND): narrower rows leave gather lanes idle and narrower outputs multiply zero-padded planes, so
+// `auto` routes only the 256-wide 'sum' case here (multilink.hip); the other widths are for callers who ask for the order.
 SG_API int sg_agg_fused_supported(int64_t in_dim, int64_t out_dim, int32_t num_links) {
-  return in_dim == fused::KD && out_dim == fused::ND && num_links >= 1 && num_links <= SG_MAX_LINKS;
+  return in_dim >= 4 && in_dim <= fused::KD && in_dim % 4 == 0 && out_dim >= 1 && out_dim <= fused::ND && num_links >= 1 &&
+         num_links <= SG_MAX_LINKS;
 }
 
 // f_ptr: tiles * R * 65 entries; f_idx, f_w (, f_pos: position of every edge in the source order, may be null): nnz.
@@ -949,8 +981,30 @@ SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, 
                             const int32_t* tile_order, int64_t n_dst, int64_t n_src, int32_t num_links, int64_t nnz,
                             int64_t in_dim, int64_t out_dim, int act, float slope, int nt_loads, void* workspace,
                             size_t workspace_bytes, void* stream) {
+  return sg_agg_fused2_hip(out, ldo, zsave, ldz, x, ldx, 0, weights, ldw, trans_w, in_dim, biases, rowsum, f_ptr, f_idx, f_w, tile_order,
+                           n_dst, n_src, num_links, nnz, in_dim, out_dim, SG_ACCUM_SUM, act, slope, nt_loads, workspace, workspace_bytes,
+                           stream);
+}
+
+// The general form.  accum = SG_ACCUM_STACK: out (n_dst, ldo >= R * out_dim) receives act( (A_r x) B_r + rowsum[:, r] b_r ) in column
+// block r.  x_level_stride: level r gathers its rows from x + r * x_level_stride (floats) -- the data gradient of 'stack', where level
+// r reads column block r of the output gradient.  in_dim: floats per gathered row in memory (multiple of 4, <= 256); k_valid <= in_dim:
+// the contraction length that exists in the weights (a caller that pads its rows to a multiple of 4 passes the true width here; the
+// padding columns of x must be finite).  zsave (n_dst, ldz): level r's aggregate at [r * in_dim, (r + 1) * in_dim).
+SG_API int sg_agg_fused2_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, const float* x, int64_t ldx, int64_t x_level_stride,
+                             const float* const* weights, int64_t ldw, int trans_w, int64_t k_valid, const float* const* biases,
+                             const float* rowsum, const int32_t* f_ptr, const int32_t* f_idx, const float* f_w,
+                             const int32_t* tile_order, int64_t n_dst, int64_t n_src, int32_t num_links, int64_t nnz,
+                             int64_t in_dim, int64_t out_dim, int accum, int act, float slope, int nt_loads, void* workspace,
+                             size_t workspace_bytes, void* stream) {
   if (!sg_agg_fused_supported(in_dim, out_dim, num_links))
-    return fail(SG_ERR_UNSUPPORTED, "fused aggregation handles in_dim = out_dim = 256 (got %lld, %lld)", (long long)in_dim, (long long)out_dim);
+    return fail(SG_ERR_UNSUPPORTED, "fused aggregation handles rows of 4 .. 256 floats (multiple of 4) and 1 .. 256 output columns per "
+                                    "level (got %lld, %lld)", (long long)in_dim, (long long)out_dim);
+  if (accum != SG_ACCUM_SUM && accum != SG_ACCUM_STACK) return fail(SG_ERR_INVALID, "accum %d", accum);
+  if (k_valid < 1 || k_valid > in_dim || x_level_stride < 0 || (x_level_stride & 3)) return fail(SG_ERR_INVALID, "k_valid / x_level_stride");
+#if SG_FUSED_DIRECT
+  if (accum != SG_ACCUM_SUM || in_dim != fused::KD || out_dim != fused::ND) return fail(SG_ERR_UNSUPPORTED, "SG_FUSED_DIRECT build: 256 x 256 'sum' only");
+#endif
   if (n_dst == 0) return SG_OK;
   if (nnz < 1) return fail(SG_ERR_UNSUPPORTED, "fused aggregation needs at least one edge");
   if (!out || !x || !weights || !f_ptr || !f_idx || !f_w) return fail(SG_ERR_INVALID, "null pointer argument");
@@ -973,7 +1027,8 @@ SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, 
   }
   const bool has_bias = biases && rowsum;
   hipLaunchKernelGGL(fused::split_w_kernel, dim3(static_cast<unsigned>(R * fused::NJB)), dim3(256), 0, st, planes, wscale, wexp,
-                     has_bias ? bias_pack : static_cast<float*>(nullptr), tab, static_cast<long long>(ldw), trans_w);
+                     has_bias ? bias_pack : static_cast<float*>(nullptr), tab, static_cast<long long>(ldw), trans_w,
+                     static_cast<int>(k_valid), static_cast<int>(out_dim));
   if (check_launch("fused::split_w_kernel") != SG_OK) return SG_ERR_HIP;
 
   fused::Args a{};
@@ -983,6 +1038,9 @@ SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, 
   a.bias = has_bias ? bias_pack : nullptr; a.rowsum = has_bias ? rowsum : nullptr;
   a.out = out; a.ldo = ldo; a.zsave = zsave; a.ldz = ldz;
   a.n_dst = static_cast<int>(n_dst); a.n_tiles = static_cast<int>(sg_agg_fused_tiles(n_dst)); a.R = num_links;
+  a.in_dim = static_cast<int>(in_dim); a.out_dim = static_cast<int>(out_dim);
+  a.stack = accum == SG_ACCUM_STACK ? 1 : 0;
+  a.x_lstride = x_level_stride;
   a.act = act; a.slope = slope;
   static const int ablate = [] { const char* e = getenv("SG_FUSED_ABLATE"); return e ? atoi(e) : 0; }();
   a.ablate = ablate;
@@ -997,15 +1055,20 @@ SG_API int sg_agg_fused_hip(float* out, int64_t ldo, float* zsave, int64_t ldz, 
   };
   const long rec = fused::prof_begin(st, nnz, zsave ? 1 : 0);
   // rows of x through 32-bit buffer offsets when every row ends below 4 GB (n_src = 0: extent unknown, 64-bit addresses)
-  const bool buf = !nt_loads && n_src > 0 && (n_src - 1) * ldx * 4 + fused::KD * 4 <= 0xffffffffll;
-  if (zsave) {
-    if (nt_loads) launch(fused::agg_contract_kernel<true, true, false>);
-    else if (buf) launch(fused::agg_contract_kernel<true, false, true>);
-    else launch(fused::agg_contract_kernel<true, false, false>);
+  const bool gen_nt = nt_loads && (in_dim != fused::KD || out_dim != fused::ND || accum == SG_ACCUM_STACK || x_level_stride != 0);
+  const bool buf = (!nt_loads || gen_nt) && n_src > 0 && ((n_src - 1) * ldx + (num_links - 1) * x_level_stride + in_dim) * 4 <= 0xffffffffll;
+  const bool gen = in_dim != fused::KD || out_dim != fused::ND || a.stack || x_level_stride != 0;
+  if (gen) {          // (nt_loads is a tuning aid of the 256-wide instantiation only)
+    if (zsave) { if (buf) launch(fused::agg_contract_kernel<true, false, true, true>); else launch(fused::agg_contract_kernel<true, false, false, true>); }
+    else { if (buf) launch(fused::agg_contract_kernel<false, false, true, true>); else launch(fused::agg_contract_kernel<false, false, false, true>); }
+  } else if (zsave) {
+    if (nt_loads) launch(fused::agg_contract_kernel<true, true, false, false>);
+    else if (buf) launch(fused::agg_contract_kernel<true, false, true, false>);
+    else launch(fused::agg_contract_kernel<true, false, false, false>);
   } else {
-    if (nt_loads) launch(fused::agg_contract_kernel<false, true, false>);
-    else if (buf) launch(fused::agg_contract_kernel<false, false, true>);
-    else launch(fused::agg_contract_kernel<false, false, false>);
+    if (nt_loads) launch(fused::agg_contract_kernel<false, true, false, false>);
+    else if (buf) launch(fused::agg_contract_kernel<false, false, true, false>);
+    else launch(fused::agg_contract_kernel<false, false, false, false>);
   }
   fused::prof_end(rec, st);
   return check_launch("fused::agg_contract_kernel");

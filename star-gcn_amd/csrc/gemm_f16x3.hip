@@ -1071,7 +1071,9 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
       GemmArgs o = h;
       fit_splits(o, static_cast<long long>(t128m) * t128n, 512);
       const int ktiles = (h.K + 31) / 32;
-      wide = wide_slices_ok(w) &&
+      // accumulate with one K slice: the wide kernel adds into C in place, so a fallback run behind it would add the product a
+      // second time -- those calls stay on the 128-wide kernel (with slices both kernels write partials and C is touched once)
+      wide = wide_slices_ok(w) && !(h.accumulate && w.splits <= 1) &&
              (variant == 8 || wide_pays(static_cast<long long>(t256m) * t256n * w.splits, w.splits > 1 ? w.tiles_per_split : ktiles,
                                         static_cast<long long>(t128m) * t128n * o.splits, o.splits > 1 ? o.tiles_per_split : ktiles));
       if (wide) {

@@ -39,13 +39,14 @@ __global__ void pack_cat_kernel(float* __restrict__ wcat, float* __restrict__ bc
     bcat[i] = b.p[r] ? b.p[r][i - static_cast<long long>(r) * U] : 0.f;
   }
 }
+// (Up: rows per level in dwcat -- U, or U rounded up to a multiple of 4 where the fused order padded its R-expanded gradient)
 __global__ void unpack_cat_kernel(MutPtrTable dw, MutPtrTable db, const float* __restrict__ dwcat,
-                                  const float* __restrict__ dbcat, int R, int U, int D) {
+                                  const float* __restrict__ dbcat, int R, int U, int D, int Up) {
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   const long long per = static_cast<long long>(U) * D;
   if (dwcat && i < per * R) {
     const int r = static_cast<int>(i / per);
-    if (dw.p[r]) dw.p[r][i - r * per] = dwcat[i];
+    if (dw.p[r]) dw.p[r][i - r * per] = dwcat[i + static_cast<long long>(r) * (Up - U) * D];
   }
   if (dbcat && i < static_cast<long long>(R) * U) {
     const int r = static_cast<int>(i / U);
@@ -105,9 +106,11 @@ __global__ void fill_rowsum_kernel(float* __restrict__ zext, const float* __rest
 // group's rows, the four groups are added through LDS and part[b][r][u] is written.  Pass 2 adds the P partials in order.
 // Bandwidth-bound on dpre (1.3 GB at the config-5 shard); deterministic.
 constexpr int kDbParts = 512;
+// dpre: row pitch ld; accum 'stack' (lstride > 0): level r reads its own column block, dpre[i, r * lstride + u].
 template <int RMAX>
 __global__ __launch_bounds__(1024) void bias_grad_partial_kernel(float* __restrict__ part, const float* __restrict__ rowsum,
-                                                                  const float* __restrict__ dpre, long long n, int R, int U) {
+                                                                  const float* __restrict__ dpre, long long n, int R, int U,
+                                                                  long long ld, int lstride) {
   __shared__ float s_rs[64 * RMAX];
   __shared__ float s_red[3][256];
   const int t = threadIdx.x, grp = t >> 8, col = t & 255;
@@ -124,10 +127,19 @@ __global__ __launch_bounds__(1024) void bias_grad_partial_kernel(float* __restri
     for (int e = t; e < rows * R; e += 1024) s_rs[(e / R) * RMAX + (e % R)] = rowsum[base * R + e];
     __syncthreads();
     if (u < U) {
+      if (lstride > 0) {                              // 'stack': one value per (row, level)
+        for (int j = grp; j < rows; j += 4) {
+          const float* rs = s_rs + j * RMAX;
+          const float* gp = dpre + (base + j) * ld + u;
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r)
+            if (r < R) acc[r] = fmaf(rs[r], gp[static_cast<long long>(r) * lstride], acc[r]);
+        }
+      } else
       for (int j = grp; j < rows; j += 16) {          // rows j, j + 4, j + 8, j + 12 of the batch in flight
         float g[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) g[q] = (j + 4 * q < rows) ? dpre[(base + j + 4 * q) * U + u] : 0.f;
+        for (int q = 0; q < 4; ++q) g[q] = (j + 4 * q < rows) ? dpre[(base + j + 4 * q) * ld + u] : 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float* rs = s_rs + ((j + 4 * q < rows) ? (j + 4 * q) : 0) * RMAX;
@@ -160,12 +172,41 @@ __global__ void bias_grad_final_kernel(float* __restrict__ db, const float* __re
   db[i] = s;
 }
 
+// dst[row, (col / U) * Up + col % U] = dout[row, col] * act'(out[row, col]) for col < W (= U or R U), zero in the padding columns
+// (the fused order rounds every level's width up to a multiple of 4 floats: its gather lanes hold one float4 each)
+__global__ void act_bwd_pitched_kernel(float* __restrict__ dst, long long dst_ld, const float* __restrict__ dout,
+                                       const float* __restrict__ out, long long n_rows, int W, int U, int Up, int act, float slope) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_rows * dst_ld) return;
+  const long long row = i / dst_ld;
+  const int pc = static_cast<int>(i - row * dst_ld), lvl = pc / Up, u = pc - lvl * Up;
+  float v = 0.f;
+  if (u < U) {
+    const long long src = row * W + static_cast<long long>(lvl) * U + u;
+    v = dout[src];
+    if (act != SG_ACT_NONE) {
+      const float y = out[src];
+      float g = 1.f;
+      switch (act) {
+        case SG_ACT_LEAKY: g = y > 0.f ? 1.f : slope; break;
+        case SG_ACT_RELU: g = y > 0.f ? 1.f : 0.f; break;
+        case SG_ACT_SIGMOID: g = y * (1.f - y); break;
+        case SG_ACT_TANH: g = 1.f - y * y; break;
+        default: break;
+      }
+      v *= g;
+    }
+  }
+  dst[i] = v;
+}
+
 inline unsigned blocks_for(long long n) { return static_cast<unsigned>((n + 255) / 256); }
 inline size_t al(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
 inline size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
 struct Dims {
   int64_t n_dst, n_src, nnz, D, U, ld, outw, RU;
+  int64_t Up, outw_p;  // fused order: U rounded up to a multiple of 4 (one float4 per gather lane) and the pitch of its dpre rows
   int R, order, stack;
   bool saves_z;       // fused order: the forward writes the aggregates (see fused_saves_z)
 };
@@ -197,7 +238,9 @@ bool fused_saves_z(const sg_multilink_plan* p) {
 // the order for these widths; AUTO prefers the fused kernel where the R-expanded matrix would cost HBM time
 int resolve_order2(const sg_multilink_plan* p, int order, int64_t in_dim, int64_t upl, int accum) {
   if (order != SG_ORDER_AUTO) return order;
-  if (accum == SG_ACCUM_SUM && p->nnz > 0 && p->n_dst > 0 && p->n_src > 0 && sg_agg_fused_supported(in_dim, upl, p->num_links)) {
+  // (the fused kernel is built and measured for 256 -> 256 'sum'; the other widths / 'stack' it handles are for callers who ask)
+  if (accum == SG_ACCUM_SUM && in_dim == 256 && upl == 256 && p->nnz > 0 && p->n_dst > 0 && p->n_src > 0 &&
+      sg_agg_fused_supported(in_dim, upl, p->num_links)) {
     const int mode = fused_mode();
     const int64_t small_side = p->n_src < p->n_dst ? p->n_src : p->n_dst;
     const int64_t big_side = p->n_src < p->n_dst ? p->n_dst : p->n_src;
@@ -229,17 +272,18 @@ int make_dims(Dims* d, const sg_multilink_plan* p, int64_t in_dim, int64_t upl, 
   d->n_dst = p->n_dst; d->n_src = p->n_src; d->nnz = p->nnz; d->D = in_dim; d->U = upl; d->R = p->num_links;
   d->order = resolve_order2(p, order, in_dim, upl, accum);
   if (d->order == SG_ORDER_FUSED) {
-    const bool can = accum == SG_ACCUM_SUM && p->nnz > 0 && sg_agg_fused_supported(in_dim, upl, p->num_links) &&
-                     has_fused(p, 0) && has_fused(p, 1);
+    const bool can = p->nnz > 0 && sg_agg_fused_supported(in_dim, upl, p->num_links) && has_fused(p, 0) && has_fused(p, 1);
     if (!can && order == SG_ORDER_AUTO) d->order = resolve_order(p, SG_ORDER_AUTO);     // a caller that attached no f-plans
     else if (!can)
-      return fail(SG_ERR_UNSUPPORTED, "SG_ORDER_FUSED needs accum 'sum', in_dim = units_per_level = 256, at least one edge and "
-                                      "plan->fused[0..1] (sg_agg_fused_plan_build_hip)");
+      return fail(SG_ERR_UNSUPPORTED, "SG_ORDER_FUSED needs in_dim in 4 .. 256 (multiple of 4), units_per_level in 1 .. 256, at least "
+                                      "one edge and plan->fused[0..1] (sg_agg_fused_plan_build_hip)");
   }
   d->stack = accum == SG_ACCUM_STACK;
   d->RU = d->R * upl;
   d->saves_z = d->order == SG_ORDER_FUSED && fused_saves_z(p);
   d->outw = d->stack ? d->RU : upl;
+  d->Up = (upl + 3) / 4 * 4;
+  d->outw_p = d->stack ? d->R * d->Up : d->Up;
   const int64_t used = d->R * in_dim + d->R;
   // row pitch of the R-expanded matrices (Zext / dZ): every level block of a row is gathered / scattered as one burst of
   // 4*D bytes, so when that burst is a multiple of 256 B the pitch is rounded to 256 B as well -- otherwise (pitch =
@@ -263,13 +307,16 @@ Layout make_layout(const Dims& d, bool backward) {
   if (d.order == SG_ORDER_FUSED) {
     sc = sg_agg_fused_workspace_bytes(d.R);
     if (backward) {
-      L.a = take(d.n_dst * d.outw * f);                                              // dpre
-      if (!d.saves_z) L.b = take(d.n_src * d.RU * f);                                // dH (written by the fused data gradient)
-      L.c = take((d.RU * d.D + d.RU) * f);                                           // dWcat | dbcat   (or dWext (U, R D) | dbcat)
-      sc = max2(sc, max2(d.saves_z ? 0 : sg_seg_weighted_pool_workspace_bytes(1, d.n_src * d.R, d.nnz, d.U),
-                         max2(d.saves_z ? sg_gemm_f32_workspace_bytes(d.U, d.R * d.D, d.n_dst, 1)
-                                        : sg_gemm_f32_workspace_bytes(d.RU, d.D, d.n_src, 1),
-                              static_cast<size_t>(kDbParts) * d.RU * f)));
+      L.a = take(d.n_dst * d.outw_p * f);                                            // dpre (levels padded to Up floats)
+      if (!d.saves_z) {
+        L.b = take(d.n_src * d.R * d.Up * f);                                        // dH (written by the fused data gradient)
+        L.wpack = take(d.n_src * d.D * f);                                           // stand-in dx when the caller wants only dW
+      }
+      L.c = take((d.R * d.Up * d.D + d.RU) * f);                                     // dWcat (R Up, D) | dbcat   (or dWext (U, R D) | dbcat)
+      const size_t gw = d.saves_z ? (d.stack ? sg_gemm_f32_workspace_bytes(d.U, d.D, d.n_dst, 1)
+                                             : sg_gemm_f32_workspace_bytes(d.U, d.R * d.D, d.n_dst, 1))
+                                  : sg_gemm_f32_workspace_bytes(d.R * d.Up, d.D, d.n_src, 1);
+      sc = max2(sc, max2(gw, static_cast<size_t>(kDbParts) * d.RU * f));
     }
   } else if (d.order == SG_ORDER_TRANSFORM_FIRST) {
     L.wpack = take(d.RU * d.D * f);
@@ -432,9 +479,9 @@ SG_API int sg_multilink_agg_fwd_hip(float* out, void* saved, const float* x, con
     if (biases && !plan->rowsum) return fail(SG_ERR_INVALID, "the fused order needs plan->rowsum for the bias term");
     const sg_fused_plan& fp = plan->fused[0];
     if (d.saves_z && !saved) return fail(SG_ERR_INVALID, "the fused order needs the `saved` buffer here (sg_multilink_agg_saved_bytes)");
-    return sg_agg_fused_hip(out, d.U, d.saves_z ? static_cast<float*>(saved) : nullptr, d.R * d.D, x, d.D, weights, d.D, 0, biases,
-                            plan->rowsum, fp.f_ptr, fp.f_idx, fp.f_w, fp.tile_order, d.n_dst, d.n_src, d.R, d.nnz, d.D, d.U, act, slope,
-                            fused_nt(), scratch, L.scratch_bytes, stream);
+    return sg_agg_fused2_hip(out, d.outw, d.saves_z ? static_cast<float*>(saved) : nullptr, d.R * d.D, x, d.D, 0, weights, d.D, 0, d.D,
+                             biases, plan->rowsum, fp.f_ptr, fp.f_idx, fp.f_w, fp.tile_order, d.n_dst, d.n_src, d.R, d.nnz, d.D, d.U,
+                             accum, act, slope, fused_nt(), scratch, L.scratch_bytes, stream);
   }
 
   if (d.order == SG_ORDER_TRANSFORM_FIRST) {
@@ -496,7 +543,8 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
   void* scratch = base + L.scratch;
   float* dpre_buf = reinterpret_cast<float*>(base + L.a);
   const float* dpre = dout;
-  if (act != SG_ACT_NONE && d.n_dst > 0) {
+  const bool repitch = d.order == SG_ORDER_FUSED && d.Up != d.U;      // the fused branch applies act' while it pads the levels
+  if (act != SG_ACT_NONE && d.n_dst > 0 && !repitch) {
     SG_TRY(sg_act_bwd_hip(dpre_buf, dout, out, d.n_dst * d.outw, act, slope, stream));
     dpre = dpre_buf;
   }
@@ -504,86 +552,86 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
   for (int r = 0; r < SG_MAX_LINKS; ++r) nob.p[r] = nullptr;
 
   if (d.order == SG_ORDER_FUSED) {
-    // dx[n] = sum_r (A_r^T dpre)[n] W_r in one kernel over the transposed plan, which also leaves dH = [A_r^T dpre]_r for
-    // the weight gradient dW_r = dH_r^T x; the bias gradient is db_r = sum_i rowsum[i, r] dpre[i] (= the column sums of dH_r)
+    // dx[n] = sum_r (A_r^T dpre_r)[n] W_r in one kernel over the transposed plan (dpre_r = dpre for 'sum', column block r of it for
+    // 'stack'), which also leaves dH = [A_r^T dpre_r]_r for the weight gradient dW_r = dH_r^T x; the bias gradient is
+    // db_r = sum_i rowsum[i, r] dpre_r[i] (= the column sums of dH_r).  Every level of dpre / dH is Up = U rounded up to a multiple
+    // of 4 floats wide (one float4 per gather lane); the padding columns are zero.
     float* dh = reinterpret_cast<float*>(base + L.b);
     float* dwcat = reinterpret_cast<float*>(base + L.c);
-    float* dbcat = dwcat + d.RU * d.D;
+    float* dbcat = dwcat + d.R * d.Up * d.D;
     if (d.n_src == 0 || d.n_dst == 0) return fail(SG_ERR_INVALID, "fused aggregation with edges but no rows");
     if (want_b && !plan->rowsum) return fail(SG_ERR_INVALID, "the fused order needs plan->rowsum for the bias gradient");
-    if (d.saves_z) {      // the forward kept Z = [A_r x]_r: dWext (U, R D) = dpre^T Z; the data gradient writes nothing but dx
-      if (want_w && !saved) return fail(SG_ERR_INVALID, "fused backward needs the `saved` buffer of the forward");
-      if (dx) {
-        const sg_fused_plan& fp = plan->fused[1];
-        SG_TRY(sg_agg_fused_hip(dx, d.D, nullptr, 0, dpre, d.U, weights, d.D, 1, nullptr, nullptr, fp.f_ptr, fp.f_idx, fp.f_w,
-                                fp.tile_order, d.n_src, d.n_dst, d.R, d.nnz, d.U, d.D, SG_ACT_NONE, 0.f, fused_nt(), scratch,
-                                L.scratch_bytes, stream));
-      }
-      float* dwext = dwcat;
-      if (want_w)
-        SG_TRY(sg_gemm_f32_hip(dwext, d.R * d.D, dpre, d.U, 1, static_cast<const float*>(saved), d.R * d.D, 0, d.U, d.R * d.D,
-                               d.n_dst, nullptr, SG_ACT_NONE, 0.f, 0, scratch, L.scratch_bytes, stream));
-      if (want_b) {
-        float* part = reinterpret_cast<float*>(scratch);
-        const int P = static_cast<int>(d.n_dst < kDbParts ? d.n_dst : kDbParts);
-        const dim3 grid(static_cast<unsigned>(P), static_cast<unsigned>((d.U + 255) / 256));
-        if (d.R <= 16)
-          hipLaunchKernelGGL(bias_grad_partial_kernel<16>, grid, dim3(1024), 0, st, part, plan->rowsum, dpre,
-                             static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U));
-        else
-          hipLaunchKernelGGL(bias_grad_partial_kernel<SG_MAX_LINKS>, grid, dim3(1024), 0, st, part, plan->rowsum, dpre,
-                             static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U));
-        hipLaunchKernelGGL(bias_grad_final_kernel, dim3(static_cast<unsigned>((d.RU + 63) / 64)), dim3(64), 0, st, dbcat, part, P, static_cast<int>(d.RU));
-        SG_TRY(check_launch("bias_grad kernels"));
-      }
-      if (want_w) {
-        MutPtrTable nodb;
-        for (int r = 0; r < SG_MAX_LINKS; ++r) nodb.p[r] = nullptr;
-        hipLaunchKernelGGL(unpack_ext_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, dw, nodb, dwext, d.R,
-                           static_cast<int>(d.U), static_cast<int>(d.D), static_cast<int>(d.R * d.D), 0);
-        SG_TRY(check_launch("unpack_ext_kernel"));
-      }
-      if (want_b) {
-        MutPtrTable nodw;
-        for (int r = 0; r < SG_MAX_LINKS; ++r) nodw.p[r] = nullptr;
-        hipLaunchKernelGGL(unpack_cat_kernel, dim3(blocks_for(d.RU)), dim3(256), 0, st, nodw, db, static_cast<const float*>(nullptr),
-                           dbcat, d.R, static_cast<int>(d.U), static_cast<int>(d.D));
-        SG_TRY(check_launch("unpack_cat_kernel"));
-      }
-      return SG_OK;
+    if (d.Up != d.U) {         // re-pitch (and apply act' in the same pass): the generic pass above wrote nothing usable
+      hipLaunchKernelGGL(act_bwd_pitched_kernel, dim3(blocks_for(d.n_dst * d.outw_p)), dim3(256), 0, st, dpre_buf, static_cast<long long>(d.outw_p),
+                         dout, out, static_cast<long long>(d.n_dst), static_cast<int>(d.outw), static_cast<int>(d.U), static_cast<int>(d.Up),
+                         act, slope);
+      SG_TRY(check_launch("act_bwd_pitched_kernel"));
+      dpre = dpre_buf;
     }
-    if (dx) {
-      const sg_fused_plan& fp = plan->fused[1];
-      SG_TRY(sg_agg_fused_hip(dx, d.D, want_w ? dh : nullptr, d.RU, dpre, d.U, weights, d.D, 1, nullptr, nullptr, fp.f_ptr,
-                              fp.f_idx, fp.f_w, fp.tile_order, d.n_src, d.n_dst, d.R, d.nnz, d.U, d.D, SG_ACT_NONE, 0.f, fused_nt(),
-                              scratch, L.scratch_bytes, stream));
-    } else if (want_w) {
-      SG_TRY(gather_view(plan, SG_VIEW_T_IDX_T, dh, d.R, d.RU, dpre, 1, d.U, plan->t_w, plan->t_idx, plan->t_indptr,
-                         d.n_src * d.R, d.nnz, d.U, SG_ACT_NONE, 0.f, scratch, L.scratch_bytes, stream, d.n_dst * d.outw * 4));
-    }
-    if (want_w) {
-      if (!x) return fail(SG_ERR_INVALID, "x is null");
-      SG_TRY(sg_gemm_f32_hip(dwcat, d.D, dh, d.RU, 1, x, d.D, 0, d.RU, d.D, d.n_src, nullptr, SG_ACT_NONE, 0.f, 0,
-                             scratch, L.scratch_bytes, stream));
-    }
-    if (want_b) {
+    const int64_t lstride = d.stack ? d.Up : 0;
+    auto bias_grad = [&]() -> int {
       float* part = reinterpret_cast<float*>(scratch);
       const int P = static_cast<int>(d.n_dst < kDbParts ? d.n_dst : kDbParts);
       const dim3 grid(static_cast<unsigned>(P), static_cast<unsigned>((d.U + 255) / 256));
       if (d.R <= 16)
         hipLaunchKernelGGL(bias_grad_partial_kernel<16>, grid, dim3(1024), 0, st, part, plan->rowsum, dpre,
-                           static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U));
+                           static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U), static_cast<long long>(d.outw_p), static_cast<int>(lstride));
       else
         hipLaunchKernelGGL(bias_grad_partial_kernel<SG_MAX_LINKS>, grid, dim3(1024), 0, st, part, plan->rowsum, dpre,
-                           static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U));
+                           static_cast<long long>(d.n_dst), d.R, static_cast<int>(d.U), static_cast<long long>(d.outw_p), static_cast<int>(lstride));
       hipLaunchKernelGGL(bias_grad_final_kernel, dim3(static_cast<unsigned>((d.RU + 63) / 64)), dim3(64), 0, st, dbcat, part, P, static_cast<int>(d.RU));
-      SG_TRY(check_launch("bias_grad kernels"));
+      return check_launch("bias_grad kernels");
+    };
+    MutPtrTable none;
+    for (int r = 0; r < SG_MAX_LINKS; ++r) none.p[r] = nullptr;
+    const sg_fused_plan& fp = plan->fused[1];
+    if (d.saves_z) {      // the forward kept Z = [A_r x]_r: dW_r = dpre_r^T Z_r; the data gradient writes nothing but dx
+      if (want_w && !saved) return fail(SG_ERR_INVALID, "fused backward needs the `saved` buffer of the forward");
+      if (dx)
+        SG_TRY(sg_agg_fused2_hip(dx, d.D, nullptr, 0, dpre, d.outw_p, lstride, weights, d.D, 1, d.U, nullptr, nullptr, fp.f_ptr, fp.f_idx,
+                                 fp.f_w, fp.tile_order, d.n_src, d.n_dst, d.R, d.nnz, d.Up, d.D, SG_ACCUM_SUM, SG_ACT_NONE, 0.f, fused_nt(),
+                                 scratch, L.scratch_bytes, stream));
+      const float* z = static_cast<const float*>(saved);
+      if (want_w && !d.stack) {        // 'sum': ONE product dWext (U, R D) = dpre^T Z
+        SG_TRY(sg_gemm_f32_hip(dwcat, d.R * d.D, dpre, d.outw_p, 1, z, d.R * d.D, 0, d.U, d.R * d.D, d.n_dst, nullptr, SG_ACT_NONE, 0.f, 0,
+                               scratch, L.scratch_bytes, stream));
+      } else if (want_w) {             // 'stack': level r contracts its own column blocks, dW_r (U, D) = dpre_r^T Z_r
+        for (int r = 0; r < d.R; ++r)
+          SG_TRY(sg_gemm_f32_hip(dwcat + static_cast<int64_t>(r) * d.U * d.D, d.D, dpre + r * d.Up, d.outw_p, 1, z + r * d.D, d.R * d.D, 0,
+                                 d.U, d.D, d.n_dst, nullptr, SG_ACT_NONE, 0.f, 0, scratch, L.scratch_bytes, stream));
+      }
+      if (want_b) SG_TRY(bias_grad());
+      if (want_w && !d.stack) {
+        hipLaunchKernelGGL(unpack_ext_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, dw, none, dwcat, d.R,
+                           static_cast<int>(d.U), static_cast<int>(d.D), static_cast<int>(d.R * d.D), 0);
+        SG_TRY(check_launch("unpack_ext_kernel"));
+      }
+      if ((want_w && d.stack) || want_b) {
+        hipLaunchKernelGGL(unpack_cat_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, (want_w && d.stack) ? dw : none,
+                           want_b ? db : none, (want_w && d.stack) ? dwcat : static_cast<const float*>(nullptr),
+                           want_b ? dbcat : static_cast<const float*>(nullptr), d.R, static_cast<int>(d.U), static_cast<int>(d.D),
+                           static_cast<int>(d.U));
+        SG_TRY(check_launch("unpack_cat_kernel"));
+      }
+      return SG_OK;
     }
+    if (dx || want_w) {      // (a caller that wants only dW still runs the data-gradient kernel: it is what writes dH)
+      float* dxo = dx ? dx : reinterpret_cast<float*>(base + L.wpack);
+      SG_TRY(sg_agg_fused2_hip(dxo, d.D, want_w ? dh : nullptr, d.R * d.Up, dpre, d.outw_p, lstride, weights, d.D, 1, d.U, nullptr, nullptr,
+                               fp.f_ptr, fp.f_idx, fp.f_w, fp.tile_order, d.n_src, d.n_dst, d.R, d.nnz, d.Up, d.D, SG_ACCUM_SUM, SG_ACT_NONE,
+                               0.f, fused_nt(), scratch, L.scratch_bytes, stream));
+    }
+    if (want_w) {
+      if (!x) return fail(SG_ERR_INVALID, "x is null");
+      SG_TRY(sg_gemm_f32_hip(dwcat, d.D, dh, d.R * d.Up, 1, x, d.D, 0, d.R * d.Up, d.D, d.n_src, nullptr, SG_ACT_NONE, 0.f, 0,
+                             scratch, L.scratch_bytes, stream));
+    }
+    if (want_b) SG_TRY(bias_grad());
     if (want_w || want_b) {
       hipLaunchKernelGGL(unpack_cat_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, dw, db,
                          want_w ? dwcat : static_cast<const float*>(nullptr),
                          want_b ? dbcat : static_cast<const float*>(nullptr), d.R, static_cast<int>(d.U),
-                         static_cast<int>(d.D));
+                         static_cast<int>(d.D), static_cast<int>(d.Up));
       SG_TRY(check_launch("unpack_cat_kernel"));
     }
     return SG_OK;
@@ -626,7 +674,7 @@ SG_API int sg_multilink_agg_bwd_hip(float* dx, float* const* dweights, float* co
       hipLaunchKernelGGL(unpack_cat_kernel, dim3(blocks_for(d.RU * d.D)), dim3(256), 0, st, dw, db,
                          want_w ? dwcat : static_cast<const float*>(nullptr),
                          want_b ? dbcat : static_cast<const float*>(nullptr), d.R, static_cast<int>(d.U),
-                         static_cast<int>(d.D));
+                         static_cast<int>(d.D), static_cast<int>(d.U));
       SG_TRY(check_launch("unpack_cat_kernel"));
     }
     return SG_OK;

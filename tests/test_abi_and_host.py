@@ -188,7 +188,13 @@ def test_fused_order_routing_and_sizes_are_host_decisions(monkeypatch):
     assert lib.sg_agg_fused_workspace_bytes(16) >= 16 * 256 * 256 * 4            # two f16 planes of sixteen 256 x 256 matrices
     assert lib.sg_agg_fused_tiles(0) == 0 and lib.sg_agg_fused_tiles(64) == 1 and lib.sg_agg_fused_tiles(65) == 2
     assert lib.sg_agg_fused_supported(256, 256, 32) == 1 and lib.sg_agg_fused_supported(256, 256, 33) == 0
-    assert lib.sg_agg_fused_supported(256, 128, 4) == 0
+    # round 6: rows of 4 .. 256 floats (multiple of 4), 1 .. 256 units per level -- the reference's 32 / 64 -> 250 among them
+    assert lib.sg_agg_fused_supported(256, 128, 4) == 1 and lib.sg_agg_fused_supported(64, 250, 5) == 1
+    assert lib.sg_agg_fused_supported(30, 64, 4) == 0 and lib.sg_agg_fused_supported(260, 64, 4) == 0 and lib.sg_agg_fused_supported(64, 257, 4) == 0
+    # U = 250: every level of the backward's dpre / dH is padded to 252 floats (one float4 per gather lane)
+    wb250 = lib.sg_multilink_agg_workspace_bytes(ref, 64, 250, 3, 0, 1)
+    assert wb250 >= (3000 * 252 + 1000 * 4 * 252 + 4 * 252 * 64) * 4
+    assert lib.sg_multilink_agg_workspace_bytes(ref, 64, 50, 3, 1, 1) >= (3000 * 4 * 52 + 1000 * 4 * 52) * 4      # 'stack'
     # a fused launch without the plan's level-major edge orders is refused with a message, not run
     for which in range(2):
         st.fused[which].f_ptr = None

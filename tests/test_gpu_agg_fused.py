@@ -62,24 +62,24 @@ def test_fused_order_rows_cut_between_gather_waves():
         _check_against_reference_order(eps, ips, sps, n_dst, n_src, R, act, seed=3)
 
 
-def _check_against_reference_order(eps, ips, sps, n_dst, n_src, R, act, seed):
+def _check_against_reference_order(eps, ips, sps, n_dst, n_src, R, act, seed, d_in=D, units=D, accum="sum"):
     from star_gcn_amd import functional as F
     from star_gcn_amd.plan import MultiLinkPlan
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(n_src, D, generator=g) * 0.1 * torch.exp(torch.randn(n_src, 1, generator=g))    # rows of very different scale
-    ws = [torch.randn(D, D, generator=g) * (3.0 / D) ** 0.5 for _ in range(R)]
-    bs = [torch.randn(D, generator=g) * 0.1 for _ in range(R)]
-    gy = torch.randn(n_dst, D, generator=g)
+    x = torch.randn(n_src, d_in, generator=g) * 0.1 * torch.exp(torch.randn(n_src, 1, generator=g))    # rows of very different scale
+    ws = [torch.randn(units, d_in, generator=g) * (3.0 / d_in) ** 0.5 for _ in range(R)]
+    bs = [torch.randn(units, generator=g) * 0.1 for _ in range(R)]
+    gy = torch.randn(n_dst, units * (R if accum == "stack" else 1), generator=g)
     xr = x.double().requires_grad_(True)
     wr = [w.double().requires_grad_(True) for w in ws]
     br = [b.double().requires_grad_(True) for b in bs]
-    ref = OM.multilink_aggregator(xr, wr, br, eps, ips, sps, accum="sum", act=act)
+    ref = OM.multilink_aggregator(xr, wr, br, eps, ips, sps, accum=accum, act=act)
     ref.backward(gy.double())
     plan = MultiLinkPlan(eps, ips, sps, n_src, "cuda")
     xd = x.cuda().requires_grad_(True)
     wd = [w.cuda().requires_grad_(True) for w in ws]
     bd = [b.cuda().requires_grad_(True) for b in bs]
-    out = F.multilink_aggregate(xd, wd, bd, plan, accum="sum", act=act, slope=0.1, order="fused")
+    out = F.multilink_aggregate(xd, wd, bd, plan, accum=accum, act=act, slope=0.1, order="fused")
     out.backward(gy.cuda())
     rel_close(out, ref, 1e-5, "out")
     rel_close(xd.grad, xr.grad, 1e-5, "dx")
@@ -88,9 +88,51 @@ def _check_against_reference_order(eps, ips, sps, n_dst, n_src, R, act, seed):
         rel_close(bd[r].grad, br[r].grad, 2e-5, "db%d" % r)
     # the data gradient alone (frozen parameters): the kernel variant that does not save the aggregates
     xd2 = x.cuda().requires_grad_(True)
-    out2 = F.multilink_aggregate(xd2, [w.cuda() for w in ws], [b.cuda() for b in bs], plan, accum="sum", act=act, order="fused")
+    out2 = F.multilink_aggregate(xd2, [w.cuda() for w in ws], [b.cuda() for b in bs], plan, accum=accum, act=act, order="fused")
     out2.backward(gy.cuda())
     assert torch.equal(out2, out) and torch.equal(xd2.grad, xd.grad)          # deterministic, and the same with / without zsave
+
+
+# The reference's own widths (experiments/cfg: EMBED.UNITS 32 / 64 -> GCN.AGG.UNITS 250, 'sum' or 'stack' = 250 // 5 = 50 units per
+# level, aggregators.py:79-81) and the halves of the bench width.  (d_in, units per level, accum)
+WIDTHS = [(128, 128, "sum"), (64, 250, "sum"), (32, 250, "sum"), (256, 250, "sum"), (252, 64, "sum"),
+          (64, 50, "stack"), (32, 50, "stack"), (128, 75, "stack"), (256, 256, "stack"), (256, 250, "stack"), (4, 1, "stack")]
+
+
+@pytest.mark.parametrize("d_in,units,accum", WIDTHS)
+@pytest.mark.parametrize("act", ["leaky", None])
+def test_fused_order_other_widths_and_stack(d_in, units, accum, act):
+    """the fused kernel at the reference's widths and with accum 'stack' (every level's product to its own column
+    block, no cross-level sum; the data gradient reads level r's column block of the output gradient), against the float64
+    layer oracle in the reference's operation order: forward, data gradient, weight and bias gradients, 1e-5.  Units that are
+    not a multiple of 4 (250) exercise the padded level pitch of the backward; graphs with ragged tiles, empty levels, cut rows."""
+    for (n_dst, n_src, nnz, R) in [(300, 40, 6000, 5), (65, 70, 50, 4), (200, 150, 9000, 3), (130, 90, 3000, 1)]:
+        rng = np.random.default_rng(n_dst + nnz + R + d_in + units)
+        eps, ips, sps = make_multilink(rng, n_dst, n_src, nnz, R)
+        _check_against_reference_order(eps, ips, sps, n_dst, n_src, R, act, seed=R + nnz + units, d_in=d_in, units=units, accum=accum)
+
+
+def test_fused_order_stack_with_cut_rows_and_more_sources_than_destinations():
+    """'stack' through both backward forms: n_dst < n_src (the forward saves the aggregates, R per-level weight-gradient products)
+    and n_dst > n_src (the data-gradient launch writes the R-expanded gradient), with a hub row cut between the gather waves."""
+    for (n_dst, n_src) in [(100, 300), (300, 100)]:
+        R = 4
+        cnt = np.zeros((R, n_dst), np.int64)
+        cnt[0, 5] = 3000
+        cnt[1, :64] = 2; cnt[1, 63] = 1500
+        cnt[2, 70] = 1
+        rng = np.random.default_rng(n_dst)
+        eps, ips, sps = [], [], []
+        for r in range(R):
+            ip = np.concatenate([[0], np.cumsum(cnt[r])]).astype(np.int32)
+            n = int(ip[-1])
+            e = rng.integers(0, n_src, n).astype(np.int32)
+            sp = rng.uniform(0.05, 1.0, n).astype(np.float32)
+            if n == 0:
+                e, sp = np.zeros(1, np.int32), np.zeros(1, np.float32)
+            eps.append(e); ips.append(ip); sps.append(sp)
+        for (d_in, units) in [(64, 50), (256, 256)]:
+            _check_against_reference_order(eps, ips, sps, n_dst, n_src, R, "leaky", seed=9, d_in=d_in, units=units, accum="stack")
 
 
 def test_fused_order_is_refused_where_it_does_not_apply():
@@ -100,19 +142,22 @@ def test_fused_order_is_refused_where_it_does_not_apply():
     rng = np.random.default_rng(5)
     eps, ips, sps = make_multilink(rng, 40, 30, 500, 3)
     plan = MultiLinkPlan(eps, ips, sps, 30, "cuda")
-    x = torch.randn(30, 64, device="cuda")
-    ws = [torch.randn(64, 64, device="cuda") for _ in range(3)]
-    bs = [torch.zeros(64, device="cuda") for _ in range(3)]
-    with pytest.raises(L.StarGCNError):
-        F.multilink_aggregate(x, ws, bs, plan, accum="sum", order="fused")       # width 64
-    x = torch.randn(30, 256, device="cuda")
-    ws = [torch.randn(256, 256, device="cuda") for _ in range(3)]
-    bs = [torch.zeros(256, device="cuda") for _ in range(3)]
-    with pytest.raises(L.StarGCNError):
-        F.multilink_aggregate(x, ws, bs, plan, accum="stack", order="fused")     # concat accumulation
-    # 'auto' stays unfused on a small graph (the R-expanded matrix is cache-resident), and says so
+    for (d_in, units) in [(30, 64), (260, 64), (64, 300)]:       # rows not a multiple of 4 floats / wider than 256 / > 256 units
+        x = torch.randn(30, d_in, device="cuda")
+        ws = [torch.randn(units, d_in, device="cuda") for _ in range(3)]
+        bs = [torch.zeros(units, device="cuda") for _ in range(3)]
+        with pytest.raises(L.StarGCNError):
+            F.multilink_aggregate(x, ws, bs, plan, accum="sum", order="fused")
+        assert not L.lib().sg_agg_fused_supported(d_in, units, 3)
+    assert L.lib().sg_agg_fused_supported(64, 250, 5) and L.lib().sg_agg_fused_supported(32, 50, 5)
+    assert L.lib().sg_agg_fused_supported(128, 128, 10) and L.lib().sg_agg_fused_supported(256, 256, 32)
+    assert not L.lib().sg_agg_fused_supported(256, 256, 33)
+    # 'auto' stays unfused on a small graph (the R-expanded matrix is cache-resident), and says so -- and for every width other
+    # than 256 -> 256 'sum' whatever the size (the kernel is tuned for that shape only)
     from star_gcn_amd import ops
     assert ops.multilink_resolve_order(plan, "auto", 256, 256, "sum") in ("transform_first", "aggregate_first")
+    assert ops.multilink_resolve_order(plan, "auto", 64, 250, "sum") in ("transform_first", "aggregate_first")
+    assert ops.multilink_resolve_order(plan, "auto", 256, 256, "stack") in ("transform_first", "aggregate_first")
 
 
 def test_fused_kernel_raw_c_abi_rows_of_other_pitch_and_saved_aggregates():

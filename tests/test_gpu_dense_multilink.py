@@ -214,6 +214,30 @@ def test_gemm_x3w_persistent_stream_and_scale_drop_fallback():
         A[5::32, :K // 2] = 0.0
         B = torch.randn(K, N, generator=g, device="cuda")
         check(A, B, False, False, "scale drop")
+        # the same product accumulated into an existing C: with one K slice the wide kernel adds in place, so a
+        # fallback run behind it would add the product twice -- such calls must stay on the 128-wide kernel.  Both the scale-drop
+        # operands (flag raised) and plain ones, default variant and variant 8.
+        for variant in (8, -1):
+            L.lib().sg_gemm_x3_variant(variant)
+            for (Ax, what) in ((A, "scale drop + accumulate"), (torch.randn(M, K, generator=g, device="cuda"), "accumulate")):
+                C0 = torch.randn(M, N, generator=g, device="cuda")
+                out = ops.gemm(Ax, B, out=C0.clone(), accumulate=True)
+                ref = C0.double() + Ax.double() @ B.double()
+                mag = C0.double().abs() + Ax.double().abs() @ B.double().abs()
+                worst = float(((out.double() - ref).abs() / (mag + 1e-300)).max())
+                assert worst <= 4e-7 * K ** 0.5, (what, variant, worst)
+        # the size the advisor named: 1 M x 256 x 256 picks the wide kernel by default routing
+        M2 = 1 << 20
+        A2 = torch.randn(M2, 256, generator=g, device="cuda")
+        A2[:, 128:] *= 2.0 ** -70
+        A2[5::32, :128] = 0.0
+        B2 = torch.randn(256, 256, generator=g, device="cuda")
+        C0 = torch.randn(M2, 256, generator=g, device="cuda")
+        L.lib().sg_gemm_x3_variant(-1)
+        out = ops.gemm(A2, B2, out=C0.clone(), accumulate=True)
+        ref = C0.double() + A2.double() @ B2.double()
+        mag = C0.double().abs() + A2.double().abs() @ B2.double().abs()
+        assert float(((out.double() - ref).abs() / (mag + 1e-300)).max()) <= 4e-7 * 16
     finally:
         L.lib().sg_gemm_x3_variant(-1)
         L.lib().sg_gemm_backend(-1)

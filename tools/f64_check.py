@@ -253,8 +253,15 @@ class Capture(object):
             for k in ("user", "item"):
                 self._h.append(layer._out_fcs[self.key[k]].register_forward_hook(
                     lambda m, i, o, l=l, k=k: self.layer_out[l].__setitem__(k, o.detach())))
-                self._h.append(layer.aggregators[(self.key[k], other[k])].register_forward_hook(
+                agg = layer.aggregators[(self.key[k], other[k])]
+                self._h.append(agg.register_forward_hook(
                     lambda m, i, o, l=l, k=k: self.agg_out[l].__setitem__(k, o.detach())))
+                # node-partitioned runs: the aggregator returns the pre-activation PARTIAL sum of a replicated destination and
+                # the layer applies `agg.activation` after the all-reduce -- that call's output is the aggregate proper
+                act = getattr(agg, "activation", None)
+                if isinstance(act, torch.nn.Module):
+                    self._h.append(act.register_forward_hook(
+                        lambda m, i, o, l=l, k=k: self.agg_out[l].__setitem__(k, o.detach())))
         self._h.append(net.rating_user_projs[0].register_forward_hook(
             lambda m, i, o: self.proj.__setitem__("user", o.detach())))
         self._h.append(net.rating_item_projs[0].register_forward_hook(
@@ -326,3 +333,76 @@ def verify_step(net, run_step, graph_arrays, y, scale, name_user="user", name_it
     out = compare(net, cap, loss.detach(), ref, name_user, name_item)
     out["score_rms"] = float("%.4g" % ref["score_rms"])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# node-partitioned runs (star-gcn_amd/dist.py: 1-D user-block partition, items replicated)
+def _rel_rows(got_block, ref_full, lo, hi):
+    """error of rows [lo, hi) against the float64 tensor of ALL rows, relative to the WHOLE tensor's scale (the N = 1 measure)"""
+    s = float(ref_full.abs().max())
+    return float((got_block.double() - ref_full[lo:hi]).abs().max()) / max(s, 1e-30)
+
+
+def verify_step_partitioned(net, run_step, graph_arrays, y, scale, lo, hi, n_user, assemble_rows, reduce_scalar,
+                            name_user="user", name_item="movie"):
+    """One rank's view of a node-partitioned step against the float64 evaluation of the definition over the WHOLE graph.
+
+    net: this rank's network (user table = rows [lo, hi) of the global one, everything else replicated); run_step() runs
+    one partitioned step INCLUDING the gradient all-reduce of the replicated parameters and returns the local loss.
+    graph_arrays / y: the whole graph, as for verify_step.  assemble_rows(block) -> (n_user, width) matrix made of every
+    rank's row block; reduce_scalar(t) -> sum over ranks (both are collectives: every rank calls them in the same order).
+    Compared on every rank: the loss, item-side layer outputs / projection (replicated: all rows), this rank's user rows of
+    every layer output / projection / embedding gradient, every replicated parameter's all-reduced gradient and the item
+    embedding gradient.  The activation-derivative rule of the single-GPU check applies unchanged: the side the product
+    took is adopted only where the float64 pre-activation lies inside fp32 rounding of zero -- the product's outputs of
+    ALL user rows are assembled for that."""
+    key = {"user": name_user, "item": name_item}
+    other = {"user": name_item, "item": name_user}
+    cap = Capture(net, name_user, name_item)
+    try:
+        loss_local = run_step()
+    finally:
+        cap.close()
+    loss = reduce_scalar(loss_local.detach().view(1))[0]
+    if loss_local.is_cuda:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    params = net_params(net, name_user, name_item)
+    params["embed"]["user"] = assemble_rows(params["embed"]["user"])
+    assert params["embed"]["user"].shape[0] == n_user
+    block = {"layer": [c["user"] for c in cap.layer_out], "agg": [c["user"] for c in cap.agg_out]}
+    for l in range(len(cap.layer_out)):          # same order on every rank
+        cap.layer_out[l]["user"] = assemble_rows(block["layer"][l])
+        cap.agg_out[l]["user"] = assemble_rows(block["agg"][l])
+    g = RawGraph(*graph_arrays)
+    assert g.n_user == n_user
+    ref = evaluate(g, params, y, scale, product=cap)
+    per = {"loss": abs(float(loss) - float(ref["loss"])) / max(abs(float(ref["loss"])), 1e-30)}
+    for l, lo_ in enumerate(ref["layer_out"]):
+        per["layer%d.out.user[block]" % l] = _rel_rows(block["layer"][l], lo_["user"], lo, hi)
+        per["layer%d.out.item" % l], _ = _rel(cap.layer_out[l]["item"], lo_["item"])
+    per["proj.user[block]"] = _rel_rows(cap.proj["user"], ref["proj"]["user"], lo, hi)
+    per["proj.item"], _ = _rel(cap.proj["item"], ref["proj"]["item"])
+    per["grad.embed.user[block]"] = _rel_rows(net.embed_layers[key["user"]].weight.grad, ref["grads"]["embed"]["user"], lo, hi)
+    per["grad.embed.item"], _ = _rel(net.embed_layers[key["item"]].weight.grad, ref["grads"]["embed"]["item"])
+    for l, layer in enumerate(net.encoders[0]._blocks):
+        for k in ("user", "item"):
+            agg, fc, gl = layer.aggregators[(key[k], other[k])], layer._out_fcs[key[k]], ref["grads"]["layers"][l][k]
+            gW = torch.stack([getattr(agg, "weight%d" % r).grad for r in range(agg._num_links)])
+            gb = torch.stack([getattr(agg, "bias%d" % r).grad for r in range(agg._num_links)])
+            per["grad.layer%d.%s.W" % (l, k)], _ = _rel(gW, torch.stack(gl["W"]))
+            per["grad.layer%d.%s.b" % (l, k)], _ = _rel(gb, torch.stack(gl["b"]))
+            per["grad.layer%d.%s.Wo" % (l, k)], _ = _rel(fc.weight.grad, gl["Wo"])
+            per["grad.layer%d.%s.bo" % (l, k)], _ = _rel(fc.bias.grad, gl["bo"])
+    pj = {"user": net.rating_user_projs[0], "item": net.rating_item_projs[0]}
+    for k in ("user", "item"):
+        per["grad.proj.%s.W" % k], _ = _rel(pj[k].weight.grad, ref["grads"]["proj"][k][0])
+        per["grad.proj.%s.b" % k], _ = _rel(pj[k].bias.grad, ref["grads"]["proj"][k][1])
+    worst = max(per, key=lambda n: per[n])
+    gworst = max((n for n in per if n.startswith("grad.")), key=lambda n: per[n])
+    return {"max_rel_err": per[worst], "worst": worst, "gradient_max_rel_err": per[gworst], "gradient_worst": gworst,
+            "tensors": len(per), "per_tensor": {n: float("%.3g" % v) for n, v in per.items()},
+            "loss_f64": float(ref["loss"]), "user_rows": [int(lo), int(hi)],
+            "activation_derivative": dict(ref["act_stats"], rule=(
+                "LeakyReLU' is discontinuous at 0: where |float64 pre-activation| <= %g * max|pre| (inside fp32 rounding) "
+                "the sign the partitioned run took is adopted; float64 decides everywhere else" % AMBIGUOUS))}
