@@ -313,7 +313,7 @@ def graph_replay(step, dev, steps):
     import star_gcn_amd.dist as sgdist
     sgdist.quiesce_for_capture(dev)     # the RCCL watchdog must have retired the warm-up collectives before capture begins
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode=sgdist.capture_error_mode()):      # 'thread_local' with RCCL: see dist.py
         loss = step()
     torch.cuda.synchronize()
     for _ in range(2):
@@ -768,7 +768,25 @@ def partition_f64_check(net, step, csr, vals, mean, std, n_user, n_item, R, E_to
         full[lo:hi] = block
         return SD.all_reduce_sum(full)          # the other ranks' rows arrive as sums with zeros: exact
 
-    out = FC.verify_step_partitioned(net, step, arrays, y_all, 1.0 / E_total, lo, hi, n_user, assemble_rows, SD.all_reduce_sum, U, I)
+    turn = None
+    import torch.distributed as dist
+    if dist.get_backend() != "nccl" and dist.get_world_size() > 1:      # the ranks share ONE GPU (development / test runs over gloo)
+        def turn(fn):
+            res = None
+            for r_ in range(dist.get_world_size()):
+                if r_ == dist.get_rank():
+                    try:
+                        res = fn()
+                    except Exception as e:      # keep the turnstile moving; the error is this rank's result
+                        res = e
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+                dist.barrier()
+            if isinstance(res, Exception):
+                raise res
+            return res
+    out = FC.verify_step_partitioned(net, step, arrays, y_all, 1.0 / E_total, lo, hi, n_user, assemble_rows, SD.all_reduce_sum, U, I,
+                                     one_at_a_time=turn)
     torch.cuda.synchronize()
     out["seconds"] = round(time.perf_counter() - t0, 2)
     return out

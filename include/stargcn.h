@@ -377,7 +377,13 @@ int sg_multilink_agg_resolve_order(const sg_multilink_plan* plan, int order);
  * >= 2^14 nodes on the smaller side, the larger side at most twice the smaller, the smaller side's R-expanded matrix beyond
  * 192 MB: multilink.hip, profiles/r5_fused_kernel.md section 7; SG_FUSED=0 / 1 in the environment forces never / whenever
  * supported), and otherwise to the rule of sg_multilink_agg_resolve_order.
- * The caller then attaches plan->fused (both entries) before the launch. */
+ * The caller then attaches plan->fused (both entries) before the launch.
+ * SG_ORDER_AUTO callers of the fwd / bwd / size entries: resolve ONCE with this function and pass the explicit order to
+ * sg_multilink_agg_saved_bytes, _workspace_bytes, _fwd_hip and _bwd_hip of the same layer call.  Inside those entries AUTO also
+ * looks at plan->fused (a plan without the level-major orders falls back to the unfused rule) and at SG_FUSED / SG_FUSED_SAVEZ:
+ * a plan whose `fused` entries change between the forward and the backward would make the backward read `saved` in another
+ * layout (Z (n_dst, R D) of the fused order vs Zext (n_dst, ld) of aggregate-first).  The Python host side does exactly this
+ * (ops.multilink_resolve_order, then the order's name everywhere). */
 int sg_multilink_agg_resolve_order2(const sg_multilink_plan* plan, int order, int64_t in_dim, int64_t units_per_level,
                                     int accum);
 /* Which gather view (SG_VIEW_*) the fused entries would issue as two source-range phases for these sizes (backward = 0 / 1),

@@ -28,8 +28,20 @@ class DeviceBatchSampler(object):
         ceil(P_mask |list|) of the list.  A key without a list is transductive (every node is a candidate)."""
         self.res, self.batch_size, self.seed = resident, int(min(batch_size, resident.nnz)), int(seed)
         self._cand = {}
+        n_of = {resident.U: resident.n_user, resident.I: resident.n_item}
         for key, ids in (recon_candidates or {}).items():
-            self._cand[key] = torch.as_tensor(ids, dtype=torch.int32).to(resident.device).contiguous()
+            # the device kernel assumes DISTINCT ids in [0, n) (the reference permutes a distinct candidate list,
+            # iterators.py:332-346): duplicates would yield duplicate reconstruction nodes, an id out of range a -1 entry
+            import numpy as np
+            arr = np.asarray(ids.cpu() if torch.is_tensor(ids) else ids).astype(np.int64).reshape(-1)
+            if key not in n_of:
+                raise L.StarGCNError("recon_candidates: unknown node key %r" % (key,))
+            if arr.size and (arr.min() < 0 or arr.max() >= n_of[key]):
+                raise L.StarGCNError("recon_candidates[%r]: ids must lie in [0, %d)" % (key, n_of[key]))
+            uniq = np.unique(arr)
+            if uniq.size != arr.size:
+                raise L.StarGCNError("recon_candidates[%r]: %d duplicate ids (the list must be distinct)" % (key, arr.size - uniq.size))
+            self._cand[key] = torch.from_numpy(arr.astype(np.int32)).to(resident.device).contiguous()
         self.P_mask, self.p_zero = float(embed_P_mask), float(embed_p_zero)
         self.iteration = 0
         dev = resident.device

@@ -83,19 +83,45 @@ def comm_stream(device):
     return s
 
 
+def capture_error_mode():
+    """The `capture_error_mode` a step with RCCL collectives should be captured under (torch.cuda.graph(...,
+    capture_error_mode=...)): 'thread_local' confines the capture's "unsafe call" checks to the capturing thread, so the
+    hipEventQuery polls of torch's RCCL watchdog THREAD on the warm-up collectives' completion events are not answered with
+    hipErrorCapturedEvent (which the watchdog turns into a process abort).  'global' (torch's default) without RCCL."""
+    return "thread_local" if (_active() and dist.get_backend() == "nccl") else "global"
+
+
 def quiesce_for_capture(device=None, settle_s=0.5):
     """Call right before a step with RCCL collectives is captured into a hipGraph.  torch's RCCL watchdog thread polls the
     completion events of the collectives enqueued so far (eagerly: warm-up steps) about every 100 ms and retires them; HIP
-    answers hipEventQuery with hipErrorCapturedEvent when the event's stream has MEANWHILE entered capture, which the
-    watchdog turns into a process abort.  A capture that begins inside that window therefore dies about once in ten runs.
-    Drain the device, then give the watchdog time to retire everything that has finished (SG_CAPTURE_SETTLE_S overrides the wait).  No-op without RCCL."""
+    answers hipEventQuery with hipErrorCapturedEvent when the event's stream has MEANWHILE entered a GLOBAL-mode capture,
+    which the watchdog turns into a process abort.  The guarantee is `capture_error_mode()` (capture in 'thread_local' mode:
+    the watchdog's queries are not the capturing thread's); this function is the belt to those braces and BEST EFFORT only
+    (ADVICE r5): it drains the device, waits until every warm-up collective this module launched reports completion
+    (Work.is_completed on the handles kept by _launch_sum), then gives the watchdog one polling period to retire them
+    (SG_CAPTURE_SETTLE_S overrides the wait).  No-op without RCCL."""
     if device is not None:
         torch.cuda.synchronize(device)
     elif torch.cuda.is_available():
         torch.cuda.synchronize()
     if _active() and dist.get_backend() == "nccl":
         import time
+        deadline = time.perf_counter() + 10.0
+        while _works and time.perf_counter() < deadline:
+            w = _works[0]
+            try:
+                done = w.is_completed()
+            except Exception:
+                done = True
+            if done:
+                _works.pop(0)
+            else:
+                time.sleep(0.001)
+        del _works[:]
         time.sleep(float(os.environ.get("SG_CAPTURE_SETTLE_S", settle_s)))
+
+
+_works = []          # Work handles of the eager RCCL collectives since the last quiesce (bounded: see _launch_sum)
 
 
 def _wait_on(cur, done):
@@ -196,7 +222,14 @@ def _launch_sum(y, pending=None):
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(cs)
-        dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        if torch.cuda.is_current_stream_capturing():
+            dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        else:       # same stream semantics (the communication stream waits for the collective), but the handle is kept for
+            work = dist.all_reduce(y, op=dist.ReduceOp.SUM, async_op=True)      # quiesce_for_capture
+            work.wait()
+            _works.append(work)
+            if len(_works) > 256:
+                del _works[:128]
         if timed:
             e1.record(cs)
             STATS.events.append((e0, e1))

@@ -206,7 +206,7 @@ class MultiLinkPlan(object):
             st.struct_bytes = ctypes.sizeof(L.MultiLinkPlanStruct)
             for which, fp in enumerate(getattr(self, "_fused", None) or ()):
                 e = st.fused[which]
-                e.f_ptr, e.f_idx, e.f_w, e.tile_order = (t.data_ptr() for t in fp)
+                e.f_ptr, e.f_idx, e.f_w, e.tile_order = (t.data_ptr() for t in fp[:4])
             for view, ph in getattr(self, "_phases", {}).items():
                 if ph is None:
                     continue
@@ -269,7 +269,7 @@ class MultiLinkPlan(object):
     def ensure_fused(self, rebuild=False):
         """The two level-major edge orders the fused aggregate -> contract kernel walks (csrc/agg_fused.hip,
         sg_agg_fused_plan_build_hip): [0] over (c_indptr, c_idx, c_w) for the forward, [1] over (t_indptr, t_idx, t_w) for
-        the data gradient; 8 bytes per edge each, resident with the plan.  The launch order of the 64-row tiles is by
+        the data gradient; 12 bytes per edge each (index, weight, source position), resident with the plan.  The launch order of the 64-row tiles is by
         descending edge count (the persistent workgroups take the heavy tiles first).  Returns False when they are missing and
         cannot be built now (stream capture)."""
         if getattr(self, "_fused", None) is not None and not rebuild:
@@ -283,8 +283,12 @@ class MultiLinkPlan(object):
                                                     (self.t_indptr, self.t_idx, self.t_w, self.n_src))):
             dev = idx.device
             tiles = int(lib.sg_agg_fused_tiles(rows))
-            if old is not None:
-                f_ptr, f_idx, f_w, order = old[which]
+            if old is not None:       # same graph, new weights (per-batch edge masking): one pass over the weights, not a re-plan
+                f_ptr, f_idx, f_w, order, f_pos = old[which]
+                L.check(lib.sg_agg_fused_refresh_hip(L.ptr(f_w), L.ptr(f_pos), L.ptr(w), self.nnz, L.stream_ptr()),
+                        "sg_agg_fused_refresh_hip")
+                built.append((f_ptr, f_idx, f_w, order, f_pos))
+                continue
             else:
                 R = self.R
                 per_row = (ip[R::R] - ip[:-1:R]).to(torch.int64) if rows > 0 else torch.zeros(0, dtype=torch.int64, device=dev)
@@ -293,10 +297,11 @@ class MultiLinkPlan(object):
                 order = torch.argsort(work.view(-1, 64).sum(1), descending=True, stable=True).to(torch.int32)
                 f_ptr = torch.empty(max(tiles, 1) * R * 65, dtype=torch.int32, device=dev)
                 f_idx, f_w = torch.empty_like(idx), torch.empty_like(w)
-            L.check(lib.sg_agg_fused_plan_build_hip(L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), None, L.ptr(order), L.ptr(ip),
+                f_pos = torch.empty_like(idx)          # source position of every edge: what a later weight refresh reads through
+            L.check(lib.sg_agg_fused_plan_build_hip(L.ptr(f_ptr), L.ptr(f_idx), L.ptr(f_w), L.ptr(f_pos), L.ptr(order), L.ptr(ip),
                                                     L.ptr(idx), L.ptr(w), rows, self.R, self.nnz, L.stream_ptr()),
                     "sg_agg_fused_plan_build_hip")
-            built.append((f_ptr, f_idx, f_w, order))
+            built.append((f_ptr, f_idx, f_w, order, f_pos))
         self._fused = tuple(built)
         self._struct = None
         return True

@@ -179,7 +179,7 @@ def test_fused_kernel_raw_c_abi_rows_of_other_pitch_and_saved_aggregates():
     x = xbig[:, :D]
     Ws = [torch.randn(D, D, device=dev, generator=g) / 16 for _ in range(R)]
     tiles = int(lib.sg_agg_fused_tiles(n_dst))
-    assert tiles == (n_dst + 63) // 64 and lib.sg_agg_fused_supported(256, 256, R) == 1 and lib.sg_agg_fused_supported(128, 256, R) == 0
+    assert tiles == (n_dst + 63) // 64 and lib.sg_agg_fused_supported(256, 256, R) == 1 and lib.sg_agg_fused_supported(130, 256, R) == 0
     order = torch.randperm(tiles, device=dev, generator=g).to(torch.int32)
     f_ptr = torch.empty(tiles * R * 65, dtype=torch.int32, device=dev)
     f_idx, f_w, f_pos = torch.empty_like(idx), torch.empty_like(w), torch.empty_like(idx)
@@ -212,8 +212,8 @@ def test_fused_kernel_raw_c_abi_rows_of_other_pitch_and_saved_aggregates():
     ws, wsn = L.workspace(lib.sg_agg_fused_workspace_bytes(R), dev)
     out = torch.empty(n_dst, D, device=dev)
     rc = lib.sg_agg_fused_hip(L.ptr(out), D, None, 0, L.ptr(x), xbig.shape[1], ops._ptr_array(Ws), D, 0, None, None, L.ptr(f_ptr),
-                              L.ptr(f_idx), L.ptr(f_w), None, n_dst, n_src, R, nnz, 128, D, 0, 0.0, 0, L.ptr(ws), wsn, L.stream_ptr())
-    assert rc == -2 and b"256" in lib.sg_last_error()          # SG_ERR_UNSUPPORTED
+                              L.ptr(f_idx), L.ptr(f_w), None, n_dst, n_src, R, nnz, 130, D, 0, 0.0, 0, L.ptr(ws), wsn, L.stream_ptr())
+    assert rc == -2 and b"256" in lib.sg_last_error()          # SG_ERR_UNSUPPORTED: rows must be a multiple of 4 floats, <= 256
     rc = lib.sg_agg_fused_hip(L.ptr(out), D, None, 0, L.ptr(x), xbig.shape[1], ops._ptr_array(Ws), D, 0, None, None, L.ptr(f_ptr),
                               L.ptr(f_idx), L.ptr(f_w), None, n_dst, n_src, R, nnz, D, D, 0, 0.0, 0, L.ptr(ws), ctypes.c_size_t(16),
                               L.stream_ptr())

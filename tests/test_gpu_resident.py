@@ -212,6 +212,13 @@ def test_device_recon_mask_inductive_rule_unseen_nodes_are_minus_one():
     assert (nu[unseen] == -1).all() and np.isin(b["recon"]["user"].cpu().numpy(), cand).all()
     assert b["recon"]["user"].numel() == k
     assert np.array_equal(b["noise"]["movie"].cpu().numpy(), np.arange(1000))   # no candidate list: transductive, as before
+    # the list is validated at construction: the device kernel assumes distinct ids inside the node range
+    from star_gcn_amd._lib import StarGCNError
+    for bad in (np.concatenate([cand, cand[:1]]), np.array([0, n], dtype=np.int64), np.array([-1, 3], dtype=np.int64)):
+        with pytest.raises(StarGCNError):
+            DeviceBatchSampler(res, 4, recon_candidates={"user": bad})
+    with pytest.raises(StarGCNError):
+        DeviceBatchSampler(res, 4, recon_candidates={"actor": cand})
 
 
 def test_device_batch_equals_host_batch():

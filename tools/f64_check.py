@@ -344,13 +344,15 @@ def _rel_rows(got_block, ref_full, lo, hi):
 
 
 def verify_step_partitioned(net, run_step, graph_arrays, y, scale, lo, hi, n_user, assemble_rows, reduce_scalar,
-                            name_user="user", name_item="movie"):
+                            name_user="user", name_item="movie", one_at_a_time=None):
     """One rank's view of a node-partitioned step against the float64 evaluation of the definition over the WHOLE graph.
 
     net: this rank's network (user table = rows [lo, hi) of the global one, everything else replicated); run_step() runs
     one partitioned step INCLUDING the gradient all-reduce of the replicated parameters and returns the local loss.
     graph_arrays / y: the whole graph, as for verify_step.  assemble_rows(block) -> (n_user, width) matrix made of every
     rank's row block; reduce_scalar(t) -> sum over ranks (both are collectives: every rank calls them in the same order).
+    one_at_a_time(fn) -> fn(): optional turnstile that lets ONE rank at a time through the float64 evaluation (ranks that share a
+    GPU over gloo: eight processes time-slicing one device made the evaluation 40x slower than eight turns).
     Compared on every rank: the loss, item-side layer outputs / projection (replicated: all rows), this rank's user rows of
     every layer output / projection / embedding gradient, every replicated parameter's all-reduced gradient and the item
     embedding gradient.  The activation-derivative rule of the single-GPU check applies unchanged: the side the product
@@ -374,9 +376,16 @@ def verify_step_partitioned(net, run_step, graph_arrays, y, scale, lo, hi, n_use
     for l in range(len(cap.layer_out)):          # same order on every rank
         cap.layer_out[l]["user"] = assemble_rows(block["layer"][l])
         cap.agg_out[l]["user"] = assemble_rows(block["agg"][l])
-    g = RawGraph(*graph_arrays)
-    assert g.n_user == n_user
-    ref = evaluate(g, params, y, scale, product=cap)
+    def _evaluate_and_compare():
+        g = RawGraph(*graph_arrays)
+        assert g.n_user == n_user
+        ref = evaluate(g, params, y, scale, product=cap)
+        return _compare_partitioned(net, cap, block, loss, ref, lo, hi, key, other)
+
+    return one_at_a_time(_evaluate_and_compare) if one_at_a_time is not None else _evaluate_and_compare()
+
+
+def _compare_partitioned(net, cap, block, loss, ref, lo, hi, key, other):
     per = {"loss": abs(float(loss) - float(ref["loss"])) / max(abs(float(ref["loss"])), 1e-30)}
     for l, lo_ in enumerate(ref["layer_out"]):
         per["layer%d.out.user[block]" % l] = _rel_rows(block["layer"][l], lo_["user"], lo, hi)
