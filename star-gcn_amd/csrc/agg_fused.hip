@@ -110,6 +110,9 @@ constexpr int NJB = ND / 32;              // 32-column blocks of the output
 #ifndef SG_FUSED_ROWPOLICY
 #define SG_FUSED_ROWPOLICY 1              // cache-policy immediate of the rows' buffer loads: 1 sc0 (ships), 0 none, 16 sc1, 2 nt
 #endif
+#ifndef SG_FUSED_SKIPB
+#define SG_FUSED_SKIPB 0                  // timing probe only (see load_b)
+#endif
 #ifndef SG_FUSED_ADB
 #define SG_FUSED_ADB 0                    // 1: the aggregate's fragments double-buffered in registers (fits only with 4 + 4 waves)
 #endif
@@ -582,9 +585,15 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
   // compiler forms one 64-bit VGPR address per unit, hoists all 32 of a level out of the loops and spills them.)  The compiler
   // does not see these loads: wait_b<N>() is the counted wait before a fragment set's first use -- N = loads issued after it.
   const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
+#if SG_FUSED_SKIPB
+  bool skip_b = false;
+#endif
   auto load_b = [&](f16x8 (&bf)[2], int r, int j, int ks) __attribute__((always_inline)) {
     if (a.ablate & 64) r = 0;       // (timing: every level multiplies by level 0's planes -- 256 KB that stay in the L2s)
     const char* ub = a.wplanes + ((((static_cast<long long>(r) * NJB + wn * NJ + j) * KS + ks) * 2) << 10);
+#if SG_FUSED_SKIPB                  // (timing probe, tools/r6_fused_skipb.sh: every second tile of a workgroup reads ONE 2 KB unit for all its
+    if (skip_b) ub = a.wplanes;     //  fragments -- what a 128-row tile, i.e. half the plane bytes per row, could save at best; results are wrong)
+#endif
 #if SG_FUSED_ASMLOAD
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(bf[0]) : "v"(lane16), "s"(ub) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(bf[1]) : "v"(lane16), "s"(ub) : "memory");
@@ -688,6 +697,9 @@ __global__ __launch_bounds__(64 * (GW + MW), 1) void agg_contract_kernel(const A
   for (int ti = 0; ti < n_my; ++ti) {
     const int tile = tile_of(slot_of(ti));
     const long long row0 = static_cast<long long>(tile) * TM;
+#if SG_FUSED_SKIPB
+    skip_b = (ti & 1) != 0;
+#endif
     if (has_bias) {       // this tile's support row sums -> LDS (each M wave a share; the level barriers publish them)
       float* dst = rs_lds + (ti & 1) * TM * a.R;
       const int cnt = TM * a.R;
