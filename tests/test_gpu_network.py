@@ -52,7 +52,10 @@ def extract(net, dtype=torch.float64):
 
 
 @pytest.mark.parametrize("accum,agg_units,order", [("sum", 250, "auto"), ("stack", 250, "auto"),
-                                                  ("sum", 60, "aggregate_first"), ("stack", 60, "transform_first")])
+                                                  ("sum", 60, "aggregate_first"), ("stack", 60, "transform_first"),
+                                                  # round 6: the fused aggregate -> contract kernel at the shipped widths
+                                                  # (embed 32 -> AGG 250; 'stack' = 5 x 50 units), whole network, all gradients
+                                                  ("sum", 250, "fused"), ("stack", 250, "fused")])
 def test_two_block_star_gcn_matches_dense_oracle(accum, agg_units, order):
     import star_gcn_amd.model as M
     import star_gcn_amd.synthetic as S
@@ -202,8 +205,9 @@ def test_layer_api_with_reference_style_lists():
     rel_close(out, ref, 1e-5, "GCNAggregator")
 
 
-@pytest.mark.parametrize("shape,embed,batch", [("ml-100k", 64, 10000), ("ml-1m", 128, 100000)])
-def test_two_block_star_gcn_at_baseline_config_sizes(shape, embed, batch):
+@pytest.mark.parametrize("shape,embed,batch,order", [("ml-100k", 64, 10000, "auto"), ("ml-1m", 128, 100000, "auto"),
+                                                     ("ml-100k", 64, 10000, "fused")])
+def test_two_block_star_gcn_at_baseline_config_sizes(shape, embed, batch, order):
     """BASELINE configs 2 and 3 (MovieLens-100k dim 64 / MovieLens-1M dim 128, 5 rating levels): the real 2-block
     network with the shipped yaml widths (AGG 250, OUT 75, mask 0.1, recon lambda 0.1, symmetric support, rating
     mini-batch) on the full-size synthetic graph, vs the float64 oracle with sparse float64 adjacency."""
@@ -215,7 +219,7 @@ def test_two_block_star_gcn_at_baseline_config_sizes(shape, embed, batch):
     rng = np.random.default_rng(1)
     torch.manual_seed(3)
     net = M.Net(graph, U, I, embed_units=embed, agg_units=(250,), out_units=(75,), nblocks=2, use_dae=True,
-                agg_accum="sum").to(dev)
+                agg_accum="sum", agg_order=order).to(dev)
     noise, recon = {}, {}
     for key, n in ((U, nu), (I, ni)):
         perm = rng.permutation(n).astype(np.int32)
