@@ -51,15 +51,14 @@ namespace f16x3 {
 // holds op(X)[row = 32 rb + (lane & 31)][k = 16 ks + 8 (lane >> 5) + 0..7]  (the operand layout of v_mfma_f32_32x32x16_f16).
 // One workgroup converts 32 rows x 64 k: coalesced 128-byte row segments in, a [row][k] tile in LDS, 1 KiB units out.
 // ---------------------------------------------------------------------------------------------------------------------
+// (rb: 32-row block of the operand, kb: 64-k block; the kernels below map their grids onto them)
 template <bool RC>
-__global__ __launch_bounds__(256) void split_kernel(char* __restrict__ planes, int* __restrict__ expo,
-                                                    const float* __restrict__ p, long long ld, int R, int K, int KS, int vec,
-                                                    int* __restrict__ clear_flag) {
+__device__ __forceinline__ void split_block(char* __restrict__ planes, int* __restrict__ expo, const float* __restrict__ p,
+                                            long long ld, int R, int K, int KS, int vec, int rb, int kb) {
   __shared__ float tile[32][65];
   __shared__ float wmax[4];
   const int t = threadIdx.x;
-  if (clear_flag && t == 0 && blockIdx.x == 0 && blockIdx.y == 0) *clear_flag = 0;      // the exactness flag of gemm_x3w.hip
-  const int rb = blockIdx.x, k0 = blockIdx.y * 64;
+  const int k0 = kb * 64;
   const int r0 = rb * 32;
   float m = 0.f;
   if (!RC) {            // element (r, k) at p[r * ld + k]: thread = (row t/8, 4 consecutive k), two passes of 32 k
@@ -137,7 +136,7 @@ __global__ __launch_bounds__(256) void split_kernel(char* __restrict__ planes, i
     e = min(max(e, -126), 126);
   }
   const float s = __uint_as_float(static_cast<unsigned>(127 + e) << 23);
-  if (t == 0) expo[static_cast<long long>(rb) * (KS >> 2) + blockIdx.y] = -e;
+  if (t == 0) expo[static_cast<long long>(rb) * (KS >> 2) + kb] = -e;
   // thread -> unit: k step ks = t / 64 of this block's four, lane = t % 64
   const int lane = t & 63, ks = t >> 6;
   const int row = lane & 31, kk = ks * 16 + (lane >> 5) * 8;
@@ -160,6 +159,25 @@ __global__ __launch_bounds__(256) void split_kernel(char* __restrict__ planes, i
   uint4* out = reinterpret_cast<uint4*>(planes) + u * 64 + lane;
   out[0] = make_uint4(h1[0], h1[1], h1[2], h1[3]);
   out[64] = make_uint4(h2[0], h2[1], h2[2], h2[3]);
+}
+
+template <bool RC>
+__global__ __launch_bounds__(256) void split_kernel(char* __restrict__ planes, int* __restrict__ expo,
+                                                    const float* __restrict__ p, long long ld, int R, int K, int KS, int vec,
+                                                    int* __restrict__ clear_flag) {
+  if (clear_flag && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) *clear_flag = 0;      // the exactness flag of gemm_x3w.hip
+  split_block<RC>(planes, expo, p, ld, R, K, KS, vec, blockIdx.x, blockIdx.y);
+}
+
+// BOTH operands of a plane-kernel product in one launch (they share K): blocks [0, rbA) of the grid's x convert A, the rest B.
+// One launch instead of two: the ML-10M step has nine such products of 5 us conversions each (profiles/r6_ml10m_step_timeline.md).
+struct SplitOp {
+  char* planes; int* expo; const float* p; long long ld; int R; int vec;
+};
+template <bool RCA, bool RCB>
+__global__ __launch_bounds__(256) void split2_kernel(SplitOp a, SplitOp b, int rbA, int K, int KS) {
+  if (static_cast<int>(blockIdx.x) < rbA) split_block<RCA>(a.planes, a.expo, a.p, a.ld, a.R, K, KS, a.vec, blockIdx.x, blockIdx.y);
+  else split_block<RCB>(b.planes, b.expo, b.p, b.ld, b.R, K, KS, b.vec, blockIdx.x - rbA, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1124,8 +1142,16 @@ int launch_gemm_f16x3(const GemmArgs& g_in, bool transA, bool transB, char* scra
     *reduced = true;
     return SG_OK;
   }
-  split(pa, ea, g.A, g.lda, transA, g.M, Mp, g.vecA, nullptr);
-  split(pb, eb, g.B, g.ldb, !transB, g.N, Np, g.vecB, nullptr);
+  {     // both operands in ONE conversion launch
+    const SplitOp sa{pa, ea, g.A, g.lda, g.M, g.vecA}, sb{pb, eb, g.B, g.ldb, g.N, g.vecB};
+    const int rbA = static_cast<int>(Mp / 32);
+    const dim3 grid(static_cast<unsigned>(rbA + Np / 32), static_cast<unsigned>(Kp / 64));
+    const bool rca = transA, rcb = !transB;
+    if (rca && rcb) hipLaunchKernelGGL((split2_kernel<true, true>), grid, dim3(256), 0, st, sa, sb, rbA, g.K, KS);
+    else if (rca) hipLaunchKernelGGL((split2_kernel<true, false>), grid, dim3(256), 0, st, sa, sb, rbA, g.K, KS);
+    else if (rcb) hipLaunchKernelGGL((split2_kernel<false, true>), grid, dim3(256), 0, st, sa, sb, rbA, g.K, KS);
+    else hipLaunchKernelGGL((split2_kernel<false, false>), grid, dim3(256), 0, st, sa, sb, rbA, g.K, KS);
+  }
   PlaneArgs pl{pa, pb, ea, eb, KS, nullptr};
   // variant: short K slices are dominated by the epilogue (two workgroups per CU overlap it); long ones by DMA latency
   const int ktiles32 = (g.K + 31) / 32;
